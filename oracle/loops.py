@@ -1,0 +1,91 @@
+"""CPU restatement of the three train_epoch / validate pairs (the measured unit)."""
+import torch
+
+from .losses import concordance_index_np, cox_loss, gate_entropy_loss, neg_partial_log_likelihood
+
+
+def train_epoch_final(model, loader, optimizer, device):
+    """final_multimodal.py:238-265: Cox on the whole batch, no label mask."""
+    model.train()
+    total, nb = 0.0, 0
+    for batch in loader:
+        ct, rna, clin = batch['image'].to(device), batch['rnaseq'].to(device), batch['clinical'].to(device)
+        label = batch['label'].to(device)
+        time, event = label[:, 0], label[:, 1]
+        hazard = model(ct, rna, clin)
+        loss = cox_loss(hazard, event, time)
+        optimizer.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        optimizer.step()
+        total += loss.item()
+        nb += 1
+    return total / nb if nb > 0 else 0
+
+
+def validate_final(model, loader, device):
+    """final_multimodal.py:268-305 (C-index by the fallback counting rule, not the lifelines call)."""
+    model.eval()
+    total, nb = 0.0, 0
+    hs, ts, es = [], [], []
+    with torch.no_grad():
+        for batch in loader:
+            ct, rna, clin = batch['image'].to(device), batch['rnaseq'].to(device), batch['clinical'].to(device)
+            label = batch['label'].to(device)
+            time, event = label[:, 0], label[:, 1]
+            hazard = model(ct, rna, clin)
+            total += cox_loss(hazard, event, time).item()
+            nb += 1
+            hs.extend(hazard.cpu().numpy()); ts.extend(time.cpu().numpy()); es.extend(event.cpu().numpy())
+    return (total / nb if nb > 0 else 0), concordance_index_np(hs, es, ts)
+
+
+def train_epoch_partial(model, loader, optimizer, device, gate_entropy_weight=0.01):
+    """partial_modality_training.py:382-435."""
+    model.train()
+    tot_cox, tot_ent, n_surv, nb = 0.0, 0.0, 0, 0
+    for batch in loader:
+        ct, rna, clin = batch['image'].to(device), batch['rnaseq'].to(device), batch['clinical'].to(device)
+        label, mask = batch['label'].to(device), batch['mask'].to(device)
+        hazard, gate = model(ct, rna, clin, mask)
+        smask = torch.as_tensor(batch['has_survival'], dtype=torch.bool, device=device)
+        c_loss = torch.tensor(0.0, device=device)
+        if smask.sum() > 0:
+            h, t, e = hazard[smask], label[smask, 0], label[smask, 1]
+            if h.shape[0] >= 2 and e.sum() > 0:
+                c_loss = cox_loss(h, e, t)
+                tot_cox += c_loss.item()
+                n_surv += 1
+        e_loss = gate_entropy_loss(gate)
+        tot_ent += e_loss.item()
+        loss = c_loss + gate_entropy_weight * e_loss
+        optimizer.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        optimizer.step()
+        nb += 1
+    return (tot_cox / n_surv if n_surv > 0 else 0), (tot_ent / nb if nb > 0 else 0)
+
+
+def train_epoch_simple(model, loader, optimizer, device):
+    """simple_fusion.py:242-279 (both `continue`s kept, the second one after the forward)."""
+    model.train()
+    total, nb = 0.0, 0
+    for batch in loader:
+        image, rnaseq = batch['image'].to(device), batch['rnaseq'].to(device)
+        time, event = batch['time'].squeeze().to(device), batch['event'].squeeze().to(device)
+        smask = torch.as_tensor(batch['has_survival'], dtype=torch.bool, device=device)
+        if smask.sum() < 2:
+            continue
+        optimizer.zero_grad()
+        lh = model(image, rnaseq)
+        lh_s, t_s, e_s = lh[smask], time[smask], event[smask].bool()
+        if e_s.sum() == 0:
+            continue
+        loss = neg_partial_log_likelihood(lh_s, e_s, t_s)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        optimizer.step()
+        total += loss.item()
+        nb += 1
+    return total / nb if nb > 0 else 0.0
