@@ -1,0 +1,211 @@
+/* mmsurv.h -- C ABI of libmmsurv_hip.so: the MI355X (gfx950) implementation of the training hot path of
+ * baek0203/multimodal_survival_prediction (per-batch forward/backward of the multimodal survival networks +
+ * Cox partial likelihood).
+ *
+ * The reference has no FFI of its own: its boundary is the Python surface of scripts/training/*.py
+ * (SURVEY.md section 8b).  Every entry point below replaces a torch/MONAI/torchsurv op sequence invoked from
+ * that surface; the replaced call site is cited per function as R/<file>:<line> (R = the reference repo).
+ *
+ * Conventions
+ *   - plain C: raw device pointers, sizes, POD parameter blocks; no torch/HIP C++ types in signatures
+ *     (hipStream_t is an opaque pointer);
+ *   - the CALLER owns every buffer (PyTorch caching allocator in the shipped host code); nothing here
+ *     allocates, frees or synchronises; all work is enqueued on the given stream, so the calls are legal
+ *     inside hipStreamBeginCapture/EndCapture;
+ *   - return 0 on success, negative on error (MMS_ERR_*); never throws;
+ *   - activations are channels-last fp32 matrices [rows = B*D*H*W][channels] ("slabs"); a dense block's
+ *     torch.cat is a column offset into its slab;
+ *   - BatchNorm batch statistics travel as fp64 (sum, sumsq) accumulators that the producer kernel's
+ *     epilogue fills with atomics; they must be zeroed (hipMemsetAsync) once per step by the caller.
+ */
+#ifndef MMSURV_H
+#define MMSURV_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifndef HIP_INCLUDE_HIP_HIP_RUNTIME_API_H
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#define MMS_OK 0
+#define MMS_ERR_ARG (-1)
+#define MMS_ERR_LAUNCH (-2)
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct Dims3 { int D; int H; int W; } Dims3;
+
+/* BatchNorm parameter source. train=1: batch statistics from the fp64 accumulators; train=0: running stats.
+ * (torch BatchNorm3d/1d, eps 1e-5, momentum 0.1: R/scripts/training/final_multimodal.py:77-96; MONAI norm="batch") */
+typedef struct BnSrc {
+    const double* sum;     /* [C] batch sum      (train) */
+    const double* sumsq;   /* [C] batch sum x^2  (train) */
+    const float* rmean;    /* [C] running mean   (eval)  */
+    const float* rvar;     /* [C] running var    (eval)  */
+    const float* gamma;    /* [C] */
+    const float* beta;     /* [C] */
+    float inv_count;       /* 1 / rows the statistics were taken over */
+    float eps;
+    int train;
+} BnSrc;
+
+
+// ---- 1x1x1 conv (dense-layer conv1, transition conv): y = relu(bn(x)) [avg-pooled 2x2x2] @ W^T -------
+typedef struct Conv1FwdP {
+    const float* x; int ldx;        // input slab [Min][ldx], first K columns used
+    int M;                          // output rows (pooled rows when pool=1)
+    int K;                          // input channels (multiple of 32)
+    const float* w;                 // [N][K] (torch Conv3d weight (N,K,1,1,1))
+    int N;
+    float* y; int ldy;              // output [M][ldy] (column offset already applied)
+    BnSrc bn;                       // over the K input channels
+    double* osum; double* osumsq;   // [N] batch-stat accumulators of y (nullptr in eval)
+    int pool;                       // 1: AvgPool3d(2,2) of relu(bn(x)) before the GEMM (== conv then pool)
+    Dims3 in;                       // input grid (pool=1)
+} Conv1FwdP;
+
+// ---- 3x3x3 conv, pad 1 (dense-layer conv2): slab[:, coff:coff+32] = conv3(relu(bn(y1)), W) ---------------
+typedef struct Conv3FwdP {
+    const float* y1;                // [M][128]
+    const int* coords;              // [M] packed (d,h,w)
+    Dims3 g; int M;
+    const float* wp;                // packed [32][27][128]  (cout, tap, cin)
+    float* out; int ldo;            // slab + coff, row pitch
+    BnSrc bn;                       // over 128 channels of y1
+    double* osum; double* osumsq;   // [32] (nullptr in eval)
+} Conv3FwdP;
+
+// ---- conv0: Conv3d(1,64,k7,s2,p3,no bias) -------------------------------------------------------------
+typedef struct Conv0FwdP {
+    const float* x;                 // [B][D][H][W]
+    Dims3 in; Dims3 out;            // out = ceil(in/2)
+    const int* coords;              // [M0] packed (od,oh,ow)
+    int M;                          // B*out voxels
+    const float* w;                 // [64][343]
+    float* y;                       // [M][64]
+    double* osum; double* osumsq;   // [64]
+} Conv0FwdP;
+
+// ---- bn0 + relu + MaxPool3d(3,2,1) -> slab1[:, 0:64] -----------------------------------------------------
+typedef struct PoolFwdP {
+    const float* y0; Dims3 in;      // [B*in][64]
+    Dims3 out; int B;
+    float* slab; int ld;            // [B*out][ld]
+    uint8_t* argmax;                // [B*out][64] tap index 0..26 of the first maximum (torch scan order)
+    BnSrc bn;
+    double* osum; double* osumsq;   // [64] stats of the pooled output (nullptr in eval)
+} PoolFwdP;
+
+// ---- norm5 + relu + global-avg-pool + Linear(1024,128) ---------------------------------------------------
+typedef struct HeadFwdP {
+    const float* slab; int ld; int C; int B; int V;   // [B*V][ld], C channels, V voxels per sample
+    BnSrc bn;
+    const float* w; const float* bias; int N;          // [N][C]
+    float* pooled;                                     // [B][C] saved for backward
+    float* out;                                        // [B][N]
+} HeadFwdP;
+
+// =========================== backward ==================================================================
+// BatchNorm backward constants of one layer: sums accumulated by the producer of dbn.
+typedef struct BnBwd {
+    const double* s1;      // [C] sum_m dbn
+    const double* s2;      // [C] sum_m dbn * xhat
+} BnBwd;
+
+// conv3 backward-data: dbn2 = (dz (*) W^T) * [a2 > 0], plus BN2-backward sums
+typedef struct Conv3BwdDataP {
+    const float* dz; int lddz;      // dslab + coff  [M][lddz], 32 columns
+    const int* coords; Dims3 g; int M;
+    const float* wpb;               // packed [128][27][32] (cin, tap, cout)
+    const float* y1;                // [M][128] forward pre-BN activations
+    BnSrc bn;                       // bn2
+    float* dbn;                     // [M][128] out
+    double* s1; double* s2;         // [128] out (atomics)
+} Conv3BwdDataP;
+
+// conv3 backward-weight: dW[cout][cin][tap] += sum_m relu(bn(y1))[nbr(m,tap)][cin] * dz[m][cout]
+typedef struct Conv3BwdWP {
+    const float* y1; const int* coords; Dims3 g; int M;
+    BnSrc bn;
+    const float* dz; int lddz;
+    float* dw;                      // canonical torch layout [32][128][27], accumulated with atomics
+    int msplit;                     // grid.z = 27 * msplit
+} Conv3BwdWP;
+
+// 1x1 conv backward (dense conv1 and transition conv).
+//   dy[m][n]  = g2[n]*rstd2[n]*(dbn2[m][n] - s1[n]/M - yhat[m][n]*s2[n]/M)     (has_bn_out=1)
+//             = dyraw[m][n]                                                     (has_bn_out=0, transition)
+//   dW[n][k] += sum_m dy[m][n] * a[m][k],   a = relu(bn_in(x)) [avg-pooled]
+//   da[m][k]  = sum_n dy[m][n] * W[n][k];   dbn_in = da * [a>0] (un-pooled /8 when pool) ; sums s1,s2 over k
+typedef struct Conv1BwdP {
+    // output-side gradient
+    const float* dyraw; int lddy;   // [M][lddy]: dbn2 (has_bn_out) or dslab_next (transition)
+    const float* y; int ldy;        // forward output of this conv (pre-BN2), needed when has_bn_out
+    BnSrc bn_out; BnBwd bb_out; int has_bn_out;
+    int M; int N;                   // rows of dy (pooled rows when pool), N output channels
+    // input side
+    const float* x; int ldx; int K; BnSrc bn_in;
+    const float* w;                 // [N][K]
+    int pool; Dims3 in;             // transition: x grid dims (rows of x = M*8)
+    float* dw;                      // [N][K] accumulated with atomics (weight kernel)
+    float* dbn; int lddbn;          // [Mx][lddbn] out (data kernel), Mx = M*(pool?8:1)
+    double* s1; double* s2;         // [K] out (data kernel)
+    int msplit;
+} Conv1BwdP;
+
+// dslab[:, 0:C] (+)= g*rstd*(dbn - s1/M - xhat*s2/M)
+typedef struct BnBwdApplyP {
+    const float* dbn; int lddbn;
+    const float* x; int ldx;
+    float* dx; int lddx;
+    int M; int C; BnSrc bn; BnBwd bb; int accumulate;
+    float* dgamma; float* dbeta;    // [C] written by block 0 (dgamma = s2, dbeta = s1)
+} BnBwdApplyP;
+
+typedef struct HeadBwdP {
+    const float* dout;              // [B][N]
+    const float* pooled;            // [B][C]
+    const float* slab; int ld; int C; int B; int V; BnSrc bn;
+    const float* w; int N;
+    float* dw; float* dbias;        // [N][C], [N]
+    float* dgamma; float* dbeta;    // [C]
+    float* dslab; int ldd;          // [B*V][ldd] first C columns written
+} HeadBwdP;
+
+typedef struct PoolBwdP {                   // maxpool backward + relu0 mask -> dbn0, sums
+    const float* dslab; int ld;     // [B*out][ld] first 64 columns
+    const uint8_t* argmax; Dims3 out; Dims3 in; int B;
+    const float* y0; BnSrc bn;
+    float* dbn;                     // [B*in][64]
+    double* s1; double* s2;         // [64]
+} PoolBwdP;
+
+typedef struct Conv0BwdWP {                 // dW0[64][343] += sum_m bn0bwd(dbn0)[m][n] * x[patch(m,k)]
+    const float* dbn; const float* y0; BnSrc bn; BnBwd bb;
+    const float* x; Dims3 in; Dims3 out; const int* coords; int M;
+    float* dw; int msplit;
+    float* dgamma; float* dbeta;    // [64]
+} Conv0BwdWP;
+
+/* ---- ABI self-description ---- */
+int mms_abi_sizeof(const char* name);      /* sizeof(struct <name>) as compiled, -1 if unknown */
+int mms_abi_version(void);
+
+/* ---- DenseNet121-3D ops (MONAI DenseNet121(spatial_dims=3,in_channels=1,out_channels=128) at
+ *      R/scripts/training/final_multimodal.py:66-71, partial_modality_training.py:171-176, simple_fusion.py:182-187) */
+int mms_init_coords(int* coords, int B, int D, int H, int W, hipStream_t s);
+int mms_conv0_fwd(const Conv0FwdP* p, hipStream_t s);          /* features.conv0 */
+int mms_pool_fwd(const PoolFwdP* p, hipStream_t s);            /* features.norm0/relu0/pool0 */
+int mms_conv1_fwd(const Conv1FwdP* p, hipStream_t s);          /* denselayer norm1/relu1/conv1; transition norm/relu/conv/pool */
+int mms_conv3_fwd(const Conv3FwdP* p, hipStream_t s);          /* denselayer norm2/relu2/conv2 + torch.cat */
+int mms_head_fwd(const HeadFwdP* p, hipStream_t s);            /* features.norm5 + class_layers */
+int mms_pack_conv3(const float* w, float* wpf, float* wpb, hipStream_t s);
+int mms_pack_conv3_table(const void* table_dev, int nlayers, hipStream_t s);
+int mms_bn_running_update(const void* table_dev, int n, float momentum, hipStream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMSURV_H */

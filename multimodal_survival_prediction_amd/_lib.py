@@ -1,0 +1,97 @@
+"""ctypes binding of libmmsurv_hip.so.  Structure layouts and prototypes are parsed from include/mmsurv.h,
+the single source of truth for the C ABI (no hand-mirrored layouts)."""
+import ctypes
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(HERE), "include", "mmsurv.h")
+_LIB = None
+_STRUCTS = {}
+_PROTOS = {}
+
+_SCALARS = {"int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double,
+            "uint32_t": ctypes.c_uint32, "uint64_t": ctypes.c_uint64, "int64_t": ctypes.c_int64,
+            "size_t": ctypes.c_size_t, "long long": ctypes.c_longlong, "unsigned": ctypes.c_uint,
+            "hipStream_t": ctypes.c_void_p}
+
+
+def lib_path():
+    return os.path.join(HERE, "libmmsurv_hip.so")
+
+
+def _strip_comments(s):
+    s = re.sub(r"/\*.*?\*/", "", s, flags=re.S)
+    return re.sub(r"//[^\n]*", "", s)
+
+
+def _ctype(tstr):
+    t = tstr.replace("const", "").strip()
+    if "*" in t:
+        return ctypes.c_void_p
+    t = " ".join(t.split())
+    if t in _SCALARS:
+        return _SCALARS[t]
+    if t in _STRUCTS:
+        return _STRUCTS[t]
+    raise KeyError("unknown C type %r in mmsurv.h" % tstr)
+
+
+def parse_header(path=HEADER):
+    """-> (structs: name -> ctypes.Structure subclass, protos: name -> [arg type strings])."""
+    src = _strip_comments(open(path).read())
+    for m in re.finditer(r"typedef\s+struct\s+(\w+)\s*\{(.*?)\}\s*(\w+)\s*;", src, flags=re.S):
+        name, body = m.group(1), m.group(2)
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            mm = re.match(r"(.*?)(\w+)$", decl, flags=re.S)
+            fields.append((mm.group(2), _ctype(mm.group(1))))
+        _STRUCTS[name] = type(name, (ctypes.Structure,), {"_fields_": fields})
+    for m in re.finditer(r"\bint\s+(mms_\w+)\s*\((.*?)\)\s*;", src, flags=re.S):
+        args = [a.strip() for a in m.group(2).split(",") if a.strip() and a.strip() != "void"]
+        _PROTOS[m.group(1)] = [re.match(r"(.*?)(\w+)$", a, flags=re.S).group(1) for a in args]
+    return _STRUCTS, _PROTOS
+
+
+def structs():
+    if not _STRUCTS:
+        parse_header()
+    return _STRUCTS
+
+
+def protos():
+    if not _PROTOS:
+        parse_header()
+    return _PROTOS
+
+
+def load_library():
+    """Load the HIP library; raises (never falls back) when it is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "libmmsurv_hip.so not found at %s -- build it with `python -m multimodal_survival_prediction_amd._build` "
+            "(or __graft_entry__.build()).  There is no CPU fallback for the hot path." % path)
+    lib = ctypes.CDLL(path)
+    parse_header()
+    for name, args in _PROTOS.items():
+        fn = getattr(lib, name)   # AttributeError here == header/library mismatch
+        fn.restype = ctypes.c_int
+        fn.argtypes = [_ctype(a) for a in args]
+    _LIB = lib
+    return lib
+
+
+class MmsError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        raise MmsError("%s failed with code %d (%s)" % (what, rc, {-1: "bad argument", -2: "launch error"}.get(rc, "?")))

@@ -1,0 +1,11 @@
+// ABI self-description: lets the host check that its view of include/mmsurv.h matches the compiled library.
+#include "common.h"
+#include <string.h>
+
+#define SZ(T) if (strcmp(name, #T) == 0) return (int)sizeof(T);
+extern "C" int mms_abi_sizeof(const char* name) {
+    SZ(Dims3) SZ(BnSrc) SZ(BnBwd) SZ(Conv1FwdP) SZ(Conv3FwdP) SZ(Conv0FwdP) SZ(PoolFwdP) SZ(HeadFwdP)
+    SZ(Conv3BwdDataP) SZ(Conv3BwdWP) SZ(Conv1BwdP) SZ(BnBwdApplyP) SZ(HeadBwdP) SZ(PoolBwdP) SZ(Conv0BwdWP)
+    return -1;
+}
+extern "C" int mms_abi_version(void) { return 1; }

@@ -1,0 +1,81 @@
+// Shared device helpers for the mmsurv gfx950 kernels (CDNA4, wave64, fp32-input MFMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mmsurv.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+
+// mean / rstd of channel c.  The batch variance is the biased one (what torch normalises with).
+__device__ __forceinline__ void bn_mean_rstd(const BnSrc& b, int c, float& mean, float& rstd) {
+    if (b.train) {
+        double m = b.sum[c] * (double)b.inv_count;
+        double v = b.sumsq[c] * (double)b.inv_count - m * m;
+        v = v > 0.0 ? v : 0.0;
+        mean = (float)m;
+        rstd = (float)(1.0 / sqrt(v + (double)b.eps));
+    } else {
+        mean = b.rmean[c];
+        rstd = 1.0f / sqrtf(b.rvar[c] + b.eps);
+    }
+}
+
+// y = (x - mean) * (gamma*rstd) + beta, the centred form torch uses (no large-mean cancellation).
+__device__ __forceinline__ float bn_apply(float x, float mean, float sc, float beta) {
+    return fmaf(x - mean, sc, beta);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block-wide sum of a double over 256 threads; result valid in every thread. red: >= 4 doubles of LDS.
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+    v = wave_sum_d(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += red[i];
+    return r;
+}
+
+// Voxel coordinate table entry: (d, h, w) packed 10 bits each + batch index in the high bits is not needed
+// (neighbours never cross a sample: bounds are checked per axis).
+__device__ __forceinline__ int pack_dhw(int d, int h, int w) { return (d << 20) | (h << 10) | w; }
+__device__ __forceinline__ void unpack_dhw(int c, int& d, int& h, int& w) {
+    d = c >> 20; h = (c >> 10) & 1023; w = c & 1023;
+}
+
+
+// dropout keep-mask from a counter hash (perf mode).  Parity mode passes an explicit mask instead.
+__device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float dropout_scale(uint32_t seed, uint32_t stream, uint32_t idx, float p) {
+    // returns 0 (dropped) or 1/(1-p) (kept)
+    uint32_t h = hash_u32(idx * 0x9E3779B9U + hash_u32(seed ^ (stream * 0x85ebca6bU)));
+    float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+    return u < p ? 0.0f : 1.0f / (1.0f - p);
+}
+
+static inline int mms_check_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MMS_OK : MMS_ERR_LAUNCH;
+}

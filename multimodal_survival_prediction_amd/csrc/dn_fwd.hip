@@ -1,0 +1,374 @@
+// DenseNet121-3D forward ops for gfx950: fused BN+ReLU prologues, fp32 MFMA contractions, batch-statistic
+// epilogues.  Replaces the torch/MIOpen op sequence behind MONAI's DenseNet121 at the reference call sites
+// final_multimodal.py:66-71, partial_modality_training.py:171-176, simple_fusion.py:182-187.
+#include "dn_ops.h"
+#include "tile_gemm.h"
+
+// ------------------------------------------------------------------------------------------------------
+// shared epilogue pieces
+// ------------------------------------------------------------------------------------------------------
+template <int TM, int TN>
+__device__ __forceinline__ void store_tile(float* y, int ldy, int M, int N, int m0, int n0, const float* Cs, int tid) {
+    for (int idx = tid; idx < TM * TN; idx += 256) {
+        int r = idx / TN, c = idx % TN, m = m0 + r, n = n0 + c;
+        if (m < M && n < N) y[(size_t)m * ldy + n] = Cs[r * (TN + 1) + c];
+    }
+}
+template <int TM, int TN>
+__device__ __forceinline__ void tile_col_stats(double* osum, double* osumsq, int M, int N, int m0, int n0,
+                                               const float* Cs, int tid) {
+    if (osum == nullptr || tid >= TN) return;
+    int n = n0 + tid;
+    if (n >= N) return;
+    double s = 0, q = 0;
+    int rows = M - m0 < TM ? M - m0 : TM;
+    for (int r = 0; r < rows; ++r) {
+        double v = Cs[r * (TN + 1) + tid];
+        s += v; q += v * v;
+    }
+    atomicAdd(&osum[n], s);
+    atomicAdd(&osumsq[n], q);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// 1x1x1 conv
+// ------------------------------------------------------------------------------------------------------
+template <int WM_, int WN_, int WK_, bool POOL>
+struct Conv1FwdOp {
+    typedef Conv1FwdP Params;
+    static constexpr int WM = WM_, WN = WN_, WK = WK_, AMODE = LD_K4, BMODE = LD_K4;
+    static constexpr int TM = 32 * WM, TN = 32 * WN;
+    static constexpr int EXTRA = 3 * 1024 + TM;
+    const float *mean, *sc, *beta;
+    const int* srcbase;
+    int m0;
+    __device__ void setup(const Params& p, int m0_, int, int, float* extra, int tid) {
+        mean = extra; sc = extra + 1024; beta = extra + 2048; srcbase = (const int*)(extra + 3072); m0 = m0_;
+        for (int c = tid; c < p.K; c += 256) {
+            float mu, rstd;
+            bn_mean_rstd(p.bn, c, mu, rstd);
+            extra[c] = mu; extra[1024 + c] = p.bn.gamma[c] * rstd; extra[2048 + c] = p.bn.beta[c];
+        }
+        if (POOL && tid < TM) {
+            int m = m0 + tid, base = -1;
+            if (m < p.M) {
+                int D2 = p.in.D >> 1, H2 = p.in.H >> 1, W2 = p.in.W >> 1, vox2 = D2 * H2 * W2;
+                int b = m / vox2, r = m % vox2, d = r / (H2 * W2), h = (r / W2) % H2, w = r % W2;
+                base = ((b * p.in.D + 2 * d) * p.in.H + 2 * h) * p.in.W + 2 * w;
+            }
+            ((int*)extra)[3072 + tid] = base;
+        }
+    }
+    __device__ void krange(const Params& p, int, int& kb, int& ke) { kb = 0; ke = p.K; }
+    __device__ float4 act4(const float4 v, int k) const {
+        float4 r;
+        r.x = fmaxf(bn_apply(v.x, mean[k], sc[k], beta[k]), 0.f);
+        r.y = fmaxf(bn_apply(v.y, mean[k + 1], sc[k + 1], beta[k + 1]), 0.f);
+        r.z = fmaxf(bn_apply(v.z, mean[k + 2], sc[k + 2], beta[k + 2]), 0.f);
+        r.w = fmaxf(bn_apply(v.w, mean[k + 3], sc[k + 3], beta[k + 3]), 0.f);
+        return r;
+    }
+    __device__ float4 a_k4(const Params& p, int m, int k) const {
+        if (m >= p.M || k >= p.K) return make_float4(0, 0, 0, 0);
+        if (!POOL) return act4(*(const float4*)(p.x + (size_t)m * p.ldx + k), k);
+        const int base = srcbase[m - m0], HW = p.in.H * p.in.W, W = p.in.W;
+        float4 s = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            int src = base + (o >> 2) * HW + ((o >> 1) & 1) * W + (o & 1);
+            float4 v = act4(*(const float4*)(p.x + (size_t)src * p.ldx + k), k);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        return make_float4(s.x * 0.125f, s.y * 0.125f, s.z * 0.125f, s.w * 0.125f);
+    }
+    __device__ float4 b_k4(const Params& p, int n, int k) const {
+        if (n >= p.N || k >= p.K) return make_float4(0, 0, 0, 0);
+        return *(const float4*)(p.w + (size_t)n * p.K + k);
+    }
+    __device__ float4 a_r4(const Params&, int, int) const { return make_float4(0, 0, 0, 0); }
+    __device__ float4 b_r4(const Params&, int, int) const { return make_float4(0, 0, 0, 0); }
+    __device__ float a_k1(const Params&, int, int) const { return 0; }
+    __device__ float b_k1(const Params&, int, int) const { return 0; }
+    __device__ void epilogue(const Params& p, int m0_, int n0, int, const float* Cs, int tid) {
+        store_tile<TM, TN>(p.y, p.ldy, p.M, p.N, m0_, n0, Cs, tid);
+        tile_col_stats<TM, TN>(p.osum, p.osumsq, p.M, p.N, m0_, n0, Cs, tid);
+    }
+};
+
+extern "C" int mms_conv1_fwd(const Conv1FwdP* pp, hipStream_t s) {
+    const Conv1FwdP& p = *pp;
+    if (p.K % 32 != 0 || p.K > 1024 || p.ldx % 4 != 0 || p.M <= 0) return MMS_ERR_ARG;
+    if (p.pool && ((p.in.D | p.in.H | p.in.W) & 1)) return MMS_ERR_ARG;
+    // big M: 64x64 tiles, no in-workgroup K split; small M: 32x32 tiles with the 4 waves splitting K
+    const bool big = (long)p.M * p.N >= 256L * 64 * 64;
+    if (big) {
+        dim3 g((p.M + 63) / 64, (p.N + 63) / 64, 1);
+        return p.pool ? launch_tile_gemm<Conv1FwdOp<2, 2, 1, true>>(p, g, s)
+                      : launch_tile_gemm<Conv1FwdOp<2, 2, 1, false>>(p, g, s);
+    }
+    dim3 g((p.M + 31) / 32, (p.N + 31) / 32, 1);
+    return p.pool ? launch_tile_gemm<Conv1FwdOp<1, 1, 4, true>>(p, g, s)
+                  : launch_tile_gemm<Conv1FwdOp<1, 1, 4, false>>(p, g, s);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// 3x3x3 conv (pad 1): implicit GEMM, K = (tap, cin) = 27*128, one K-step per tap
+// ------------------------------------------------------------------------------------------------------
+struct Conv3FwdOp {
+    typedef Conv3FwdP Params;
+    static constexpr int WM = 1, WN = 1, WK = 4, AMODE = LD_K4, BMODE = LD_K4;
+    static constexpr int TM = 32, TN = 32;
+    static constexpr int EXTRA = 3 * 128 + 32;
+    const float *mean, *sc, *beta;
+    const int* rowc;
+    int m0;
+    __device__ void setup(const Params& p, int m0_, int, int, float* extra, int tid) {
+        mean = extra; sc = extra + 128; beta = extra + 256; rowc = (const int*)(extra + 384); m0 = m0_;
+        if (tid < 128) {
+            float mu, rstd;
+            bn_mean_rstd(p.bn, tid, mu, rstd);
+            extra[tid] = mu; extra[128 + tid] = p.bn.gamma[tid] * rstd; extra[256 + tid] = p.bn.beta[tid];
+        }
+        if (tid < 32) ((int*)extra)[384 + tid] = (m0 + tid < p.M) ? p.coords[m0 + tid] : -1;
+    }
+    __device__ void krange(const Params&, int, int& kb, int& ke) { kb = 0; ke = 27 * 128; }
+    __device__ float4 a_k4(const Params& p, int m, int k) const {
+        const int c = rowc[m - m0];
+        if (c < 0) return make_float4(0, 0, 0, 0);
+        const int tap = k >> 7, cin = k & 127;
+        const int kd = tap / 9 - 1, kh = (tap / 3) % 3 - 1, kw = tap % 3 - 1;
+        int d, h, w;
+        unpack_dhw(c, d, h, w);
+        if ((unsigned)(d + kd) >= (unsigned)p.g.D || (unsigned)(h + kh) >= (unsigned)p.g.H ||
+            (unsigned)(w + kw) >= (unsigned)p.g.W)
+            return make_float4(0, 0, 0, 0);      // zero padding is applied AFTER bn+relu
+        const int src = m + (kd * p.g.H + kh) * p.g.W + kw;
+        const float4 v = *(const float4*)(p.y1 + (size_t)src * 128 + cin);
+        float4 r;
+        r.x = fmaxf(bn_apply(v.x, mean[cin], sc[cin], beta[cin]), 0.f);
+        r.y = fmaxf(bn_apply(v.y, mean[cin + 1], sc[cin + 1], beta[cin + 1]), 0.f);
+        r.z = fmaxf(bn_apply(v.z, mean[cin + 2], sc[cin + 2], beta[cin + 2]), 0.f);
+        r.w = fmaxf(bn_apply(v.w, mean[cin + 3], sc[cin + 3], beta[cin + 3]), 0.f);
+        return r;
+    }
+    __device__ float4 b_k4(const Params& p, int n, int k) const {
+        return *(const float4*)(p.wp + (size_t)n * (27 * 128) + k);
+    }
+    __device__ float4 a_r4(const Params&, int, int) const { return make_float4(0, 0, 0, 0); }
+    __device__ float4 b_r4(const Params&, int, int) const { return make_float4(0, 0, 0, 0); }
+    __device__ float a_k1(const Params&, int, int) const { return 0; }
+    __device__ float b_k1(const Params&, int, int) const { return 0; }
+    __device__ void epilogue(const Params& p, int m0_, int n0, int, const float* Cs, int tid) {
+        store_tile<TM, TN>(p.out, p.ldo, p.M, 32, m0_, n0, Cs, tid);
+        tile_col_stats<TM, TN>(p.osum, p.osumsq, p.M, 32, m0_, n0, Cs, tid);
+    }
+};
+
+extern "C" int mms_conv3_fwd(const Conv3FwdP* pp, hipStream_t s) {
+    const Conv3FwdP& p = *pp;
+    if (p.M <= 0 || p.ldo % 4 != 0) return MMS_ERR_ARG;
+    return launch_tile_gemm<Conv3FwdOp>(p, dim3((p.M + 31) / 32, 1, 1), s);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// conv0: Conv3d(1, 64, k7, s2, p3) as implicit GEMM, K = 343 taps
+// ------------------------------------------------------------------------------------------------------
+struct Conv0FwdOp {
+    typedef Conv0FwdP Params;
+    static constexpr int WM = 2, WN = 2, WK = 1, AMODE = LD_K1, BMODE = LD_K1;
+    static constexpr int TM = 64, TN = 64;
+    static constexpr int EXTRA = 4 * 64;
+    const int* info;   // per tile row: sample offset, id0, ih0, iw0
+    int m0;
+    __device__ void setup(const Params& p, int m0_, int, int, float* extra, int tid) {
+        info = (const int*)extra; m0 = m0_;
+        if (tid < 64) {
+            int* o = (int*)extra + 4 * tid;
+            int m = m0 + tid;
+            if (m < p.M) {
+                int od, oh, ow;
+                unpack_dhw(p.coords[m], od, oh, ow);
+                int b = m / (p.out.D * p.out.H * p.out.W);
+                o[0] = b * p.in.D * p.in.H * p.in.W; o[1] = 2 * od - 3; o[2] = 2 * oh - 3; o[3] = 2 * ow - 3;
+            } else {
+                o[0] = -1; o[1] = o[2] = o[3] = 0;
+            }
+        }
+    }
+    __device__ void krange(const Params&, int, int& kb, int& ke) { kb = 0; ke = 343; }
+    __device__ float a_k1(const Params& p, int m, int k) const {
+        if (k >= 343) return 0.f;
+        const int* o = info + 4 * (m - m0);
+        if (o[0] < 0) return 0.f;
+        const int kd = k / 49, kh = (k / 7) % 7, kw = k % 7;
+        const int id = o[1] + kd, ih = o[2] + kh, iw = o[3] + kw;
+        if ((unsigned)id >= (unsigned)p.in.D || (unsigned)ih >= (unsigned)p.in.H || (unsigned)iw >= (unsigned)p.in.W)
+            return 0.f;
+        return p.x[(size_t)o[0] + ((size_t)id * p.in.H + ih) * p.in.W + iw];
+    }
+    __device__ float b_k1(const Params& p, int n, int k) const { return k < 343 ? p.w[n * 343 + k] : 0.f; }
+    __device__ float4 a_k4(const Params&, int, int) const { return make_float4(0, 0, 0, 0); }
+    __device__ float4 b_k4(const Params&, int, int) const { return make_float4(0, 0, 0, 0); }
+    __device__ float4 a_r4(const Params&, int, int) const { return make_float4(0, 0, 0, 0); }
+    __device__ float4 b_r4(const Params&, int, int) const { return make_float4(0, 0, 0, 0); }
+    __device__ void epilogue(const Params& p, int m0_, int n0, int, const float* Cs, int tid) {
+        store_tile<TM, TN>(p.y, 64, p.M, 64, m0_, n0, Cs, tid);
+        tile_col_stats<TM, TN>(p.osum, p.osumsq, p.M, 64, m0_, n0, Cs, tid);
+    }
+};
+
+extern "C" int mms_conv0_fwd(const Conv0FwdP* pp, hipStream_t s) {
+    const Conv0FwdP& p = *pp;
+    if (p.M <= 0) return MMS_ERR_ARG;
+    return launch_tile_gemm<Conv0FwdOp>(p, dim3((p.M + 63) / 64, 1, 1), s);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// bn0 + relu + maxpool(3,2,1): one workgroup = 32 pooled voxels x 64 channels
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const PoolFwdP p) {
+    __shared__ double red[2][4][64];
+    const int c = threadIdx.x & 63, vr = threadIdx.x >> 6;
+    float mu, rstd;
+    bn_mean_rstd(p.bn, c, mu, rstd);
+    const float sc = p.bn.gamma[c] * rstd, be = p.bn.beta[c];
+    const int vox_out = p.out.D * p.out.H * p.out.W, Mout = p.B * vox_out;
+    double s = 0, q = 0;
+    for (int it = 0; it < 8; ++it) {
+        int m = blockIdx.x * 32 + it * 4 + vr;
+        if (m >= Mout) break;
+        int b = m / vox_out, r = m % vox_out;
+        int od = r / (p.out.H * p.out.W), oh = (r / p.out.W) % p.out.H, ow = r % p.out.W;
+        float best = -INFINITY;
+        int bi = 0;
+        for (int t = 0; t < 27; ++t) {
+            int id = 2 * od - 1 + t / 9, ih = 2 * oh - 1 + (t / 3) % 3, iw = 2 * ow - 1 + t % 3;
+            if ((unsigned)id >= (unsigned)p.in.D || (unsigned)ih >= (unsigned)p.in.H || (unsigned)iw >= (unsigned)p.in.W)
+                continue;
+            size_t src = ((size_t)(b * p.in.D + id) * p.in.H + ih) * p.in.W + iw;
+            float v = fmaxf(bn_apply(p.y0[src * 64 + c], mu, sc, be), 0.f);
+            if (v > best) { best = v; bi = t; }   // strict >: first maximum in scan order wins (torch)
+        }
+        p.slab[(size_t)m * p.ld + c] = best;
+        if (p.argmax) p.argmax[(size_t)m * 64 + c] = (uint8_t)bi;
+        s += best; q += (double)best * best;
+    }
+    if (p.osum) {
+        red[0][vr][c] = s; red[1][vr][c] = q;
+        __syncthreads();
+        if (vr == 0) {
+            atomicAdd(&p.osum[c], red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+            atomicAdd(&p.osumsq[c], red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+        }
+    }
+}
+
+extern "C" int mms_pool_fwd(const PoolFwdP* pp, hipStream_t s) {
+    const PoolFwdP& p = *pp;
+    int Mout = p.B * p.out.D * p.out.H * p.out.W;
+    if (Mout <= 0) return MMS_ERR_ARG;
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3((Mout + 31) / 32), dim3(256), 0, s, p);
+    return mms_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------------
+// head: norm5 + relu + global average pool + Linear(C, N)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_fwd_kernel(const HeadFwdP p) {
+    extern __shared__ float pooled[];   // [B][C]
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < p.B * p.C; idx += 256) {
+        int b = idx / p.C, c = idx % p.C;
+        float mu, rstd;
+        bn_mean_rstd(p.bn, c, mu, rstd);
+        const float sc = p.bn.gamma[c] * rstd, be = p.bn.beta[c];
+        float a = 0;
+        for (int v = 0; v < p.V; ++v) a += fmaxf(bn_apply(p.slab[(size_t)(b * p.V + v) * p.ld + c], mu, sc, be), 0.f);
+        a /= (float)p.V;
+        pooled[idx] = a;
+        if (blockIdx.x == 0 && p.pooled) p.pooled[idx] = a;
+    }
+    __syncthreads();
+    const int n = blockIdx.x * 4 + (tid >> 6), lane = tid & 63;
+    if (n >= p.N) return;
+    for (int b = 0; b < p.B; ++b) {
+        float a = 0;
+        for (int c = lane; c < p.C; c += 64) a = fmaf(p.w[(size_t)n * p.C + c], pooled[b * p.C + c], a);
+        a = wave_sum(a);
+        if (lane == 0) p.out[b * p.N + n] = a + p.bias[n];
+    }
+}
+
+extern "C" int mms_head_fwd(const HeadFwdP* pp, hipStream_t s) {
+    const HeadFwdP& p = *pp;
+    size_t smem = (size_t)p.B * p.C * sizeof(float);
+    if (smem > 64 * 1024 || p.B <= 0) return MMS_ERR_ARG;
+    hipLaunchKernelGGL(head_fwd_kernel, dim3((p.N + 3) / 4), dim3(256), smem, s, p);
+    return mms_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------------
+// helpers: voxel coordinate tables, conv2 weight packing, BN running-stat update
+// ------------------------------------------------------------------------------------------------------
+__global__ void init_coords_kernel(int* coords, int M, Dims3 g) {
+    int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    int r = m % (g.D * g.H * g.W);
+    coords[m] = pack_dhw(r / (g.H * g.W), (r / g.W) % g.H, r % g.W);
+}
+extern "C" int mms_init_coords(int* coords, int B, int D, int H, int W, hipStream_t s) {
+    if (D > 1023 || H > 1023 || W > 1023) return MMS_ERR_ARG;
+    int M = B * D * H * W;
+    Dims3 g{D, H, W};
+    hipLaunchKernelGGL(init_coords_kernel, dim3((M + 255) / 256), dim3(256), 0, s, coords, M, g);
+    return mms_check_launch();
+}
+
+// canonical torch conv2 weight [32][128][27] -> fwd pack [32][27][128] and bwd-data pack [128][27][32]
+__global__ void pack_conv3_kernel(const float* __restrict__ w, float* __restrict__ wpf, float* __restrict__ wpb) {
+    int idx = blockIdx.x * 256 + threadIdx.x;      // over [cout][tap][cin]
+    if (idx >= 32 * 27 * 128) return;
+    int cin = idx & 127, tap = (idx >> 7) % 27, cout = idx / (27 * 128);
+    float v = w[(cout * 128 + cin) * 27 + tap];
+    wpf[idx] = v;
+    wpb[(cin * 27 + tap) * 32 + cout] = v;
+}
+extern "C" int mms_pack_conv3(const float* w, float* wpf, float* wpb, hipStream_t s) {
+    hipLaunchKernelGGL(pack_conv3_kernel, dim3(32 * 27 * 128 / 256), dim3(256), 0, s, w, wpf, wpb);
+    return mms_check_launch();
+}
+
+// batched variant over a device table of layer pointers (one launch per forward)
+struct PackEntry { const float* w; float* wpf; float* wpb; };
+__global__ void pack_conv3_table_kernel(const PackEntry* tab) {
+    const PackEntry e = tab[blockIdx.y];
+    int idx = blockIdx.x * 256 + threadIdx.x;
+    int cin = idx & 127, tap = (idx >> 7) % 27, cout = idx / (27 * 128);
+    float v = e.w[(cout * 128 + cin) * 27 + tap];
+    e.wpf[idx] = v;
+    e.wpb[(cin * 27 + tap) * 32 + cout] = v;
+}
+extern "C" int mms_pack_conv3_table(const void* table_dev, int nlayers, hipStream_t s) {
+    hipLaunchKernelGGL(pack_conv3_table_kernel, dim3(32 * 27 * 128 / 256, nlayers), dim3(256), 0, s,
+                       (const PackEntry*)table_dev);
+    return mms_check_launch();
+}
+
+// running_mean/var momentum update (torch: running = 0.9*running + 0.1*batch, unbiased var; nbt += 1)
+struct BnRunEntry { const double* sum; const double* sumsq; float* rmean; float* rvar; long long* nbt; int C; float count; };
+__global__ void bn_running_update_kernel(const BnRunEntry* tab, float momentum) {
+    const BnRunEntry e = tab[blockIdx.x];
+    for (int c = threadIdx.x; c < e.C; c += blockDim.x) {
+        double m = e.sum[c] / e.count, v = e.sumsq[c] / e.count - m * m;
+        if (v < 0) v = 0;
+        double unb = e.count > 1.f ? v * e.count / (e.count - 1.0) : v;
+        e.rmean[c] = (1.f - momentum) * e.rmean[c] + momentum * (float)m;
+        e.rvar[c] = (1.f - momentum) * e.rvar[c] + momentum * (float)unb;
+    }
+    if (threadIdx.x == 0 && e.nbt) *e.nbt += 1;
+}
+extern "C" int mms_bn_running_update(const void* table_dev, int n, float momentum, hipStream_t s) {
+    if (n <= 0) return MMS_OK;
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3(n), dim3(256), 0, s, (const BnRunEntry*)table_dev, momentum);
+    return mms_check_launch();
+}
