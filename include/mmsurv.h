@@ -153,6 +153,7 @@ typedef struct Conv1BwdP {
     float* dbn; int lddbn;          // [Mx][lddbn] out (data kernel), Mx = M*(pool?8:1)
     double* s1; double* s2;         // [K] out (data kernel)
     int msplit;
+    float* dgamma_out; float* dbeta_out;   // [N] BN2 parameter grads (= s2_out, s1_out), written by the weight kernel
 } Conv1BwdP;
 
 // dslab[:, 0:C] (+)= g*rstd*(dbn - s1/M - xhat*s2/M)
@@ -201,9 +202,31 @@ int mms_pool_fwd(const PoolFwdP* p, hipStream_t s);            /* features.norm0
 int mms_conv1_fwd(const Conv1FwdP* p, hipStream_t s);          /* denselayer norm1/relu1/conv1; transition norm/relu/conv/pool */
 int mms_conv3_fwd(const Conv3FwdP* p, hipStream_t s);          /* denselayer norm2/relu2/conv2 + torch.cat */
 int mms_head_fwd(const HeadFwdP* p, hipStream_t s);            /* features.norm5 + class_layers */
+int mms_conv3_bwd_data(const Conv3BwdDataP* p, hipStream_t s);  /* autograd of conv2 wrt its input + relu2 mask */
+int mms_conv3_bwd_weight(const Conv3BwdWP* p, hipStream_t s);    /* autograd of conv2 wrt weight */
+int mms_conv1_bwd_data(const Conv1BwdP* p, hipStream_t s);       /* norm2 backward + conv1 wrt input + relu1 mask */
+int mms_conv1_bwd_weight(const Conv1BwdP* p, hipStream_t s);     /* norm2 backward + conv1 wrt weight */
+int mms_bn_bwd_apply(const BnBwdApplyP* p, hipStream_t s);       /* norm1 backward into the block's gradient slab */
+int mms_head_bwd(const HeadBwdP* p, hipStream_t s);              /* class_layers + norm5 backward */
+int mms_pool_bwd(const PoolBwdP* p, hipStream_t s);              /* pool0 + relu0 backward */
+int mms_conv0_bwd_weight(const Conv0BwdWP* p, hipStream_t s);    /* norm0 backward + conv0 wrt weight */
 int mms_pack_conv3(const float* w, float* wpf, float* wpb, hipStream_t s);
 int mms_pack_conv3_table(const void* table_dev, int nlayers, hipStream_t s);
 int mms_bn_running_update(const void* table_dev, int n, float momentum, hipStream_t s);
+
+
+/* ---- whole-encoder driver: replaces `self.ct_encoder(ct)` / `self.image_encoder(image)` and its autograd
+ *      (R/scripts/training/final_multimodal.py:124, partial_modality_training.py:245, simple_fusion.py:226).
+ *      params: 364 device pointers in torch named_parameters() order of MONAI DenseNet121;
+ *      buffers: 121 x {running_mean, running_var, num_batches_tracked} in module order;
+ *      grads: 364 device pointers, ACCUMULATED into (caller zeroes).  D,H,W multiples of 32.            */
+int mms_dn121_workspace_bytes(int B, int D, int H, int W, size_t* bytes);
+int mms_dn121_region(int B, int D, int H, int W, const char* name, int index, size_t* off, size_t* bytes);
+int mms_dn121_init(void* ws, int B, int D, int H, int W, const void* const* params, const void* const* buffers, hipStream_t s);
+int mms_dn121_forward(void* ws, int B, int D, int H, int W, const float* x, const void* const* params,
+                      const void* const* buffers, float* out, int train, hipStream_t s);
+int mms_dn121_backward(void* ws, int B, int D, int H, int W, const float* x, const void* const* params,
+                       const float* dout, void* const* grads, hipStream_t s);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,576 @@
+// DenseNet121-3D backward ops for gfx950 (what torch autograd would run for MONAI's DenseNet121 under
+// loss.backward() at final_multimodal.py:258, partial_modality_training.py:426, simple_fusion.py:272).
+// BatchNorm backward (training mode):  dx = g*rstd*(dbn - mean_m(dbn) - xhat*mean_m(dbn*xhat));
+// the two per-channel sums are accumulated (fp64 atomics) by the kernel that produces dbn and consumed by
+// the next kernel's operand prologue, so dx of the inner BN (norm2) is never materialised.
+#include "dn_ops.h"
+#include "tile_gemm.h"
+
+#define Z4 make_float4(0, 0, 0, 0)
+
+// ------------------------------------------------------------------------------------------------------
+// conv3 backward-data:  dbn2[m][cin] = [a2>0] * sum_{tap,cout} dz[m - off(tap)][cout] * W[cout][cin][tap]
+// ------------------------------------------------------------------------------------------------------
+struct Conv3BwdDataOp {
+    typedef Conv3BwdDataP Params;
+    static constexpr int WM = 1, WN = 4, WK = 1, AMODE = LD_K4, BMODE = LD_K4;
+    static constexpr int TM = 32, TN = 128;
+    static constexpr int EXTRA = 4 * 128 + 32 + 2 * 2 * 128 * 2;   // bn consts, row coords, fp64 reduction scratch
+    float* ex;
+    const int* rowc;
+    int m0;
+    __device__ void setup(const Params& p, int m0_, int, int, float* extra, int tid) {
+        ex = extra; rowc = (const int*)(extra + 512); m0 = m0_;
+        if (tid < 128) {
+            float mu, rstd;
+            bn_mean_rstd(p.bn, tid, mu, rstd);
+            extra[tid] = mu; extra[128 + tid] = rstd; extra[256 + tid] = p.bn.gamma[tid]; extra[384 + tid] = p.bn.beta[tid];
+        }
+        if (tid < 32) ((int*)extra)[512 + tid] = (m0 + tid < p.M) ? p.coords[m0 + tid] : -1;
+    }
+    __device__ void krange(const Params&, int, int& kb, int& ke) { kb = 0; ke = 27 * 32; }
+    __device__ float4 a_k4(const Params& p, int m, int k) const {
+        const int c = rowc[m - m0];
+        if (c < 0) return Z4;
+        const int tap = k >> 5, co = k & 31;
+        const int kd = tap / 9 - 1, kh = (tap / 3) % 3 - 1, kw = tap % 3 - 1;
+        int d, h, w;
+        unpack_dhw(c, d, h, w);
+        if ((unsigned)(d - kd) >= (unsigned)p.g.D || (unsigned)(h - kh) >= (unsigned)p.g.H ||
+            (unsigned)(w - kw) >= (unsigned)p.g.W)
+            return Z4;
+        const int src = m - ((kd * p.g.H + kh) * p.g.W + kw);
+        return *(const float4*)(p.dz + (size_t)src * p.lddz + co);
+    }
+    __device__ float4 b_k4(const Params& p, int n, int k) const { return *(const float4*)(p.wpb + (size_t)n * 864 + k); }
+    __device__ float4 a_r4(const Params&, int, int) const { return Z4; }
+    __device__ float4 b_r4(const Params&, int, int) const { return Z4; }
+    __device__ float a_k1(const Params&, int, int) const { return 0; }
+    __device__ float b_k1(const Params&, int, int) const { return 0; }
+    __device__ void epilogue(const Params& p, int m0_, int, int, const float* Cs, int tid) {
+        const int c = tid & 127, rg = tid >> 7;
+        const float mu = ex[c], rstd = ex[128 + c], ga = ex[256 + c], be = ex[384 + c];
+        double s1 = 0, s2 = 0;
+        const int rows = p.M - m0_ < TM ? p.M - m0_ : TM;
+        for (int r = rg; r < rows; r += 2) {
+            const size_t o = (size_t)(m0_ + r) * 128 + c;
+            const float xh = (p.y1[o] - mu) * rstd;
+            const float pre = fmaf(ga, xh, be);
+            const float g = pre > 0.f ? Cs[r * (TN + 1) + c] : 0.f;
+            p.dbn[o] = g;
+            s1 += g; s2 += (double)g * xh;
+        }
+        double* red = (double*)(ex + 544);     // [2][2][128], 8-byte aligned (544*4 = 2176)
+        red[(rg * 2 + 0) * 128 + c] = s1; red[(rg * 2 + 1) * 128 + c] = s2;
+        __syncthreads();
+        if (rg == 0) {
+            atomicAdd(&p.s1[c], red[c] + red[2 * 128 + c]);
+            atomicAdd(&p.s2[c], red[128 + c] + red[3 * 128 + c]);
+        }
+    }
+};
+
+extern "C" int mms_conv3_bwd_data(const Conv3BwdDataP* pp, hipStream_t s) {
+    const Conv3BwdDataP& p = *pp;
+    if (p.M <= 0 || p.lddz % 4 != 0) return MMS_ERR_ARG;
+    return launch_tile_gemm<Conv3BwdDataOp>(p, dim3((p.M + 31) / 32, 1, 1), s);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// conv3 backward-weight: dW[cout][cin][tap] += sum_m a2[m + off(tap)][cin] * dz[m][cout]
+// tile: rows = cin (128), cols = cout (32), reduction index = voxel m (split over grid.z with the tap)
+// ------------------------------------------------------------------------------------------------------
+struct Conv3BwdWOp {
+    typedef Conv3BwdWP Params;
+    static constexpr int WM = 4, WN = 1, WK = 1, AMODE = LD_R4, BMODE = LD_R4;
+    static constexpr int TM = 128, TN = 32;
+    static constexpr int EXTRA = 3 * 128;
+    const float *mean, *sc, *beta;
+    int tap, kd, kh, kw, mb, me;
+    __device__ void setup(const Params& p, int, int, int z, float* extra, int tid) {
+        mean = extra; sc = extra + 128; beta = extra + 256;
+        if (tid < 128) {
+            float mu, rstd;
+            bn_mean_rstd(p.bn, tid, mu, rstd);
+            extra[tid] = mu; extra[128 + tid] = p.bn.gamma[tid] * rstd; extra[256 + tid] = p.bn.beta[tid];
+        }
+        tap = z % 27;
+        kd = tap / 9 - 1; kh = (tap / 3) % 3 - 1; kw = tap % 3 - 1;
+        const int chunk = z / 27;
+        int mc = (p.M + p.msplit - 1) / p.msplit;
+        mc = (mc + 31) & ~31;
+        mb = chunk * mc;
+        me = mb + mc < p.M ? mb + mc : p.M;
+    }
+    __device__ void krange(const Params&, int, int& kb, int& ke) { kb = mb; ke = me; }
+    __device__ float4 a_r4(const Params& p, int cin, int m) const {
+        if (m >= me) return Z4;
+        int d, h, w;
+        unpack_dhw(p.coords[m], d, h, w);
+        if ((unsigned)(d + kd) >= (unsigned)p.g.D || (unsigned)(h + kh) >= (unsigned)p.g.H ||
+            (unsigned)(w + kw) >= (unsigned)p.g.W)
+            return Z4;
+        const int src = m + (kd * p.g.H + kh) * p.g.W + kw;
+        const float4 v = *(const float4*)(p.y1 + (size_t)src * 128 + cin);
+        float4 r;
+        r.x = fmaxf(bn_apply(v.x, mean[cin], sc[cin], beta[cin]), 0.f);
+        r.y = fmaxf(bn_apply(v.y, mean[cin + 1], sc[cin + 1], beta[cin + 1]), 0.f);
+        r.z = fmaxf(bn_apply(v.z, mean[cin + 2], sc[cin + 2], beta[cin + 2]), 0.f);
+        r.w = fmaxf(bn_apply(v.w, mean[cin + 3], sc[cin + 3], beta[cin + 3]), 0.f);
+        return r;
+    }
+    __device__ float4 b_r4(const Params& p, int co, int m) const {
+        if (m >= me) return Z4;
+        return *(const float4*)(p.dz + (size_t)m * p.lddz + co);
+    }
+    __device__ float4 a_k4(const Params&, int, int) const { return Z4; }
+    __device__ float4 b_k4(const Params&, int, int) const { return Z4; }
+    __device__ float a_k1(const Params&, int, int) const { return 0; }
+    __device__ float b_k1(const Params&, int, int) const { return 0; }
+    __device__ void epilogue(const Params& p, int, int, int, const float* Cs, int tid) {
+        if (mb >= me) return;
+        for (int idx = tid; idx < TM * TN; idx += 256) {
+            const int cin = idx & 127, co = idx >> 7;
+            atomicAdd(&p.dw[((size_t)co * 128 + cin) * 27 + tap], Cs[cin * (TN + 1) + co]);
+        }
+    }
+};
+
+extern "C" int mms_conv3_bwd_weight(const Conv3BwdWP* pp, hipStream_t s) {
+    const Conv3BwdWP& p = *pp;
+    if (p.M <= 0 || p.msplit <= 0 || p.lddz % 4 != 0) return MMS_ERR_ARG;
+    return launch_tile_gemm<Conv3BwdWOp>(p, dim3(1, 1, 27 * p.msplit), s);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// 1x1 conv backward.  Shared pieces: dy(m, n) with the output-side BN backward folded in, a(m, k) recompute.
+// ------------------------------------------------------------------------------------------------------
+struct DyConsts {   // per output channel n (LDS): dy = A*(dbn - B - yhat*C), yhat = (y - mean)*rstd
+    float *A, *Bc, *Cc, *mean, *rstd;
+    __device__ void init(const Conv1BwdP& p, float* e, int n0, int cnt, int tid) {
+        A = e; Bc = e + cnt; Cc = e + 2 * cnt; mean = e + 3 * cnt; rstd = e + 4 * cnt;
+        if (!p.has_bn_out) return;
+        for (int i = tid; i < cnt; i += 256) {
+            const int n = n0 + i;
+            if (n < p.N) {
+                float mu, rs;
+                bn_mean_rstd(p.bn_out, n, mu, rs);
+                A[i] = p.bn_out.gamma[n] * rs;
+                Bc[i] = (float)(p.bb_out.s1[n] * (double)p.bn_out.inv_count);
+                Cc[i] = (float)(p.bb_out.s2[n] * (double)p.bn_out.inv_count);
+                mean[i] = mu; rstd[i] = rs;
+            } else {
+                A[i] = Bc[i] = Cc[i] = mean[i] = rstd[i] = 0.f;
+            }
+        }
+    }
+    __device__ __forceinline__ float dy(const Conv1BwdP& p, float g, float y, int i) const {
+        if (!p.has_bn_out) return g;
+        return A[i] * (g - Bc[i] - (y - mean[i]) * rstd[i] * Cc[i]);
+    }
+};
+
+// ---- data: dbn_in[m][k] = [a>0] * sum_n dy[m][n] * W[n][k]  (+ un-pool) ; rows m, cols k, reduce over n
+template <int WM_, int WN_, int WK_, bool POOL>
+struct Conv1BwdDataOp {
+    typedef Conv1BwdP Params;
+    static constexpr int WM = WM_, WN = WN_, WK = WK_, AMODE = LD_K4, BMODE = LD_R4;
+    static constexpr int TM = 32 * WM, TN = 32 * WN;
+    // dy consts for all N (<=512 without bn_out, 128 with), bn_in consts for TN columns, srcbase[TM], fp64 scratch
+    static constexpr int EXTRA = 5 * 128 + 4 * TN + TM + 1024;   // + fp64 [256/TN][2][TN] reduction scratch
+    DyConsts dc;
+    float* ein;
+    const int* srcbase;
+    int m0;
+    __device__ void setup(const Params& p, int m0_, int n0, int, float* extra, int tid) {
+        m0 = m0_;
+        dc.init(p, extra, 0, 128, tid);
+        ein = extra + 640;
+        srcbase = (const int*)(extra + 640 + 4 * TN);
+        if (tid < TN) {
+            const int k = n0 + tid;
+            float mu = 0, rs = 0, ga = 0, be = 0;
+            if (k < p.K) { bn_mean_rstd(p.bn_in, k, mu, rs); ga = p.bn_in.gamma[k]; be = p.bn_in.beta[k]; }
+            ein[tid] = mu; ein[TN + tid] = rs; ein[2 * TN + tid] = ga; ein[3 * TN + tid] = be;
+        }
+        if (POOL && tid < TM) {
+            int m = m0 + tid, base = -1;
+            if (m < p.M) {
+                int D2 = p.in.D >> 1, H2 = p.in.H >> 1, W2 = p.in.W >> 1, vox2 = D2 * H2 * W2;
+                int b = m / vox2, r = m % vox2, d = r / (H2 * W2), h = (r / W2) % H2, w = r % W2;
+                base = ((b * p.in.D + 2 * d) * p.in.H + 2 * h) * p.in.W + 2 * w;
+            }
+            ((int*)extra)[640 + 4 * TN + tid] = base;
+        }
+    }
+    __device__ void krange(const Params& p, int, int& kb, int& ke) { kb = 0; ke = p.N; }
+    __device__ float4 a_k4(const Params& p, int m, int n) const {   // A(m, n) = dy[m][n..n+3]
+        if (m >= p.M || n >= p.N) return Z4;
+        const float4 g = *(const float4*)(p.dyraw + (size_t)m * p.lddy + n);
+        if (!p.has_bn_out) return g;
+        const float4 y = *(const float4*)(p.y + (size_t)m * p.ldy + n);
+        return make_float4(dc.dy(p, g.x, y.x, n), dc.dy(p, g.y, y.y, n + 1), dc.dy(p, g.z, y.z, n + 2), dc.dy(p, g.w, y.w, n + 3));
+    }
+    __device__ float4 b_r4(const Params& p, int k, int n) const {   // B(col k..k+3, n) = W[n][k..k+3]
+        if (n >= p.N || k >= p.K) return Z4;
+        return *(const float4*)(p.w + (size_t)n * p.K + k);
+    }
+    __device__ float4 a_r4(const Params&, int, int) const { return Z4; }
+    __device__ float4 b_k4(const Params&, int, int) const { return Z4; }
+    __device__ float a_k1(const Params&, int, int) const { return 0; }
+    __device__ float b_k1(const Params&, int, int) const { return 0; }
+    __device__ void epilogue(const Params& p, int m0_, int n0, int, const float* Cs, int tid) {
+        constexpr int RG = 256 / TN;              // row groups
+        const int c = tid % TN, rg = tid / TN, k = n0 + c;
+        const float mu = ein[c], rs = ein[TN + c], ga = ein[2 * TN + c], be = ein[3 * TN + c];
+        double s1 = 0, s2 = 0;
+        const int rows = p.M - m0_ < TM ? p.M - m0_ : TM;
+        if (k < p.K) {
+            for (int r = rg; r < rows; r += RG) {
+                const float da = Cs[r * (TN + 1) + c];
+                if (!POOL) {
+                    const size_t m = m0_ + r;
+                    const float xh = (p.x[m * p.ldx + k] - mu) * rs;
+                    const float g = fmaf(ga, xh, be) > 0.f ? da : 0.f;
+                    p.dbn[m * p.lddbn + k] = g;
+                    s1 += g; s2 += (double)g * xh;
+                } else {
+                    const int base = srcbase[r], HW = p.in.H * p.in.W, W = p.in.W;
+                    const float d8 = da * 0.125f;
+#pragma unroll
+                    for (int o = 0; o < 8; ++o) {
+                        const size_t src = base + (o >> 2) * HW + ((o >> 1) & 1) * W + (o & 1);
+                        const float xh = (p.x[src * p.ldx + k] - mu) * rs;
+                        const float g = fmaf(ga, xh, be) > 0.f ? d8 : 0.f;
+                        p.dbn[src * p.lddbn + k] = g;
+                        s1 += g; s2 += (double)g * xh;
+                    }
+                }
+            }
+        }
+        double* red = (double*)(ein + 4 * TN + TM);     // offset (640 + 4TN + TM)*4 bytes: multiple of 8
+        red[(rg * 2 + 0) * TN + c] = s1; red[(rg * 2 + 1) * TN + c] = s2;
+        __syncthreads();
+        if (rg == 0 && k < p.K) {
+            double a = 0, b = 0;
+            for (int g = 0; g < RG; ++g) { a += red[(g * 2) * TN + c]; b += red[(g * 2 + 1) * TN + c]; }
+            atomicAdd(&p.s1[k], a);
+            atomicAdd(&p.s2[k], b);
+        }
+    }
+};
+
+extern "C" int mms_conv1_bwd_data(const Conv1BwdP* pp, hipStream_t s) {
+    const Conv1BwdP& p = *pp;
+    if (p.M <= 0 || p.K % 32 != 0 || p.N % 32 != 0 || p.ldx % 4 != 0 || p.lddy % 4 != 0) return MMS_ERR_ARG;
+    if (p.has_bn_out && p.N != 128) return MMS_ERR_ARG;
+    const bool big = (long)p.M * p.K >= 256L * 64 * 64;
+    if (big) {
+        dim3 g((p.M + 63) / 64, (p.K + 63) / 64, 1);
+        return p.pool ? launch_tile_gemm<Conv1BwdDataOp<2, 2, 1, true>>(p, g, s)
+                      : launch_tile_gemm<Conv1BwdDataOp<2, 2, 1, false>>(p, g, s);
+    }
+    dim3 g((p.M + 31) / 32, (p.K + 31) / 32, 1);
+    return p.pool ? launch_tile_gemm<Conv1BwdDataOp<1, 1, 4, true>>(p, g, s)
+                  : launch_tile_gemm<Conv1BwdDataOp<1, 1, 4, false>>(p, g, s);
+}
+
+// ---- weight: dW[n][k] += sum_m dy[m][n] * a[m][k] ; rows n, cols k, reduce over m (split over grid.z)
+template <bool POOL>
+struct Conv1BwdWOp {
+    typedef Conv1BwdP Params;
+    static constexpr int WM = 2, WN = 2, WK = 1, AMODE = LD_R4, BMODE = LD_R4;
+    static constexpr int TM = 64, TN = 64;
+    static constexpr int EXTRA = 5 * 64 + 3 * 64;
+    DyConsts dc;
+    const float *mean, *sc, *beta;
+    int n0r, k0c, mb, me;
+    __device__ void setup(const Params& p, int m0_, int n0, int z, float* extra, int tid) {
+        n0r = m0_; k0c = n0;
+        dc.init(p, extra, n0r, 64, tid);
+        mean = extra + 320; sc = extra + 384; beta = extra + 448;
+        if (tid < 64) {
+            const int k = k0c + tid;
+            float mu = 0, rs = 0, ga = 0, be = 0;
+            if (k < p.K) { bn_mean_rstd(p.bn_in, k, mu, rs); ga = p.bn_in.gamma[k]; be = p.bn_in.beta[k]; }
+            extra[320 + tid] = mu; extra[384 + tid] = ga * rs; extra[448 + tid] = be;
+        }
+        int mc = (p.M + p.msplit - 1) / p.msplit;
+        mc = (mc + 31) & ~31;
+        mb = z * mc;
+        me = mb + mc < p.M ? mb + mc : p.M;
+        // BN2 parameter grads: dgamma = sum dbn*xhat, dbeta = sum dbn
+        if (p.has_bn_out && p.dgamma_out && blockIdx.y == 0 && z == 0 && tid < 64 && n0r + tid < p.N) {
+            p.dgamma_out[n0r + tid] += (float)p.bb_out.s2[n0r + tid];
+            p.dbeta_out[n0r + tid] += (float)p.bb_out.s1[n0r + tid];
+        }
+    }
+    __device__ void krange(const Params&, int, int& kb, int& ke) { kb = mb; ke = me; }
+    __device__ float4 a_r4(const Params& p, int n, int m) const {   // A(row n..n+3, m) = dy[m][n..n+3]
+        if (m >= me || n >= p.N) return Z4;
+        const float4 g = *(const float4*)(p.dyraw + (size_t)m * p.lddy + n);
+        if (!p.has_bn_out) return g;
+        const float4 y = *(const float4*)(p.y + (size_t)m * p.ldy + n);
+        const int i = n - n0r;
+        return make_float4(dc.dy(p, g.x, y.x, i), dc.dy(p, g.y, y.y, i + 1), dc.dy(p, g.z, y.z, i + 2), dc.dy(p, g.w, y.w, i + 3));
+    }
+    __device__ float4 act4(const float4 v, int i) const {
+        return make_float4(fmaxf(bn_apply(v.x, mean[i], sc[i], beta[i]), 0.f), fmaxf(bn_apply(v.y, mean[i + 1], sc[i + 1], beta[i + 1]), 0.f),
+                           fmaxf(bn_apply(v.z, mean[i + 2], sc[i + 2], beta[i + 2]), 0.f), fmaxf(bn_apply(v.w, mean[i + 3], sc[i + 3], beta[i + 3]), 0.f));
+    }
+    __device__ float4 b_r4(const Params& p, int k, int m) const {   // B(col k..k+3, m) = a[m][k..k+3]
+        if (m >= me || k >= p.K) return Z4;
+        const int i = k - k0c;
+        if (!POOL) return act4(*(const float4*)(p.x + (size_t)m * p.ldx + k), i);
+        const int D2 = p.in.D >> 1, H2 = p.in.H >> 1, W2 = p.in.W >> 1, vox2 = D2 * H2 * W2;
+        const int b = m / vox2, r = m % vox2, d = r / (H2 * W2), h = (r / W2) % H2, w = r % W2;
+        const int base = ((b * p.in.D + 2 * d) * p.in.H + 2 * h) * p.in.W + 2 * w, HW = p.in.H * p.in.W, W = p.in.W;
+        float4 s = Z4;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            const size_t src = base + (o >> 2) * HW + ((o >> 1) & 1) * W + (o & 1);
+            const float4 v = act4(*(const float4*)(p.x + src * p.ldx + k), i);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        return make_float4(s.x * 0.125f, s.y * 0.125f, s.z * 0.125f, s.w * 0.125f);
+    }
+    __device__ float4 a_k4(const Params&, int, int) const { return Z4; }
+    __device__ float4 b_k4(const Params&, int, int) const { return Z4; }
+    __device__ float a_k1(const Params&, int, int) const { return 0; }
+    __device__ float b_k1(const Params&, int, int) const { return 0; }
+    __device__ void epilogue(const Params& p, int, int, int, const float* Cs, int tid) {
+        if (mb >= me) return;
+        for (int idx = tid; idx < TM * TN; idx += 256) {
+            const int r = idx / TN, c = idx % TN, n = n0r + r, k = k0c + c;
+            if (n < p.N && k < p.K) atomicAdd(&p.dw[(size_t)n * p.K + k], Cs[r * (TN + 1) + c]);
+        }
+    }
+};
+
+extern "C" int mms_conv1_bwd_weight(const Conv1BwdP* pp, hipStream_t s) {
+    const Conv1BwdP& p = *pp;
+    if (p.M <= 0 || p.msplit <= 0 || p.K % 32 != 0 || p.N % 32 != 0) return MMS_ERR_ARG;
+    dim3 g((p.N + 63) / 64, (p.K + 63) / 64, p.msplit);
+    return p.pool ? launch_tile_gemm<Conv1BwdWOp<true>>(p, g, s) : launch_tile_gemm<Conv1BwdWOp<false>>(p, g, s);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// BN backward apply into the gradient slab: dx[:, 0:C] (+)= g*rstd*(dbn - s1/M - xhat*s2/M)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyP p) {
+    extern __shared__ float cst[];    // [4][C]: mean, rstd, g*rstd, s1/M ; s2/M in a 5th row
+    const int tid = threadIdx.x, C = p.C;
+    for (int c = tid; c < C; c += 256) {
+        float mu, rs;
+        bn_mean_rstd(p.bn, c, mu, rs);
+        cst[c] = mu; cst[C + c] = rs; cst[2 * C + c] = p.bn.gamma[c] * rs;
+        cst[3 * C + c] = (float)(p.bb.s1[c] * (double)p.bn.inv_count);
+        cst[4 * C + c] = (float)(p.bb.s2[c] * (double)p.bn.inv_count);
+        if (blockIdx.x == 0 && p.dgamma) {
+            p.dgamma[c] += (float)p.bb.s2[c];
+            p.dbeta[c] += (float)p.bb.s1[c];
+        }
+    }
+    __syncthreads();
+    const int r0 = blockIdx.x * 32, rows = p.M - r0 < 32 ? p.M - r0 : 32;
+    const int C4 = C >> 2;
+    for (int idx = tid; idx < rows * C4; idx += 256) {
+        const int r = idx / C4, c = (idx % C4) * 4;
+        const size_t m = r0 + r;
+        const float4 g = *(const float4*)(p.dbn + m * p.lddbn + c);
+        const float4 x = *(const float4*)(p.x + m * p.ldx + c);
+        float4* dst = (float4*)(p.dx + m * p.lddx + c);
+        float4 o = p.accumulate ? *dst : make_float4(0, 0, 0, 0);
+        const float gv[4] = {g.x, g.y, g.z, g.w}, xv[4] = {x.x, x.y, x.z, x.w};
+        float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cc = c + j;
+            const float xh = (xv[j] - cst[cc]) * cst[C + cc];
+            ov[j] += cst[2 * C + cc] * (gv[j] - cst[3 * C + cc] - xh * cst[4 * C + cc]);
+        }
+        *dst = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    }
+}
+
+extern "C" int mms_bn_bwd_apply(const BnBwdApplyP* pp, hipStream_t s) {
+    const BnBwdApplyP& p = *pp;
+    if (p.M <= 0 || p.C % 4 != 0 || p.C > 2048 || p.lddbn % 4 || p.ldx % 4 || p.lddx % 4) return MMS_ERR_ARG;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((p.M + 31) / 32), dim3(256), 5 * p.C * sizeof(float), s, p);
+    return mms_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------------
+// head backward: Linear(C,N) + global-avg-pool + relu + norm5.  M = B*V rows is small: one thread per channel
+// walks all rows, so the BN sums need no atomics.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_bwd_feat_kernel(const HeadBwdP p) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= p.C) return;
+    float mu, rs;
+    bn_mean_rstd(p.bn, c, mu, rs);
+    const float ga = p.bn.gamma[c], be = p.bn.beta[c];
+    const int M = p.B * p.V;
+    const float invV = 1.f / (float)p.V;
+    double s1 = 0, s2 = 0;
+    for (int b = 0; b < p.B; ++b) {
+        float dp = 0;
+        for (int n = 0; n < p.N; ++n) dp = fmaf(p.dout[b * p.N + n], p.w[(size_t)n * p.C + c], dp);
+        dp *= invV;
+        for (int v = 0; v < p.V; ++v) {
+            const size_t m = (size_t)b * p.V + v;
+            const float xh = (p.slab[m * p.ld + c] - mu) * rs;
+            const float g = fmaf(ga, xh, be) > 0.f ? dp : 0.f;
+            p.dslab[m * p.ldd + c] = g;            // stash dbn; finalised below
+            s1 += g; s2 += (double)g * xh;
+        }
+    }
+    const float m1 = (float)(s1 / M), m2 = (float)(s2 / M);
+    for (int m = 0; m < M; ++m) {
+        const float xh = (p.slab[(size_t)m * p.ld + c] - mu) * rs;
+        const float g = p.dslab[(size_t)m * p.ldd + c];
+        p.dslab[(size_t)m * p.ldd + c] = ga * rs * (g - m1 - xh * m2);
+    }
+    p.dgamma[c] += (float)s2;
+    p.dbeta[c] += (float)s1;
+}
+__global__ __launch_bounds__(256) void head_bwd_w_kernel(const HeadBwdP p) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= p.N * p.C) return;
+    const int n = idx / p.C, c = idx % p.C;
+    float a = 0;
+    for (int b = 0; b < p.B; ++b) a = fmaf(p.dout[b * p.N + n], p.pooled[b * p.C + c], a);
+    p.dw[idx] += a;
+    if (c == 0) {
+        float d = 0;
+        for (int b = 0; b < p.B; ++b) d += p.dout[b * p.N + n];
+        p.dbias[n] += d;
+    }
+}
+extern "C" int mms_head_bwd(const HeadBwdP* pp, hipStream_t s) {
+    const HeadBwdP& p = *pp;
+    if (p.B <= 0) return MMS_ERR_ARG;
+    hipLaunchKernelGGL(head_bwd_feat_kernel, dim3((p.C + 255) / 256), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(head_bwd_w_kernel, dim3((p.N * p.C + 255) / 256), dim3(256), 0, s, p);
+    return mms_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------------
+// maxpool(3,2,1) backward (gather form, no atomics on the gradient) + relu0 mask -> dbn0, BN0 sums
+// one workgroup = 256 conv0-grid voxels x 64 channels
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolBwdP p) {
+    __shared__ double red[2][4][64];
+    const int c = threadIdx.x & 63, vr = threadIdx.x >> 6;
+    float mu, rs;
+    bn_mean_rstd(p.bn, c, mu, rs);
+    const float ga = p.bn.gamma[c], be = p.bn.beta[c];
+    const int vox_in = p.in.D * p.in.H * p.in.W, Min = p.B * vox_in;
+    double s1 = 0, s2 = 0;
+    for (int it = 0; it < 64; ++it) {
+        const int m = blockIdx.x * 256 + it * 4 + vr;
+        if (m >= Min) break;
+        const int b = m / vox_in, r = m % vox_in;
+        const int id = r / (p.in.H * p.in.W), ih = (r / p.in.W) % p.in.H, iw = r % p.in.W;
+        float g = 0;
+        // windows od with 2*od-1 <= id <= 2*od+1
+        for (int od = id >> 1; od <= (id + 1) >> 1; ++od) {
+            if (od >= p.out.D) continue;
+            for (int oh = ih >> 1; oh <= (ih + 1) >> 1; ++oh) {
+                if (oh >= p.out.H) continue;
+                for (int ow = iw >> 1; ow <= (iw + 1) >> 1; ++ow) {
+                    if (ow >= p.out.W) continue;
+                    const int tap = ((id - 2 * od + 1) * 3 + (ih - 2 * oh + 1)) * 3 + (iw - 2 * ow + 1);
+                    const size_t mo = ((size_t)(b * p.out.D + od) * p.out.H + oh) * p.out.W + ow;
+                    if (p.argmax[mo * 64 + c] == tap) g += p.dslab[mo * p.ld + c];
+                }
+            }
+        }
+        const float xh = (p.y0[(size_t)m * 64 + c] - mu) * rs;
+        g = fmaf(ga, xh, be) > 0.f ? g : 0.f;
+        p.dbn[(size_t)m * 64 + c] = g;
+        s1 += g; s2 += (double)g * xh;
+    }
+    red[0][vr][c] = s1; red[1][vr][c] = s2;
+    __syncthreads();
+    if (vr == 0) {
+        atomicAdd(&p.s1[c], red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+        atomicAdd(&p.s2[c], red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    }
+}
+extern "C" int mms_pool_bwd(const PoolBwdP* pp, hipStream_t s) {
+    const PoolBwdP& p = *pp;
+    const int Min = p.B * p.in.D * p.in.H * p.in.W;
+    if (Min <= 0) return MMS_ERR_ARG;
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3((Min + 255) / 256), dim3(256), 0, s, p);
+    return mms_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------------
+// conv0 backward-weight: dW0[n][k] += sum_m dy0[m][n] * x[patch(m,k)], dy0 = BN0-backward(dbn0)
+// tile: rows = tap k (343), cols = n (64), reduction over output voxels m (split over grid.z)
+// ------------------------------------------------------------------------------------------------------
+struct Conv0BwdWOp {
+    typedef Conv0BwdWP Params;
+    static constexpr int WM = 2, WN = 2, WK = 1, AMODE = LD_K1, BMODE = LD_R4;
+    static constexpr int TM = 64, TN = 64;
+    static constexpr int EXTRA = 5 * 64;
+    float *A, *Bc, *Cc, *mean, *rstd;
+    int k0r, mb, me;
+    __device__ void setup(const Params& p, int m0_, int, int z, float* extra, int tid) {
+        k0r = m0_;
+        A = extra; Bc = extra + 64; Cc = extra + 128; mean = extra + 192; rstd = extra + 256;
+        if (tid < 64) {
+            float mu, rs;
+            bn_mean_rstd(p.bn, tid, mu, rs);
+            A[tid] = p.bn.gamma[tid] * rs;
+            Bc[tid] = (float)(p.bb.s1[tid] * (double)p.bn.inv_count);
+            Cc[tid] = (float)(p.bb.s2[tid] * (double)p.bn.inv_count);
+            mean[tid] = mu; rstd[tid] = rs;
+            if (blockIdx.x == 0 && z == 0 && p.dgamma) {
+                p.dgamma[tid] += (float)p.bb.s2[tid];
+                p.dbeta[tid] += (float)p.bb.s1[tid];
+            }
+        }
+        int mc = (p.M + p.msplit - 1) / p.msplit;
+        mc = (mc + 31) & ~31;
+        mb = z * mc;
+        me = mb + mc < p.M ? mb + mc : p.M;
+    }
+    __device__ void krange(const Params&, int, int& kb, int& ke) { kb = mb; ke = me; }
+    __device__ float a_k1(const Params& p, int k, int m) const {    // A(row = tap k, m) = x[patch(m, k)]
+        if (k >= 343 || m >= me) return 0.f;
+        int od, oh, ow;
+        unpack_dhw(p.coords[m], od, oh, ow);
+        const int b = m / (p.out.D * p.out.H * p.out.W);
+        const int id = 2 * od - 3 + k / 49, ih = 2 * oh - 3 + (k / 7) % 7, iw = 2 * ow - 3 + k % 7;
+        if ((unsigned)id >= (unsigned)p.in.D || (unsigned)ih >= (unsigned)p.in.H || (unsigned)iw >= (unsigned)p.in.W)
+            return 0.f;
+        return p.x[((size_t)(b * p.in.D + id) * p.in.H + ih) * p.in.W + iw];
+    }
+    __device__ __forceinline__ float dy(float g, float y, int n) const {
+        return A[n] * (g - Bc[n] - (y - mean[n]) * rstd[n] * Cc[n]);
+    }
+    __device__ float4 b_r4(const Params& p, int n, int m) const {   // B(col n..n+3, m) = dy0[m][n..n+3]
+        if (m >= me) return Z4;
+        const float4 g = *(const float4*)(p.dbn + (size_t)m * 64 + n);
+        const float4 y = *(const float4*)(p.y0 + (size_t)m * 64 + n);
+        return make_float4(dy(g.x, y.x, n), dy(g.y, y.y, n + 1), dy(g.z, y.z, n + 2), dy(g.w, y.w, n + 3));
+    }
+    __device__ float4 a_k4(const Params&, int, int) const { return Z4; }
+    __device__ float4 b_k4(const Params&, int, int) const { return Z4; }
+    __device__ float4 a_r4(const Params&, int, int) const { return Z4; }
+    __device__ float b_k1(const Params&, int, int) const { return 0; }
+    __device__ void epilogue(const Params& p, int, int, int, const float* Cs, int tid) {
+        if (mb >= me) return;
+        for (int idx = tid; idx < TM * TN; idx += 256) {
+            const int r = idx & 63, c = idx >> 6, k = k0r + r;     // r fastest: dW0[n][k] contiguous in k
+            if (k < 343) atomicAdd(&p.dw[c * 343 + k], Cs[r * (TN + 1) + c]);
+        }
+    }
+};
+extern "C" int mms_conv0_bwd_weight(const Conv0BwdWP* pp, hipStream_t s) {
+    const Conv0BwdWP& p = *pp;
+    if (p.M <= 0 || p.msplit <= 0) return MMS_ERR_ARG;
+    return launch_tile_gemm<Conv0BwdWOp>(p, dim3(6, 1, p.msplit), s);
+}

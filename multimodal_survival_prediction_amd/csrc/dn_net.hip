@@ -1,0 +1,333 @@
+// DenseNet121-3D network driver: the whole encoder forward / backward as one C-ABI call each.
+// Host-only code (no kernels besides the ones it launches): computes the workspace layout for a (B, D, H, W)
+// problem, enqueues the fused ops of dn_fwd.hip / dn_bwd.hip on the caller's stream in dependency order.
+// No allocation, no synchronisation (graph-capturable); mms_dn121_init is the only call that copies tables.
+//
+// Topology restated from MONAI DenseNet121(spatial_dims=3, in_channels=1, out_channels=128):
+// init_features 64, growth 32, bn_size 4, block_config (6,12,24,16) -- see oracle/densenet3d.py.
+// Parameter table order == torch named_parameters() order of that module (364 tensors):
+//   conv0.w, norm0.{w,b}, per dense layer {norm1.w, norm1.b, conv1.w, norm2.w, norm2.b, conv2.w},
+//   after blocks 1-3 transition{norm.w, norm.b, conv.w}, norm5.{w,b}, class_layers.out.{w,b}
+// Buffer table order: per BatchNorm in module order {running_mean, running_var, num_batches_tracked} (121 BNs).
+#include "dn_ops.h"
+#include <string.h>
+
+namespace {
+
+constexpr int NB = 4;
+constexpr int LAYERS[NB] = {6, 12, 24, 16};
+constexpr int C0[NB] = {64, 128, 256, 512};
+constexpr int CTOT[NB] = {256, 512, 1024, 1024};
+constexpr int NLAYER = 58;
+constexpr int NBN = 121;
+constexpr int NPARAM = 364;
+
+struct PackEntry { const float* w; float* wpf; float* wpb; };
+struct BnRunEntry { const double* sum; const double* sumsq; float* rmean; float* rvar; long long* nbt; int C; float count; };
+
+struct Plan {
+    int B; Dims3 in, g0, g[NB];
+    int M0, M[NB];
+    // byte offsets into the workspace
+    size_t coords0, coords[NB], y0, argmax, slab[NB], dslab[NB], y1[NLAYER], wpf[NLAYER], wpb[NLAYER];
+    size_t dbn_mid, dbn_in, dbn0, pooled, tab_pack, tab_bn;
+    // fp64 statistic accumulators (one contiguous region, zeroed once per step)
+    size_t stats_begin, stats_end;
+    size_t st_y0, st_slab[NB], st_y1[NLAYER];          // forward (sum | sumsq), each 2*C doubles
+    size_t bb_y0, bb_y1[NLAYER], bb_in[NLAYER], bb_tr[3];   // backward (s1 | s2)
+    size_t total;
+};
+
+inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+bool make_plan(Plan& P, int B, int D, int H, int W) {
+    if (B <= 0 || D < 32 || H < 32 || W < 32 || (D % 32) || (H % 32) || (W % 32)) return false;   // 5 halvings, even dims at each
+    if (D > 1023 * 2 || H > 1023 * 2 || W > 1023 * 2) return false;
+    P.B = B; P.in = Dims3{D, H, W};
+    P.g0 = Dims3{D / 2, H / 2, W / 2};
+    P.g[0] = Dims3{D / 4, H / 4, W / 4};
+    for (int b = 1; b < NB; ++b) P.g[b] = Dims3{P.g[b - 1].D / 2, P.g[b - 1].H / 2, P.g[b - 1].W / 2};
+    P.M0 = B * P.g0.D * P.g0.H * P.g0.W;
+    for (int b = 0; b < NB; ++b) P.M[b] = B * P.g[b].D * P.g[b].H * P.g[b].W;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = al(o + bytes); return r; };
+    P.coords0 = take((size_t)P.M0 * 4);
+    for (int b = 0; b < NB; ++b) P.coords[b] = take((size_t)P.M[b] * 4);
+    P.y0 = take((size_t)P.M0 * 64 * 4);
+    P.argmax = take((size_t)P.M[0] * 64);
+    for (int b = 0; b < NB; ++b) P.slab[b] = take((size_t)P.M[b] * CTOT[b] * 4);
+    for (int b = 0; b < NB; ++b) P.dslab[b] = take((size_t)P.M[b] * CTOT[b] * 4);
+    int l = 0;
+    for (int b = 0; b < NB; ++b)
+        for (int i = 0; i < LAYERS[b]; ++i, ++l) {
+            P.y1[l] = take((size_t)P.M[b] * 128 * 4);
+            P.wpf[l] = take((size_t)32 * 27 * 128 * 4);
+            P.wpb[l] = take((size_t)32 * 27 * 128 * 4);
+        }
+    P.dbn_mid = take((size_t)P.M[0] * 128 * 4);
+    size_t mx = 0;
+    for (int b = 0; b < NB; ++b) { size_t v = (size_t)P.M[b] * CTOT[b] * 4; if (v > mx) mx = v; }
+    P.dbn_in = take(mx);
+    P.dbn0 = take((size_t)P.M0 * 64 * 4);
+    P.pooled = take((size_t)B * 1024 * 4);
+    P.tab_pack = take(sizeof(PackEntry) * NLAYER);
+    P.tab_bn = take(sizeof(BnRunEntry) * NBN);
+    P.stats_begin = o;
+    P.st_y0 = take(2 * 64 * 8);
+    for (int b = 0; b < NB; ++b) P.st_slab[b] = take((size_t)2 * CTOT[b] * 8);
+    for (int i = 0; i < NLAYER; ++i) P.st_y1[i] = take(2 * 128 * 8);
+    P.bb_y0 = take(2 * 64 * 8);
+    for (int i = 0; i < NLAYER; ++i) P.bb_y1[i] = take(2 * 128 * 8);
+    for (int i = 0; i < NLAYER; ++i) P.bb_in[i] = take(2 * 1024 * 8);
+    for (int i = 0; i < 3; ++i) P.bb_tr[i] = take(2 * 1024 * 8);
+    P.stats_end = o;
+    P.total = o;
+    return true;
+}
+
+// parameter-table indexing
+struct Idx {
+    int conv0 = 0, n0w = 1, n0b = 2;
+    int layer[NLAYER];          // first of the 6 tensors of dense layer l
+    int trans[3];               // first of the 3 tensors of transition t
+    int n5w, n5b, outw, outb;
+    int bn_layer1[NLAYER], bn_layer2[NLAYER], bn_trans[3], bn5, bn0 = 0;   // BatchNorm ordinal (buffer table)
+    Idx() {
+        int p = 3, q = 1, l = 0;
+        for (int b = 0; b < NB; ++b) {
+            for (int i = 0; i < LAYERS[b]; ++i, ++l) { layer[l] = p; p += 6; bn_layer1[l] = q++; bn_layer2[l] = q++; }
+            if (b < 3) { trans[b] = p; p += 3; bn_trans[b] = q++; }
+        }
+        n5w = p++; n5b = p++; bn5 = q++; outw = p++; outb = p++;
+    }
+};
+const Idx IDX;
+
+template <class T> inline T* at(void* ws, size_t off) { return (T*)((char*)ws + off); }
+
+inline BnSrc mk_bn(void* ws, size_t st_off, int Ctot_, const float* const* prm, int iw, const void* const* buf, int bn_ord,
+                   int count, int train) {
+    BnSrc b;
+    b.sum = at<double>(ws, st_off);
+    b.sumsq = at<double>(ws, st_off) + Ctot_;
+    b.rmean = buf ? (const float*)buf[3 * bn_ord] : nullptr;
+    b.rvar = buf ? (const float*)buf[3 * bn_ord + 1] : nullptr;
+    b.gamma = prm[iw]; b.beta = prm[iw + 1];
+    b.inv_count = 1.0f / (float)count; b.eps = 1e-5f; b.train = train;
+    return b;
+}
+
+}  // namespace
+
+extern "C" int mms_init_coords(int*, int, int, int, int, hipStream_t);
+extern "C" int mms_pack_conv3_table(const void*, int, hipStream_t);
+extern "C" int mms_bn_running_update(const void*, int, float, hipStream_t);
+extern "C" int mms_conv0_fwd(const Conv0FwdP*, hipStream_t);
+extern "C" int mms_pool_fwd(const PoolFwdP*, hipStream_t);
+extern "C" int mms_conv1_fwd(const Conv1FwdP*, hipStream_t);
+extern "C" int mms_conv3_fwd(const Conv3FwdP*, hipStream_t);
+extern "C" int mms_head_fwd(const HeadFwdP*, hipStream_t);
+extern "C" int mms_conv3_bwd_data(const Conv3BwdDataP*, hipStream_t);
+extern "C" int mms_conv3_bwd_weight(const Conv3BwdWP*, hipStream_t);
+extern "C" int mms_conv1_bwd_data(const Conv1BwdP*, hipStream_t);
+extern "C" int mms_conv1_bwd_weight(const Conv1BwdP*, hipStream_t);
+extern "C" int mms_bn_bwd_apply(const BnBwdApplyP*, hipStream_t);
+extern "C" int mms_head_bwd(const HeadBwdP*, hipStream_t);
+extern "C" int mms_pool_bwd(const PoolBwdP*, hipStream_t);
+extern "C" int mms_conv0_bwd_weight(const Conv0BwdWP*, hipStream_t);
+
+#define TRY(x) do { int rc_ = (x); if (rc_ != MMS_OK) return rc_; } while (0)
+
+extern "C" int mms_dn121_workspace_bytes(int B, int D, int H, int W, size_t* bytes) {
+    Plan P;
+    if (!make_plan(P, B, D, H, W) || !bytes) return MMS_ERR_ARG;
+    *bytes = P.total;
+    return MMS_OK;
+}
+
+// Named workspace regions, for tests/diagnostics: returns byte offset and size.
+extern "C" int mms_dn121_region(int B, int D, int H, int W, const char* name, int index, size_t* off, size_t* bytes) {
+    Plan P;
+    if (!make_plan(P, B, D, H, W)) return MMS_ERR_ARG;
+    auto set = [&](size_t o, size_t n) { *off = o; *bytes = n; return MMS_OK; };
+    if (!strcmp(name, "y0")) return set(P.y0, (size_t)P.M0 * 64 * 4);
+    if (!strcmp(name, "slab") && index >= 0 && index < NB) return set(P.slab[index], (size_t)P.M[index] * CTOT[index] * 4);
+    if (!strcmp(name, "dslab") && index >= 0 && index < NB) return set(P.dslab[index], (size_t)P.M[index] * CTOT[index] * 4);
+    if (!strcmp(name, "y1") && index >= 0 && index < NLAYER) {
+        int b = 0, l = index;
+        while (l >= LAYERS[b]) { l -= LAYERS[b]; ++b; }
+        return set(P.y1[index], (size_t)P.M[b] * 128 * 4);
+    }
+    if (!strcmp(name, "stats")) return set(P.stats_begin, P.stats_end - P.stats_begin);
+    return MMS_ERR_ARG;
+}
+
+// One-time (per workspace / per parameter-pointer set) initialisation: coordinate tables + device tables.
+extern "C" int mms_dn121_init(void* ws, int B, int D, int H, int W, const void* const* params,
+                              const void* const* buffers, hipStream_t s) {
+    Plan P;
+    if (!make_plan(P, B, D, H, W) || !ws || !params || !buffers) return MMS_ERR_ARG;
+    TRY(mms_init_coords(at<int>(ws, P.coords0), B, P.g0.D, P.g0.H, P.g0.W, s));
+    for (int b = 0; b < NB; ++b) TRY(mms_init_coords(at<int>(ws, P.coords[b]), B, P.g[b].D, P.g[b].H, P.g[b].W, s));
+    PackEntry pk[NLAYER];
+    BnRunEntry bn[NBN];
+    auto set_bn = [&](int ord, size_t st, int Ctot_, int C, int count) {
+        bn[ord].sum = at<double>(ws, st); bn[ord].sumsq = at<double>(ws, st) + Ctot_;
+        bn[ord].rmean = (float*)buffers[3 * ord]; bn[ord].rvar = (float*)buffers[3 * ord + 1];
+        bn[ord].nbt = (long long*)buffers[3 * ord + 2]; bn[ord].C = C; bn[ord].count = (float)count;
+    };
+    set_bn(0, P.st_y0, 64, 64, P.M0);
+    int l = 0;
+    for (int b = 0; b < NB; ++b) {
+        int C = C0[b];
+        for (int i = 0; i < LAYERS[b]; ++i, ++l, C += 32) {
+            pk[l].w = (const float*)params[IDX.layer[l] + 5];
+            pk[l].wpf = at<float>(ws, P.wpf[l]); pk[l].wpb = at<float>(ws, P.wpb[l]);
+            set_bn(IDX.bn_layer1[l], P.st_slab[b], CTOT[b], C, P.M[b]);
+            set_bn(IDX.bn_layer2[l], P.st_y1[l], 128, 128, P.M[b]);
+        }
+        if (b < 3) set_bn(IDX.bn_trans[b], P.st_slab[b], CTOT[b], CTOT[b], P.M[b]);
+        else set_bn(IDX.bn5, P.st_slab[b], CTOT[b], CTOT[b], P.M[b]);
+    }
+    if (hipMemcpyAsync(at<void>(ws, P.tab_pack), pk, sizeof(pk), hipMemcpyHostToDevice, s) != hipSuccess) return MMS_ERR_LAUNCH;
+    if (hipMemcpyAsync(at<void>(ws, P.tab_bn), bn, sizeof(bn), hipMemcpyHostToDevice, s) != hipSuccess) return MMS_ERR_LAUNCH;
+    if (hipStreamSynchronize(s) != hipSuccess) return MMS_ERR_LAUNCH;   // pk/bn are stack arrays
+    return MMS_OK;
+}
+
+extern "C" int mms_dn121_forward(void* ws, int B, int D, int H, int W, const float* x, const void* const* params_,
+                                 const void* const* buffers, float* out, int train, hipStream_t s) {
+    Plan P;
+    if (!make_plan(P, B, D, H, W) || !ws || !x || !params_ || !out) return MMS_ERR_ARG;
+    const float* const* prm = (const float* const*)params_;
+    if (train) {
+        if (hipMemsetAsync(at<void>(ws, P.stats_begin), 0, P.stats_end - P.stats_begin, s) != hipSuccess) return MMS_ERR_LAUNCH;
+    }
+    TRY(mms_pack_conv3_table(at<void>(ws, P.tab_pack), NLAYER, s));
+    auto st = [&](size_t off, int Ctot_, int coff, bool sq) -> double* {
+        return train ? at<double>(ws, off) + (sq ? Ctot_ : 0) + coff : nullptr;
+    };
+    {   // stem
+        Conv0FwdP c0{x, P.in, P.g0, at<int>(ws, P.coords0), P.M0, prm[IDX.conv0], at<float>(ws, P.y0),
+                     st(P.st_y0, 64, 0, false), st(P.st_y0, 64, 0, true)};
+        TRY(mms_conv0_fwd(&c0, s));
+        PoolFwdP pf{at<float>(ws, P.y0), P.g0, P.g[0], B, at<float>(ws, P.slab[0]), CTOT[0], at<uint8_t>(ws, P.argmax),
+                    mk_bn(ws, P.st_y0, 64, prm, IDX.n0w, buffers, IDX.bn0, P.M0, train),
+                    st(P.st_slab[0], CTOT[0], 0, false), st(P.st_slab[0], CTOT[0], 0, true)};
+        TRY(mms_pool_fwd(&pf, s));
+    }
+    int l = 0;
+    for (int b = 0; b < NB; ++b) {
+        int C = C0[b];
+        float* slab = at<float>(ws, P.slab[b]);
+        for (int i = 0; i < LAYERS[b]; ++i, ++l, C += 32) {
+            const int ip = IDX.layer[l];
+            Conv1FwdP c1{slab, CTOT[b], P.M[b], C, prm[ip + 2], 128, at<float>(ws, P.y1[l]), 128,
+                         mk_bn(ws, P.st_slab[b], CTOT[b], prm, ip, buffers, IDX.bn_layer1[l], P.M[b], train),
+                         st(P.st_y1[l], 128, 0, false), st(P.st_y1[l], 128, 0, true), 0, Dims3{0, 0, 0}};
+            TRY(mms_conv1_fwd(&c1, s));
+            Conv3FwdP c3{at<float>(ws, P.y1[l]), at<int>(ws, P.coords[b]), P.g[b], P.M[b], at<float>(ws, P.wpf[l]),
+                         slab + C, CTOT[b], mk_bn(ws, P.st_y1[l], 128, prm, ip + 3, buffers, IDX.bn_layer2[l], P.M[b], train),
+                         st(P.st_slab[b], CTOT[b], C, false), st(P.st_slab[b], CTOT[b], C, true)};
+            TRY(mms_conv3_fwd(&c3, s));
+        }
+        if (b < 3) {
+            const int ip = IDX.trans[b];
+            Conv1FwdP t{slab, CTOT[b], P.M[b + 1], CTOT[b], prm[ip + 2], CTOT[b] / 2, at<float>(ws, P.slab[b + 1]), CTOT[b + 1],
+                        mk_bn(ws, P.st_slab[b], CTOT[b], prm, ip, buffers, IDX.bn_trans[b], P.M[b], train),
+                        st(P.st_slab[b + 1], CTOT[b + 1], 0, false), st(P.st_slab[b + 1], CTOT[b + 1], 0, true), 1, P.g[b]};
+            TRY(mms_conv1_fwd(&t, s));
+        }
+    }
+    HeadFwdP hd{at<float>(ws, P.slab[3]), CTOT[3], 1024, B, P.M[3] / B,
+                mk_bn(ws, P.st_slab[3], CTOT[3], prm, IDX.n5w, buffers, IDX.bn5, P.M[3], train),
+                prm[IDX.outw], prm[IDX.outb], 128, at<float>(ws, P.pooled), out};
+    TRY(mms_head_fwd(&hd, s));
+    if (train && buffers) TRY(mms_bn_running_update(at<void>(ws, P.tab_bn), NBN, 0.1f, s));
+    return MMS_OK;
+}
+
+// Backward of the training-mode forward that last ran on this workspace.  grads are ACCUMULATED into
+// (caller zeroes them, e.g. one hipMemsetAsync over a flat gradient buffer).  dout: [B][128].
+extern "C" int mms_dn121_backward(void* ws, int B, int D, int H, int W, const float* x, const void* const* params_,
+                                  const float* dout, void* const* grads_, hipStream_t s) {
+    Plan P;
+    if (!make_plan(P, B, D, H, W) || !ws || !x || !params_ || !dout || !grads_) return MMS_ERR_ARG;
+    const float* const* prm = (const float* const*)params_;
+    float* const* grd = (float* const*)grads_;
+    auto bbsrc = [&](size_t off, int stride) { return BnBwd{at<double>(ws, off), at<double>(ws, off) + stride}; };
+    {
+        HeadBwdP hb{dout, at<float>(ws, P.pooled), at<float>(ws, P.slab[3]), CTOT[3], 1024, B, P.M[3] / B,
+                    mk_bn(ws, P.st_slab[3], CTOT[3], prm, IDX.n5w, nullptr, 0, P.M[3], 1), prm[IDX.outw], 128,
+                    grd[IDX.outw], grd[IDX.outb], grd[IDX.n5w], grd[IDX.n5b], at<float>(ws, P.dslab[3]), CTOT[3]};
+        TRY(mms_head_bwd(&hb, s));
+    }
+    int l = NLAYER;
+    for (int b = NB - 1; b >= 0; --b) {
+        int C = CTOT[b];
+        float* slab = at<float>(ws, P.slab[b]);
+        float* dslab = at<float>(ws, P.dslab[b]);
+        const int M = P.M[b];
+        for (int i = LAYERS[b] - 1; i >= 0; --i) {
+            --l; C -= 32;
+            const int ip = IDX.layer[l];
+            const BnSrc bn1 = mk_bn(ws, P.st_slab[b], CTOT[b], prm, ip, nullptr, 0, M, 1);
+            const BnSrc bn2 = mk_bn(ws, P.st_y1[l], 128, prm, ip + 3, nullptr, 0, M, 1);
+            Conv3BwdDataP bd{dslab + C, CTOT[b], at<int>(ws, P.coords[b]), P.g[b], M, at<float>(ws, P.wpb[l]),
+                             at<float>(ws, P.y1[l]), bn2, at<float>(ws, P.dbn_mid),
+                             at<double>(ws, P.bb_y1[l]), at<double>(ws, P.bb_y1[l]) + 128};
+            TRY(mms_conv3_bwd_data(&bd, s));
+            int ms3 = (M + 511) / 512; if (ms3 < 1) ms3 = 1;
+            Conv3BwdWP bw{at<float>(ws, P.y1[l]), at<int>(ws, P.coords[b]), P.g[b], M, bn2, dslab + C, CTOT[b],
+                          grd[ip + 5], ms3};
+            TRY(mms_conv3_bwd_weight(&bw, s));
+            int ms1 = M / 256; if (ms1 < 1) ms1 = 1; if (ms1 > 32) ms1 = 32;
+            Conv1BwdP c1{};
+            c1.dyraw = at<float>(ws, P.dbn_mid); c1.lddy = 128;
+            c1.y = at<float>(ws, P.y1[l]); c1.ldy = 128;
+            c1.bn_out = bn2; c1.bb_out = bbsrc(P.bb_y1[l], 128); c1.has_bn_out = 1;
+            c1.M = M; c1.N = 128;
+            c1.x = slab; c1.ldx = CTOT[b]; c1.K = C; c1.bn_in = bn1;
+            c1.w = prm[ip + 2]; c1.pool = 0; c1.in = Dims3{0, 0, 0};
+            c1.dw = grd[ip + 2];
+            c1.dbn = at<float>(ws, P.dbn_in); c1.lddbn = CTOT[b];
+            c1.s1 = at<double>(ws, P.bb_in[l]); c1.s2 = at<double>(ws, P.bb_in[l]) + 1024;
+            c1.msplit = ms1; c1.dgamma_out = grd[ip + 3]; c1.dbeta_out = grd[ip + 4];
+            TRY(mms_conv1_bwd_weight(&c1, s));
+            TRY(mms_conv1_bwd_data(&c1, s));
+            BnBwdApplyP ap{at<float>(ws, P.dbn_in), CTOT[b], slab, CTOT[b], dslab, CTOT[b], M, C, bn1,
+                           bbsrc(P.bb_in[l], 1024), 1, grd[ip], grd[ip + 1]};
+            TRY(mms_bn_bwd_apply(&ap, s));
+        }
+        if (b > 0) {   // transition b-1 -> b
+            const int t = b - 1, ip = IDX.trans[t], Kp = CTOT[t], Mp = P.M[t];
+            const BnSrc bnt = mk_bn(ws, P.st_slab[t], CTOT[t], prm, ip, nullptr, 0, Mp, 1);
+            int ms1 = M / 256; if (ms1 < 1) ms1 = 1; if (ms1 > 32) ms1 = 32;
+            Conv1BwdP c1{};
+            c1.dyraw = dslab; c1.lddy = CTOT[b]; c1.y = nullptr; c1.ldy = 0; c1.has_bn_out = 0;
+            c1.bn_out = bnt; c1.bb_out = BnBwd{nullptr, nullptr};
+            c1.M = M; c1.N = Kp / 2;
+            c1.x = at<float>(ws, P.slab[t]); c1.ldx = CTOT[t]; c1.K = Kp; c1.bn_in = bnt;
+            c1.w = prm[ip + 2]; c1.pool = 1; c1.in = P.g[t];
+            c1.dw = grd[ip + 2];
+            c1.dbn = at<float>(ws, P.dbn_in); c1.lddbn = CTOT[t];
+            c1.s1 = at<double>(ws, P.bb_tr[t]); c1.s2 = at<double>(ws, P.bb_tr[t]) + 1024;
+            c1.msplit = ms1; c1.dgamma_out = nullptr; c1.dbeta_out = nullptr;
+            TRY(mms_conv1_bwd_weight(&c1, s));
+            TRY(mms_conv1_bwd_data(&c1, s));
+            BnBwdApplyP ap{at<float>(ws, P.dbn_in), CTOT[t], at<float>(ws, P.slab[t]), CTOT[t], at<float>(ws, P.dslab[t]), CTOT[t],
+                           Mp, Kp, bnt, bbsrc(P.bb_tr[t], 1024), 0, grd[ip], grd[ip + 1]};
+            TRY(mms_bn_bwd_apply(&ap, s));
+        } else {       // stem
+            const BnSrc bn0 = mk_bn(ws, P.st_y0, 64, prm, IDX.n0w, nullptr, 0, P.M0, 1);
+            PoolBwdP pb{dslab, CTOT[0], at<uint8_t>(ws, P.argmax), P.g[0], P.g0, B, at<float>(ws, P.y0), bn0,
+                        at<float>(ws, P.dbn0), at<double>(ws, P.bb_y0), at<double>(ws, P.bb_y0) + 64};
+            TRY(mms_pool_bwd(&pb, s));
+            int ms0 = P.M0 / 1024; if (ms0 < 1) ms0 = 1; if (ms0 > 64) ms0 = 64;
+            Conv0BwdWP cw{at<float>(ws, P.dbn0), at<float>(ws, P.y0), bn0, bbsrc(P.bb_y0, 64), x, P.in, P.g0,
+                          at<int>(ws, P.coords0), P.M0, grd[IDX.conv0], ms0, grd[IDX.n0w], grd[IDX.n0b]};
+            TRY(mms_conv0_bwd_weight(&cw, s));
+        }
+    }
+    return MMS_OK;
+}
