@@ -76,3 +76,65 @@ def pack_conv3(w):
     wpb = torch.empty(128 * 27 * 32, dtype=torch.float32, device=w.device)
     _lib.check(_lib.load_library().mms_pack_conv3(w.data_ptr(), wpf.data_ptr(), wpb.data_ptr(), stream()), "mms_pack_conv3")
     return wpf, wpb
+
+
+# ---- backward ops ---------------------------------------------------------------------------------------
+def bnbwd(s1, s2):
+    return _S()["BnBwd"](ptr(s1), ptr(s2))
+
+
+def conv3_bwd_data(dz, coords, dims, wpb, y1, bn, dbn, s1, s2):
+    p = _S()["Conv3BwdDataP"](ptr(dz), dz.stride(0), ptr(coords), dims3(dims), y1.shape[0], ptr(wpb), ptr(y1), bn,
+                              ptr(dbn), ptr(s1), ptr(s2))
+    call("mms_conv3_bwd_data", p)
+
+
+def conv3_bwd_weight(y1, coords, dims, bn, dz, dw, msplit=1):
+    p = _S()["Conv3BwdWP"](ptr(y1), ptr(coords), dims3(dims), y1.shape[0], bn, ptr(dz), dz.stride(0), ptr(dw), msplit)
+    call("mms_conv3_bwd_weight", p)
+
+
+def conv1_bwd(which, dyraw, M, N, x, K, bn_in, w, dw, dbn, s1, s2, y=None, bn_out=None, bb_out=None, pool=False,
+              in_dims=(0, 0, 0), msplit=1, dgamma_out=None, dbeta_out=None):
+    S = _S()
+    p = S["Conv1BwdP"]()
+    p.dyraw, p.lddy = ptr(dyraw), dyraw.stride(0)
+    p.y, p.ldy = (ptr(y), y.stride(0)) if y is not None else (None, 0)
+    p.has_bn_out = 1 if bn_out is not None else 0
+    p.bn_out = bn_out if bn_out is not None else bn_in
+    p.bb_out = bb_out if bb_out is not None else S["BnBwd"](None, None)
+    p.M, p.N = M, N
+    p.x, p.ldx, p.K, p.bn_in = ptr(x), x.stride(0), K, bn_in
+    setattr(p, "in", dims3(in_dims))
+    p.w = ptr(w)
+    p.pool = 1 if pool else 0
+    p.dw = ptr(dw)
+    p.dbn, p.lddbn = ptr(dbn), dbn.stride(0)
+    p.s1, p.s2 = ptr(s1), ptr(s2)
+    p.msplit = msplit
+    p.dgamma_out, p.dbeta_out = ptr(dgamma_out), ptr(dbeta_out)
+    call("mms_conv1_bwd_weight" if which == "weight" else "mms_conv1_bwd_data", p)
+
+
+def bn_bwd_apply(dbn, x, dx, M, C, bn, bb, accumulate, dgamma, dbeta):
+    p = _S()["BnBwdApplyP"](ptr(dbn), dbn.stride(0), ptr(x), x.stride(0), ptr(dx), dx.stride(0), M, C, bn, bb,
+                            1 if accumulate else 0, ptr(dgamma), ptr(dbeta))
+    call("mms_bn_bwd_apply", p)
+
+
+def head_bwd(dout, pooled, slab, C, B, V, bn, w, dw, dbias, dgamma, dbeta, dslab):
+    p = _S()["HeadBwdP"](ptr(dout), ptr(pooled), ptr(slab), slab.stride(0), C, B, V, bn, ptr(w), w.shape[0],
+                         ptr(dw), ptr(dbias), ptr(dgamma), ptr(dbeta), ptr(dslab), dslab.stride(0))
+    call("mms_head_bwd", p)
+
+
+def pool_bwd(dslab, argmax, out_dims, in_dims, B, y0, bn, dbn, s1, s2):
+    p = _S()["PoolBwdP"](ptr(dslab), dslab.stride(0), ptr(argmax), dims3(out_dims), dims3(in_dims), B, ptr(y0), bn,
+                         ptr(dbn), ptr(s1), ptr(s2))
+    call("mms_pool_bwd", p)
+
+
+def conv0_bwd_weight(dbn, y0, bn, bb, x, in_dims, out_dims, coords, dw, msplit, dgamma, dbeta):
+    p = _S()["Conv0BwdWP"](ptr(dbn), ptr(y0), bn, bb, ptr(x), dims3(in_dims), dims3(out_dims), ptr(coords),
+                           y0.shape[0], ptr(dw), msplit, ptr(dgamma), ptr(dbeta))
+    call("mms_conv0_bwd_weight", p)

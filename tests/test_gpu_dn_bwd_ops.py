@@ -1,0 +1,174 @@
+"""Strict (1e-4) GPU parity of the DenseNet backward ops against torch autograd on CPU, on problems small enough
+that fp32 ReLU-mask flips between two implementations are improbable (a few 1e4 ReLU inputs)."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import DEV, assert_close, cl, stats
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from multimodal_survival_prediction_amd import ops as o
+    return o
+
+
+def _d(t):
+    return t.detach().to(DEV).contiguous()
+
+
+@pytest.mark.parametrize("B,dims,C,Ctot,ms", [(2, (4, 4, 2), 64, 256, 1), (4, (8, 8, 4), 96, 256, 4), (3, (2, 2, 1), 512, 1024, 1),
+                                              (2, (16, 16, 8), 224, 256, 16)])
+def test_dense_layer_backward(ops, B, dims, C, Ctot, ms):
+    """One _DenseLayer: norm1-relu-conv1-norm2-relu-conv2 + cat; gradient w.r.t. every parameter and the input slab."""
+    torch.manual_seed(0)
+    M = B * dims[0] * dims[1] * dims[2]
+    x = (torch.randn(B, C, *dims) * 1.3 + 0.2).requires_grad_(True)
+    n1, n2 = nn.BatchNorm3d(C), nn.BatchNorm3d(128)
+    c1, c2 = nn.Conv3d(C, 128, 1, bias=False), nn.Conv3d(128, 32, 3, padding=1, bias=False)
+    with torch.no_grad():
+        for n in (n1, n2):
+            n.weight.uniform_(0.5, 1.5); n.bias.normal_(0, 0.3)
+    y1 = c1(F.relu(n1(x)))
+    z = c2(F.relu(n2(y1)))
+    out = torch.cat([x, z], 1)
+    dout = torch.randn_like(out)
+    out.backward(dout)
+
+    slab = torch.zeros(M, Ctot, device=DEV); slab[:, :C] = _d(cl(x))
+    dslab = torch.zeros(M, Ctot, device=DEV); dslab[:, :C + 32] = _d(cl(dout))
+    coords = ops.init_coords(B, dims, DEV)
+    g1, b1, g2, b2 = _d(n1.weight), _d(n1.bias), _d(n2.weight), _d(n2.bias)
+    w1, w2 = _d(c1.weight.view(128, C)), _d(c2.weight)
+    wpf, wpb = ops.pack_conv3(w2)
+    sx, qx = slab[:, :C].double().sum(0), (slab[:, :C].double() ** 2).sum(0)
+    bn1 = ops.bnsrc(g1, b1, M, True, sx, qx)
+    y1d = torch.empty(M, 128, device=DEV)
+    s1y, q1y = stats(DEV, 128)
+    ops.conv1_fwd(slab, C, w1, y1d, bn1, M, s1y, q1y)
+    bn2 = ops.bnsrc(g2, b2, M, True, s1y, q1y)
+    ops.conv3_fwd(y1d, coords, dims, wpf, slab[:, C:C + 32], bn2)
+    assert_close(slab[:, C:C + 32], cl(z), 1e-4, "fwd z")
+    # backward chain, in the driver's order
+    dbn_mid = torch.empty(M, 128, device=DEV)
+    a1, a2 = stats(DEV, 128)
+    ops.conv3_bwd_data(dslab[:, C:C + 32], coords, dims, wpb, y1d, bn2, dbn_mid, a1, a2)
+    dw2 = torch.zeros_like(w2)
+    ops.conv3_bwd_weight(y1d, coords, dims, bn2, dslab[:, C:C + 32], dw2, ms)
+    dw1 = torch.zeros_like(w1)
+    dg2, db2, dg1, db1 = (torch.zeros(128, device=DEV), torch.zeros(128, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV))
+    dbn_in = torch.empty(M, Ctot, device=DEV)
+    e1, e2 = stats(DEV, 1024)
+    bb2 = ops.bnbwd(a1, a2)
+    kw = dict(y=y1d, bn_out=bn2, bb_out=bb2, msplit=ms, dgamma_out=dg2, dbeta_out=db2)
+    ops.conv1_bwd("weight", dbn_mid, M, 128, slab, C, bn1, w1, dw1, dbn_in, e1, e2, **kw)
+    ops.conv1_bwd("data", dbn_mid, M, 128, slab, C, bn1, w1, dw1, dbn_in, e1, e2, **kw)
+    ops.bn_bwd_apply(dbn_in, slab, dslab, M, C, bn1, ops.bnbwd(e1, e2), True, dg1, db1)
+    torch.cuda.synchronize()
+    assert_close(dw2, c2.weight.grad, 1e-4, "dW conv2")
+    assert_close(dg2, n2.weight.grad, 1e-4, "dgamma2")
+    assert_close(db2, n2.bias.grad, 1e-4, "dbeta2")
+    assert_close(dw1, c1.weight.grad.view(128, C), 1e-4, "dW conv1")
+    assert_close(dg1, n1.weight.grad, 1e-4, "dgamma1")
+    assert_close(db1, n1.bias.grad, 1e-4, "dbeta1")
+    assert_close(dslab[:, :C], cl(x.grad), 1e-4, "dx (accumulated into the gradient slab)")
+
+
+@pytest.mark.parametrize("B,dims,C,ms", [(2, (4, 4, 2), 256, 1), (2, (8, 8, 4), 512, 2), (4, (2, 2, 2), 1024, 1)])
+def test_transition_backward(ops, B, dims, C, ms):
+    torch.manual_seed(1)
+    M = B * dims[0] * dims[1] * dims[2]
+    N = C // 2
+    x = (torch.randn(B, C, *dims) + 0.3).requires_grad_(True)
+    n, c = nn.BatchNorm3d(C), nn.Conv3d(C, N, 1, bias=False)
+    with torch.no_grad():
+        n.weight.uniform_(0.5, 1.5); n.bias.normal_(0, 0.3)
+    out = F.avg_pool3d(c(F.relu(n(x))), 2, 2)
+    dout = torch.randn_like(out)
+    out.backward(dout)
+    slab = _d(cl(x))
+    g, b, w = _d(n.weight), _d(n.bias), _d(c.weight.view(N, C))
+    sx, qx = slab.double().sum(0), (slab.double() ** 2).sum(0)   # keep alive: bnsrc stores raw pointers
+    bn = ops.bnsrc(g, b, M, True, sx, qx)
+    dnext = torch.zeros(M // 8, 2 * C, device=DEV); dnext[:, :N] = _d(cl(dout))
+    dw = torch.zeros_like(w)
+    dbn_in = torch.empty(M, C, device=DEV)
+    e1, e2 = stats(DEV, 1024)
+    for which in ("weight", "data"):
+        ops.conv1_bwd(which, dnext, M // 8, N, slab, C, bn, w, dw, dbn_in, e1, e2, pool=True, in_dims=dims, msplit=ms)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dx = torch.full((M, C), 7.0, device=DEV)     # assign semantics: previous content must not matter
+    ops.bn_bwd_apply(dbn_in, slab, dx, M, C, bn, ops.bnbwd(e1, e2), False, dg, db)
+    torch.cuda.synchronize()
+    assert_close(dw, c.weight.grad.view(N, C), 1e-4, "dW")
+    assert_close(dg, n.weight.grad, 1e-4, "dgamma")
+    assert_close(db, n.bias.grad, 1e-4, "dbeta")
+    assert_close(dx, cl(x.grad), 1e-4, "dx")
+
+
+@pytest.mark.parametrize("B,dims,ms", [(2, (16, 16, 8), 1), (1, (32, 32, 16), 4), (2, (12, 8, 10), 2)])
+def test_stem_backward(ops, B, dims, ms):
+    torch.manual_seed(2)
+    x = torch.rand(B, 1, *dims)
+    c0, n0 = nn.Conv3d(1, 64, 7, stride=2, padding=3, bias=False), nn.BatchNorm3d(64)
+    with torch.no_grad():
+        n0.weight.uniform_(0.5, 1.5); n0.bias.normal_(0, 0.3)
+    y0 = c0(x)
+    p0 = F.max_pool3d(F.relu(n0(y0)), 3, 2, 1)
+    dout = torch.randn_like(p0)
+    p0.backward(dout)
+    od, pd = tuple(y0.shape[2:]), tuple(p0.shape[2:])
+    M0, M1 = B * od[0] * od[1] * od[2], B * pd[0] * pd[1] * pd[2]
+    xd, w0 = _d(x), _d(c0.weight.view(64, 343))
+    g, b = _d(n0.weight), _d(n0.bias)
+    coords = ops.init_coords(B, od, DEV)
+    y0d = torch.empty(M0, 64, device=DEV)
+    s, q = stats(DEV, 64)
+    ops.conv0_fwd(xd, dims, od, coords, w0, y0d, s, q)
+    bn = ops.bnsrc(g, b, M0, True, s, q)
+    slab = torch.zeros(M1, 256, device=DEV)
+    am = torch.zeros(M1, 64, dtype=torch.uint8, device=DEV)
+    ops.pool_fwd(y0d, od, pd, B, slab, am, bn)
+    dslab = torch.zeros(M1, 256, device=DEV); dslab[:, :64] = _d(cl(dout))
+    dbn0 = torch.empty(M0, 64, device=DEV)
+    a1, a2 = stats(DEV, 64)
+    ops.pool_bwd(dslab, am, pd, od, B, y0d, bn, dbn0, a1, a2)
+    dw, dg, db = torch.zeros_like(w0), torch.zeros(64, device=DEV), torch.zeros(64, device=DEV)
+    ops.conv0_bwd_weight(dbn0, y0d, bn, ops.bnbwd(a1, a2), xd, dims, od, coords, dw, ms, dg, db)
+    torch.cuda.synchronize()
+    assert_close(dw, c0.weight.grad.view(64, 343), 1e-4, "dW0")
+    assert_close(dg, n0.weight.grad, 1e-4, "dgamma0")
+    assert_close(db, n0.bias.grad, 1e-4, "dbeta0")
+
+
+@pytest.mark.parametrize("B,V", [(4, 4), (2, 8), (8, 1)])
+def test_head_backward(ops, B, V):
+    torch.manual_seed(3)
+    C = 1024
+    x = (torch.randn(B, C, V, 1, 1) + 0.2).requires_grad_(True)
+    n5, lin = nn.BatchNorm3d(C), nn.Linear(C, 128)
+    with torch.no_grad():
+        n5.weight.uniform_(0.5, 1.5); n5.bias.normal_(0, 0.3)
+    out = lin(F.relu(n5(x)).mean(dim=(2, 3, 4)))
+    dout = torch.randn_like(out)
+    out.backward(dout)
+    slab = _d(cl(x))
+    g, b, w, bias = _d(n5.weight), _d(n5.bias), _d(lin.weight), _d(lin.bias)
+    sx, qx = slab.double().sum(0), (slab.double() ** 2).sum(0)   # keep alive: bnsrc stores raw pointers
+    bn = ops.bnsrc(g, b, B * V, True, sx, qx)
+    pooled, o = torch.empty(B, C, device=DEV), torch.empty(B, 128, device=DEV)
+    ops.head_fwd(slab, C, B, V, bn, w, bias, pooled, o)
+    dw, dbias = torch.zeros_like(w), torch.zeros(128, device=DEV)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dslab = torch.empty(B * V, C, device=DEV)
+    ops.head_bwd(_d(dout), pooled, slab, C, B, V, bn, w, dw, dbias, dg, db, dslab)
+    torch.cuda.synchronize()
+    assert_close(o, out, 1e-4, "head fwd")
+    assert_close(dw, lin.weight.grad, 1e-4, "dW out")
+    assert_close(dbias, lin.bias.grad, 1e-4, "dbias")
+    assert_close(dg, n5.weight.grad, 1e-4, "dgamma5")
+    assert_close(db, n5.bias.grad, 1e-4, "dbeta5")
+    assert_close(dslab, cl(x.grad), 1e-4, "dslab4")

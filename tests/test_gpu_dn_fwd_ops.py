@@ -154,7 +154,7 @@ def test_head_fwd(ops, B, V, C):
     slab = cl(x).to(DEV)
     s, q = slab.double().sum(0), (slab.double() ** 2).sum(0)
     gd, bd = g.to(DEV), b.to(DEV)
-    bn = ops.bnsrc(gd, bd, B * V, True, s, q)
+    bn = ops.bnsrc(gd, bd, B * V, True, s, q)   # s, q, gd, bd stay referenced: bnsrc stores raw pointers
     pd_, out = torch.empty(B, C, device=DEV), torch.empty(B, 128, device=DEV)
     ops.head_fwd(slab, C, B, V, bn, w.to(DEV), bias.to(DEV), pd_, out)
     torch.cuda.synchronize()
