@@ -104,7 +104,7 @@ typedef struct HeadFwdP {
     BnSrc bn;
     const float* w; const float* bias; int N;          // [N][C]
     float* pooled;                                     // [B][C] saved for backward
-    float* out;                                        // [B][N]
+    float* out; int ldo;                               // [B][ldo] first N columns written
 } HeadFwdP;
 
 // =========================== backward ==================================================================
@@ -166,7 +166,7 @@ typedef struct BnBwdApplyP {
 } BnBwdApplyP;
 
 typedef struct HeadBwdP {
-    const float* dout;              // [B][N]
+    const float* dout; int lddout;  // [B][lddout] first N columns read
     const float* pooled;            // [B][C]
     const float* slab; int ld; int C; int B; int V; BnSrc bn;
     const float* w; int N;
@@ -189,6 +189,88 @@ typedef struct Conv0BwdWP {                 // dW0[64][343] += sum_m bn0bwd(dbn0
     float* dw; int msplit;
     float* dgamma; float* dbeta;    // [64]
 } Conv0BwdWP;
+
+/* =========================== heads: small-batch MLP, gate, Cox, optimizer ============================== */
+/* Input prologue of a Linear layer: x' = dropout(relu(bn1d(x))) -- the BatchNorm1d/ReLU/Dropout that FOLLOW the
+ * previous Linear in the reference's nn.Sequential (R/scripts/training/final_multimodal.py:93-117) are applied
+ * while this layer reads its input.  All M rows of a column sit in one lane, so batch statistics need no atomics. */
+typedef struct InProlog {
+    int bn;                         // 1: BatchNorm1d (+ReLU) on the input columns
+    const float* gamma; const float* beta;
+    float* rmean; float* rvar; long long* nbt;   // running stats (read in eval, momentum-updated in train by fwd)
+    float eps; float momentum;
+    int train;
+    float drop_p;                   // dropout probability applied after bn+relu (0 = none; ignored in eval)
+    const float* drop_mask;         // optional explicit multiplicative mask [M][K] (already scaled by 1/(1-p)); parity mode
+    const uint32_t* rng;            // device {seed, step} for the hash RNG when drop_mask is null
+    uint32_t stream_id;             // distinguishes dropout sites
+} InProlog;
+
+typedef struct LinearFwdP {
+    const float* x; int ldx; int M; int K;
+    InProlog pro;
+    const float* w; const float* bias; int N;     // torch Linear: w [N][K]
+    float* y; int ldy; int out_relu;              // y = [relu](x' W^T + b)
+} LinearFwdP;
+
+typedef struct LinearBwdP {
+    const float* dy; int lddy;      // gradient w.r.t. y (post-activation) [M][lddy]
+    const float* y; int ldy;        // forward output (relu mask when out_relu)
+    int out_relu;
+    const float* x; int ldx; int M; int K; InProlog pro;
+    const float* w; int N;
+    float* dw; float* dbias;        // accumulated (+=)
+    float* dx; int lddx;            // gradient w.r.t. the RAW input x (before the prologue) [M][lddx]; null = skip
+    float* dgamma; float* dbeta;    // prologue BN parameter grads (+=), null when pro.bn == 0
+} LinearBwdP;
+
+/* Gated late fusion (R/scripts/training/partial_modality_training.py:257-271): feats [M][288] = ct|rna|clin,
+ * mask [M][3]; masked = feats*mask; gate = softmax(W2 relu(W1 [masked|mask] + b1) + b2); fused = masked*gate. */
+typedef struct GateP {
+    const float* feats; const float* mask; int M;
+    const float* w1; const float* b1; const float* w2; const float* b2;   // [64][291],[64],[3][64],[3]
+    float* hidden;                  // [M][64] saved
+    float* gate;                    // [M][3]  saved / output
+    float* fused;                   // [M][288]
+    // backward
+    const float* dfused;            // [M][288]
+    float ent_weight;               // lambda * upstream of gate_entropy_loss (R/...:322-331); 0 = none
+    float* dfeats;                  // [M][288]
+    float* dw1; float* db1; float* dw2; float* db2;   // accumulated (atomics)
+    float* entropy;                 // optional scalar out (fwd): -mean_b(entropy_b)
+} GateP;
+
+/* Cox negative partial log-likelihood, Breslow risk sets (R/scripts/training/final_multimodal.py:171-186;
+ * torchsurv on untied times): loss = -(1/n_e) sum_{i:e_i} (h_i - log sum_{j: t_j>=t_i} exp h_j).
+ * valid: optional per-sample 0/1 (has_survival); excluded samples get dh = 0.
+ * out[0] = loss, out[1] = 1 if the batch is usable (>=2 valid samples and >=1 event) else 0 (loss 0, dh 0). */
+typedef struct CoxP {
+    const float* h; int ldh;        // log-hazards, element i at h[i*ldh]
+    const float* time; const float* event; const float* valid; int n;
+    float scale;                    // upstream gradient
+    float* lse;                     // [n] workspace (multi-block path)
+    float* dh; int lddh;            // dL/dh (null = forward only)
+    float* out;                     // [2]
+} CoxP;
+
+/* Harrell C, pair counting (R/scripts/training/simple_fusion.py:59-73): counts[0]=concordant (h_i>h_j),
+ * counts[1]=tied hazards, counts[2]=permissible pairs (e_i==1, t_j>t_i). */
+typedef struct CindexP {
+    const float* h; const float* time; const float* event; int n;
+    unsigned long long* counts;     // [3], zeroed by the caller
+} CindexP;
+
+/* clip_grad_norm_(max_norm) + Adam/AdamW over one flat fp32 parameter buffer (R/...final_multimodal.py:259-260,350;
+ * simple_fusion.py:273-274,391).  hyper (device): {lr, beta1, beta2, eps, weight_decay, max_norm}; state (device):
+ * {step (as float), sumsq scratch (double as 2 floats)}; skip: optional device flag, 0 => no-op (degenerate batch). */
+typedef struct AdamP {
+    float* p; float* g; float* m; float* v; long long n;
+    const float* hyper;             // [6]
+    double* sumsq;                  // [1] zeroed by mms_grad_sumsq's caller each step
+    float* step;                    // [1] step counter (incremented by the update kernel when not skipped)
+    const float* skip_flag;         // null or device scalar: update only if *skip_flag != 0
+    int adamw;                      // 0: Adam with L2-coupled weight decay; 1: AdamW (decoupled)
+} AdamP;
 
 /* ---- ABI self-description ---- */
 int mms_abi_sizeof(const char* name);      /* sizeof(struct <name>) as compiled, -1 if unknown */
@@ -215,6 +297,16 @@ int mms_pack_conv3_table(const void* table_dev, int nlayers, hipStream_t s);
 int mms_bn_running_update(const void* table_dev, int n, float momentum, hipStream_t s);
 
 
+/* ---- heads ---- */
+int mms_linear_fwd(const LinearFwdP* p, hipStream_t s);        /* nn.Linear (+ preceding BN1d/ReLU/Dropout, + following ReLU) */
+int mms_linear_bwd(const LinearBwdP* p, hipStream_t s);
+int mms_gate_fwd(const GateP* p, hipStream_t s);
+int mms_gate_bwd(const GateP* p, hipStream_t s);
+int mms_cox_fwd_bwd(const CoxP* p, hipStream_t s);
+int mms_cindex_counts(const CindexP* p, hipStream_t s);
+int mms_grad_sumsq(const AdamP* p, hipStream_t s);             /* sum of squares of the flat gradient (fp64 atomics) */
+int mms_clip_adam(const AdamP* p, hipStream_t s);              /* clip by global norm + Adam/AdamW update */
+
 /* ---- whole-encoder driver: replaces `self.ct_encoder(ct)` / `self.image_encoder(image)` and its autograd
  *      (R/scripts/training/final_multimodal.py:124, partial_modality_training.py:245, simple_fusion.py:226).
  *      params: 364 device pointers in torch named_parameters() order of MONAI DenseNet121;
@@ -224,9 +316,9 @@ int mms_dn121_workspace_bytes(int B, int D, int H, int W, size_t* bytes);
 int mms_dn121_region(int B, int D, int H, int W, const char* name, int index, size_t* off, size_t* bytes);
 int mms_dn121_init(void* ws, int B, int D, int H, int W, const void* const* params, const void* const* buffers, hipStream_t s);
 int mms_dn121_forward(void* ws, int B, int D, int H, int W, const float* x, const void* const* params,
-                      const void* const* buffers, float* out, int train, hipStream_t s);
+                      const void* const* buffers, float* out, int ldo, int train, hipStream_t s);
 int mms_dn121_backward(void* ws, int B, int D, int H, int W, const float* x, const void* const* params,
-                       const float* dout, void* const* grads, hipStream_t s);
+                       const float* dout, int lddout, void* const* grads, hipStream_t s);
 
 #ifdef __cplusplus
 }

@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void head_bwd_feat_kernel(const HeadBwdP p) {
     double s1 = 0, s2 = 0;
     for (int b = 0; b < p.B; ++b) {
         float dp = 0;
-        for (int n = 0; n < p.N; ++n) dp = fmaf(p.dout[b * p.N + n], p.w[(size_t)n * p.C + c], dp);
+        for (int n = 0; n < p.N; ++n) dp = fmaf(p.dout[b * p.lddout + n], p.w[(size_t)n * p.C + c], dp);
         dp *= invV;
         for (int v = 0; v < p.V; ++v) {
             const size_t m = (size_t)b * p.V + v;
@@ -439,11 +439,11 @@ __global__ __launch_bounds__(256) void head_bwd_w_kernel(const HeadBwdP p) {
     if (idx >= p.N * p.C) return;
     const int n = idx / p.C, c = idx % p.C;
     float a = 0;
-    for (int b = 0; b < p.B; ++b) a = fmaf(p.dout[b * p.N + n], p.pooled[b * p.C + c], a);
+    for (int b = 0; b < p.B; ++b) a = fmaf(p.dout[b * p.lddout + n], p.pooled[b * p.C + c], a);
     p.dw[idx] += a;
     if (c == 0) {
         float d = 0;
-        for (int b = 0; b < p.B; ++b) d += p.dout[b * p.N + n];
+        for (int b = 0; b < p.B; ++b) d += p.dout[b * p.lddout + n];
         p.dbias[n] += d;
     }
 }

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadFwdP p) {
         float a = 0;
         for (int c = lane; c < p.C; c += 64) a = fmaf(p.w[(size_t)n * p.C + c], pooled[b * p.C + c], a);
         a = wave_sum(a);
-        if (lane == 0) p.out[b * p.N + n] = a + p.bias[n];
+        if (lane == 0) p.out[b * p.ldo + n] = a + p.bias[n];
     }
 }
 

@@ -196,7 +196,7 @@ extern "C" int mms_dn121_init(void* ws, int B, int D, int H, int W, const void* 
 }
 
 extern "C" int mms_dn121_forward(void* ws, int B, int D, int H, int W, const float* x, const void* const* params_,
-                                 const void* const* buffers, float* out, int train, hipStream_t s) {
+                                 const void* const* buffers, float* out, int ldo, int train, hipStream_t s) {
     Plan P;
     if (!make_plan(P, B, D, H, W) || !ws || !x || !params_ || !out) return MMS_ERR_ARG;
     const float* const* prm = (const float* const*)params_;
@@ -241,7 +241,7 @@ extern "C" int mms_dn121_forward(void* ws, int B, int D, int H, int W, const flo
     }
     HeadFwdP hd{at<float>(ws, P.slab[3]), CTOT[3], 1024, B, P.M[3] / B,
                 mk_bn(ws, P.st_slab[3], CTOT[3], prm, IDX.n5w, buffers, IDX.bn5, P.M[3], train),
-                prm[IDX.outw], prm[IDX.outb], 128, at<float>(ws, P.pooled), out};
+                prm[IDX.outw], prm[IDX.outb], 128, at<float>(ws, P.pooled), out, ldo};
     TRY(mms_head_fwd(&hd, s));
     if (train && buffers) TRY(mms_bn_running_update(at<void>(ws, P.tab_bn), NBN, 0.1f, s));
     return MMS_OK;
@@ -250,14 +250,14 @@ extern "C" int mms_dn121_forward(void* ws, int B, int D, int H, int W, const flo
 // Backward of the training-mode forward that last ran on this workspace.  grads are ACCUMULATED into
 // (caller zeroes them, e.g. one hipMemsetAsync over a flat gradient buffer).  dout: [B][128].
 extern "C" int mms_dn121_backward(void* ws, int B, int D, int H, int W, const float* x, const void* const* params_,
-                                  const float* dout, void* const* grads_, hipStream_t s) {
+                                  const float* dout, int lddout, void* const* grads_, hipStream_t s) {
     Plan P;
     if (!make_plan(P, B, D, H, W) || !ws || !x || !params_ || !dout || !grads_) return MMS_ERR_ARG;
     const float* const* prm = (const float* const*)params_;
     float* const* grd = (float* const*)grads_;
     auto bbsrc = [&](size_t off, int stride) { return BnBwd{at<double>(ws, off), at<double>(ws, off) + stride}; };
     {
-        HeadBwdP hb{dout, at<float>(ws, P.pooled), at<float>(ws, P.slab[3]), CTOT[3], 1024, B, P.M[3] / B,
+        HeadBwdP hb{dout, lddout, at<float>(ws, P.pooled), at<float>(ws, P.slab[3]), CTOT[3], 1024, B, P.M[3] / B,
                     mk_bn(ws, P.st_slab[3], CTOT[3], prm, IDX.n5w, nullptr, 0, P.M[3], 1), prm[IDX.outw], 128,
                     grd[IDX.outw], grd[IDX.outb], grd[IDX.n5w], grd[IDX.n5b], at<float>(ws, P.dslab[3]), CTOT[3]};
         TRY(mms_head_bwd(&hb, s));

@@ -1,0 +1,454 @@
+// Heads of the survival networks for gfx950: small-batch Linear layers with the neighbouring
+// BatchNorm1d / ReLU / Dropout fused in, the softmax gate, the Cox partial likelihood, Harrell's C and the
+// clip + Adam update.  Replaces the torch op sequences at final_multimodal.py:93-120,137-148,171-186,259-260;
+// partial_modality_training.py:213-218,257-275,322-331; simple_fusion.py:167-178,206-215,47-73.
+//
+// Batch rows M <= 32: every lane keeps all M rows of "its" input column in registers, so BatchNorm1d batch
+// statistics, their backward and the per-row dropout are lane-local (no atomics, no extra launches); weights
+// are streamed once with coalesced loads (these layers are HBM/L2-bound: 2.7 M parameters, 4 rows).
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------------
+// input prologue  x' = dropout(relu(bn1d(x)))  on the M values of one column, lane-local
+// ------------------------------------------------------------------------------------------------------
+template <int MM>
+struct ColProlog {
+    float xhat[MM], pre[MM], scale[MM];   // saved for the backward
+    float mean, rstd, gamma;
+    template <bool UPDATE_RUNNING>
+    __device__ __forceinline__ void apply(const InProlog& pr, float (&x)[MM], int M, int k, int K) {
+        if (pr.bn) {
+            float mu, var;
+            if (pr.train) {
+                mu = 0;
+#pragma unroll
+                for (int m = 0; m < MM; ++m) if (m < M) mu += x[m];
+                mu /= (float)M;
+                var = 0;
+#pragma unroll
+                for (int m = 0; m < MM; ++m) if (m < M) { float d = x[m] - mu; var = fmaf(d, d, var); }
+                var /= (float)M;
+                if (UPDATE_RUNNING) {
+                    const float unb = M > 1 ? var * (float)M / (float)(M - 1) : var;
+                    pr.rmean[k] = (1.f - pr.momentum) * pr.rmean[k] + pr.momentum * mu;
+                    pr.rvar[k] = (1.f - pr.momentum) * pr.rvar[k] + pr.momentum * unb;
+                }
+            } else {
+                mu = pr.rmean[k]; var = pr.rvar[k];
+            }
+            mean = mu; rstd = 1.0f / sqrtf(var + pr.eps); gamma = pr.gamma[k];
+            const float be = pr.beta[k];
+#pragma unroll
+            for (int m = 0; m < MM; ++m) {
+                xhat[m] = (x[m] - mu) * rstd;
+                pre[m] = fmaf(gamma, xhat[m], be);
+                x[m] = fmaxf(pre[m], 0.f);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MM; ++m) scale[m] = 1.f;
+        if (pr.train && (pr.drop_mask || pr.drop_p > 0.f)) {
+#pragma unroll
+            for (int m = 0; m < MM; ++m) {
+                if (m < M) {
+                    scale[m] = pr.drop_mask ? pr.drop_mask[(size_t)m * K + k]
+                                            : dropout_scale(pr.rng[0] + 0x9E3779B9u * pr.rng[1], pr.stream_id, (uint32_t)(m * K + k), pr.drop_p);
+                    x[m] *= scale[m];
+                }
+            }
+        }
+    }
+};
+
+template <int MM>
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const LinearFwdP p) {
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= p.N) return;
+    const bool upd = (n == 0) && p.pro.bn && p.pro.train;
+    float acc[MM];
+#pragma unroll
+    for (int m = 0; m < MM; ++m) acc[m] = 0.f;
+    for (int k = lane; k < p.K; k += 64) {
+        float x[MM];
+#pragma unroll
+        for (int m = 0; m < MM; ++m) x[m] = m < p.M ? p.x[(size_t)m * p.ldx + k] : 0.f;
+        ColProlog<MM> cp;
+        if (upd) cp.template apply<true>(p.pro, x, p.M, k, p.K); else cp.template apply<false>(p.pro, x, p.M, k, p.K);
+        const float w = p.w[(size_t)n * p.K + k];
+#pragma unroll
+        for (int m = 0; m < MM; ++m) acc[m] = fmaf(w, x[m], acc[m]);
+    }
+    if (upd && lane == 0 && p.pro.nbt) *p.pro.nbt += 1;
+    const float b = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+        float v = wave_sum(acc[m]);
+        if (lane == 0 && m < p.M) {
+            v += b;
+            p.y[(size_t)m * p.ldy + n] = p.out_relu ? fmaxf(v, 0.f) : v;
+        }
+    }
+}
+
+template <int MM>
+static int launch_linear_fwd(const LinearFwdP& p, hipStream_t s) {
+    hipLaunchKernelGGL(linear_fwd_kernel<MM>, dim3((p.N + 3) / 4), dim3(256), 0, s, p);
+    return mms_check_launch();
+}
+extern "C" int mms_linear_fwd(const LinearFwdP* pp, hipStream_t s) {
+    const LinearFwdP& p = *pp;
+    if (p.M <= 0 || p.M > 32 || p.N <= 0 || p.K <= 0) return MMS_ERR_ARG;
+    if (p.pro.bn && p.pro.train && p.M < 2) return MMS_ERR_ARG;   // torch: "Expected more than 1 value per channel"
+    if (p.M <= 4) return launch_linear_fwd<4>(p, s);
+    if (p.M <= 8) return launch_linear_fwd<8>(p, s);
+    if (p.M <= 16) return launch_linear_fwd<16>(p, s);
+    return launch_linear_fwd<32>(p, s);
+}
+
+// ---- backward: weight/bias (one wave per output feature n) ---------------------------------------------------
+template <int MM>
+__global__ __launch_bounds__(256) void linear_bwd_w_kernel(const LinearBwdP p) {
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= p.N) return;
+    float dz[MM], db = 0.f;
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+        float g = 0.f;
+        if (m < p.M) {
+            g = p.dy[(size_t)m * p.lddy + n];
+            if (p.out_relu && !(p.y[(size_t)m * p.ldy + n] > 0.f)) g = 0.f;
+        }
+        dz[m] = g; db += g;
+    }
+    if (lane == 0 && p.dbias) p.dbias[n] += db;
+    for (int k = lane; k < p.K; k += 64) {
+        float x[MM];
+#pragma unroll
+        for (int m = 0; m < MM; ++m) x[m] = m < p.M ? p.x[(size_t)m * p.ldx + k] : 0.f;
+        ColProlog<MM> cp;
+        cp.template apply<false>(p.pro, x, p.M, k, p.K);
+        float a = 0.f;
+#pragma unroll
+        for (int m = 0; m < MM; ++m) a = fmaf(dz[m], x[m], a);
+        p.dw[(size_t)n * p.K + k] += a;
+    }
+}
+
+// ---- backward: input (one thread per input column k), prologue backward lane-local --------------------------
+template <int MM>
+__global__ __launch_bounds__(256) void linear_bwd_x_kernel(const LinearBwdP p) {
+    __shared__ float dzs[MM][128];
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    float acc[MM];
+#pragma unroll
+    for (int m = 0; m < MM; ++m) acc[m] = 0.f;
+    for (int nb = 0; nb < p.N; nb += 128) {
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < MM * 128; idx += 256) {
+            const int m = idx >> 7, n = nb + (idx & 127);
+            float g = 0.f;
+            if (m < p.M && n < p.N) {
+                g = p.dy[(size_t)m * p.lddy + n];
+                if (p.out_relu && !(p.y[(size_t)m * p.ldy + n] > 0.f)) g = 0.f;
+            }
+            dzs[m][idx & 127] = g;
+        }
+        __syncthreads();
+        if (k < p.K) {
+            const int ne = p.N - nb < 128 ? p.N - nb : 128;
+            for (int n = 0; n < ne; ++n) {
+                const float w = p.w[(size_t)(nb + n) * p.K + k];
+#pragma unroll
+                for (int m = 0; m < MM; ++m) acc[m] = fmaf(dzs[m][n], w, acc[m]);
+            }
+        }
+    }
+    if (k >= p.K) return;
+    float x[MM];
+#pragma unroll
+    for (int m = 0; m < MM; ++m) x[m] = m < p.M ? p.x[(size_t)m * p.ldx + k] : 0.f;
+    ColProlog<MM> cp;
+    cp.template apply<false>(p.pro, x, p.M, k, p.K);
+    float dxv[MM];
+    if (p.pro.bn) {
+        float s1 = 0.f, s2 = 0.f, dpre[MM];
+#pragma unroll
+        for (int m = 0; m < MM; ++m) {
+            dpre[m] = (m < p.M && cp.pre[m] > 0.f) ? acc[m] * cp.scale[m] : 0.f;
+            s1 += dpre[m]; s2 = fmaf(dpre[m], cp.xhat[m], s2);
+        }
+        if (p.dgamma) { p.dgamma[k] += s2; p.dbeta[k] += s1; }
+        const float gr = cp.gamma * cp.rstd, m1 = s1 / (float)p.M, m2 = s2 / (float)p.M;
+#pragma unroll
+        for (int m = 0; m < MM; ++m)
+            dxv[m] = p.pro.train ? gr * (dpre[m] - m1 - cp.xhat[m] * m2) : gr * dpre[m];
+    } else {
+#pragma unroll
+        for (int m = 0; m < MM; ++m) dxv[m] = acc[m] * cp.scale[m];
+    }
+#pragma unroll
+    for (int m = 0; m < MM; ++m) if (m < p.M) p.dx[(size_t)m * p.lddx + k] = dxv[m];
+}
+
+template <int MM>
+static int launch_linear_bwd(const LinearBwdP& p, hipStream_t s) {
+    if (p.dw) hipLaunchKernelGGL(linear_bwd_w_kernel<MM>, dim3((p.N + 3) / 4), dim3(256), 0, s, p);
+    if (p.dx) hipLaunchKernelGGL(linear_bwd_x_kernel<MM>, dim3((p.K + 255) / 256), dim3(256), 0, s, p);
+    return mms_check_launch();
+}
+extern "C" int mms_linear_bwd(const LinearBwdP* pp, hipStream_t s) {
+    const LinearBwdP& p = *pp;
+    if (p.M <= 0 || p.M > 32 || p.N <= 0 || p.K <= 0) return MMS_ERR_ARG;
+    if (p.M <= 4) return launch_linear_bwd<4>(p, s);
+    if (p.M <= 8) return launch_linear_bwd<8>(p, s);
+    if (p.M <= 16) return launch_linear_bwd<16>(p, s);
+    return launch_linear_bwd<32>(p, s);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// gated fusion: one workgroup per patient row
+// ------------------------------------------------------------------------------------------------------
+#define GATE_F 288
+#define GATE_IN 291
+__device__ __forceinline__ int gate_seg(int t) { return t < 128 ? 0 : (t < 256 ? 1 : 2); }
+
+__global__ __launch_bounds__(256) void gate_fwd_kernel(const GateP p) {
+    __shared__ float G[GATE_IN + 1], h[64], g[3];
+    const int m = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int i = t; i < GATE_IN; i += 256)
+        G[i] = i < GATE_F ? p.feats[(size_t)m * GATE_F + i] * p.mask[m * 3 + gate_seg(i)] : p.mask[m * 3 + (i - GATE_F)];
+    __syncthreads();
+    for (int j = wave * 16; j < wave * 16 + 16; ++j) {
+        float a = 0.f;
+        for (int k = lane; k < GATE_IN; k += 64) a = fmaf(p.w1[j * GATE_IN + k], G[k], a);
+        a = wave_sum(a);
+        if (lane == 0) { h[j] = fmaxf(a + p.b1[j], 0.f); p.hidden[m * 64 + j] = h[j]; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float l[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) l[c] = wave_sum(p.w2[c * 64 + lane] * h[lane]) + p.b2[c];
+        if (lane == 0) {
+            const float mx = fmaxf(l[0], fmaxf(l[1], l[2]));
+            const float e0 = expf(l[0] - mx), e1 = expf(l[1] - mx), e2 = expf(l[2] - mx), inv = 1.f / (e0 + e1 + e2);
+            g[0] = e0 * inv; g[1] = e1 * inv; g[2] = e2 * inv;
+            float ent = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { p.gate[m * 3 + c] = g[c]; ent += g[c] * logf(g[c] + 1e-8f); }
+            if (p.entropy) atomicAdd(p.entropy, ent / (float)p.M);     // gate_entropy_loss = -mean(entropy)
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < GATE_F; i += 256) p.fused[(size_t)m * GATE_F + i] = G[i] * g[gate_seg(i)];
+}
+
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const GateP p) {
+    __shared__ float G[GATE_IN + 1], h[64], g[3], dgs[3], dl[3], dhp[64], red[4][3];
+    const int m = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int i = t; i < GATE_IN; i += 256)
+        G[i] = i < GATE_F ? p.feats[(size_t)m * GATE_F + i] * p.mask[m * 3 + gate_seg(i)] : p.mask[m * 3 + (i - GATE_F)];
+    if (t < 64) h[t] = p.hidden[m * 64 + t];
+    if (t < 3) g[t] = p.gate[m * 3 + t];
+    __syncthreads();
+    // dgate[c] = sum over segment c of dfused * masked
+    float part[3] = {0.f, 0.f, 0.f};
+    for (int i = t; i < GATE_F; i += 256) part[gate_seg(i)] += p.dfused[(size_t)m * GATE_F + i] * G[i];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { float v = wave_sum(part[c]); if (lane == 0) red[wave][c] = v; }
+    __syncthreads();
+    if (t == 0) {
+        float dg[3], dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            dg[c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+            if (p.ent_weight != 0.f) dg[c] += p.ent_weight / (float)p.M * (logf(g[c] + 1e-8f) + g[c] / (g[c] + 1e-8f));
+            dot += g[c] * dg[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { dl[c] = g[c] * (dg[c] - dot); atomicAdd(&p.db2[c], dl[c]); }
+    }
+    __syncthreads();
+    if (t < 64) {
+        float dh = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { dh = fmaf(dl[c], p.w2[c * 64 + t], dh); atomicAdd(&p.dw2[c * 64 + t], dl[c] * h[t]); }
+        dhp[t] = h[t] > 0.f ? dh : 0.f;
+        atomicAdd(&p.db1[t], dhp[t]);
+    }
+    __syncthreads();
+    for (int idx = t; idx < 64 * GATE_IN; idx += 256) {
+        const int j = idx / GATE_IN, k = idx % GATE_IN;
+        atomicAdd(&p.dw1[idx], dhp[j] * G[k]);
+    }
+    for (int i = t; i < GATE_F; i += 256) {
+        float dG = 0.f;
+        for (int j = 0; j < 64; ++j) dG = fmaf(dhp[j], p.w1[j * GATE_IN + i], dG);
+        const int sg = gate_seg(i);
+        p.dfeats[(size_t)m * GATE_F + i] = (p.dfused[(size_t)m * GATE_F + i] * g[sg] + dG) * p.mask[m * 3 + sg];
+    }
+}
+extern "C" int mms_gate_fwd(const GateP* pp, hipStream_t s) {
+    if (pp->M <= 0) return MMS_ERR_ARG;
+    hipLaunchKernelGGL(gate_fwd_kernel, dim3(pp->M), dim3(256), 0, s, *pp);
+    return mms_check_launch();
+}
+extern "C" int mms_gate_bwd(const GateP* pp, hipStream_t s) {
+    if (pp->M <= 0) return MMS_ERR_ARG;
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(pp->M), dim3(256), 0, s, *pp);
+    return mms_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Cox partial likelihood, O(n^2) risk-set form.  One wave per row i, lanes over j (wavefront-shuffle reductions).
+//   pass 1: lse_i = log sum_{j valid, t_j >= t_i} exp(h_j)          pass 2: loss, dh
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool cox_valid(const CoxP& p, int i) { return p.valid == nullptr || p.valid[i] != 0.f; }
+
+__global__ __launch_bounds__(256) void cox_lse_kernel(const CoxP p) {
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= p.n) return;
+    if (!cox_valid(p, i)) { if (lane == 0) p.lse[i] = 0.f; return; }
+    const float ti = p.time[i];
+    float mx = -INFINITY;
+    for (int j = lane; j < p.n; j += 64)
+        if (cox_valid(p, j) && p.time[j] >= ti) mx = fmaxf(mx, p.h[(size_t)j * p.ldh]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int j = lane; j < p.n; j += 64)
+        if (cox_valid(p, j) && p.time[j] >= ti) s += expf(p.h[(size_t)j * p.ldh] - mx);
+    s = wave_sum(s);
+    if (lane == 0) p.lse[i] = mx + logf(s);
+}
+
+__global__ __launch_bounds__(256) void cox_grad_kernel(const CoxP p) {
+    __shared__ float red[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k = blockIdx.x * 4 + wave;
+    // batch counts (every block recomputes them: n is small)
+    float nv = 0.f, ne = 0.f, ls = 0.f;
+    for (int j = threadIdx.x; j < p.n; j += 256)
+        if (cox_valid(p, j)) {
+            nv += 1.f;
+            if (p.event[j] != 0.f) { ne += 1.f; ls += p.h[(size_t)j * p.ldh] - p.lse[j]; }
+        }
+    nv = wave_sum(nv); ne = wave_sum(ne); ls = wave_sum(ls);
+    if (lane == 0) { red[wave] = nv; red[4 + wave] = ne; }
+    __syncthreads();
+    nv = red[0] + red[1] + red[2] + red[3]; ne = red[4] + red[5] + red[6] + red[7];
+    __syncthreads();
+    if (lane == 0) red[wave] = ls;
+    __syncthreads();
+    ls = red[0] + red[1] + red[2] + red[3];
+    const bool usable = nv >= 2.f && ne > 0.f;      // final_multimodal.py:173-176
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        p.out[0] = usable ? -ls / (ne + 1e-8f) : 0.f;
+        p.out[1] = usable ? 1.f : 0.f;
+    }
+    if (k >= p.n || p.dh == nullptr) return;
+    float gsum = 0.f;
+    if (usable && cox_valid(p, k)) {
+        const float tk = p.time[k], hk = p.h[(size_t)k * p.ldh];
+        for (int i = lane; i < p.n; i += 64)
+            if (cox_valid(p, i) && p.event[i] != 0.f && p.time[i] <= tk) gsum += expf(hk - p.lse[i]);
+        gsum = wave_sum(gsum);
+        if (lane == 0) p.dh[(size_t)k * p.lddh] = -p.scale * ((p.event[k] != 0.f ? 1.f : 0.f) - gsum) / (ne + 1e-8f);
+    } else if (lane == 0) {
+        p.dh[(size_t)k * p.lddh] = 0.f;
+    }
+}
+extern "C" int mms_cox_fwd_bwd(const CoxP* pp, hipStream_t s) {
+    const CoxP& p = *pp;
+    if (p.n <= 0 || !p.lse || !p.out) return MMS_ERR_ARG;
+    hipLaunchKernelGGL(cox_lse_kernel, dim3((p.n + 3) / 4), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(cox_grad_kernel, dim3((p.n + 3) / 4), dim3(256), 0, s, p);
+    return mms_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Harrell's C pair counts: one wave per event row i
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cindex_kernel(const CindexP p) {
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= p.n || p.event[i] != 1.f) return;
+    const float ti = p.time[i], hi = p.h[i];
+    unsigned conc = 0, tied = 0, perm = 0;
+    for (int j = lane; j < p.n; j += 64)
+        if (p.time[j] > ti) {
+            ++perm;
+            const float hj = p.h[j];
+            conc += hi > hj; tied += hi == hj;
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { conc += __shfl_xor(conc, o, 64); tied += __shfl_xor(tied, o, 64); perm += __shfl_xor(perm, o, 64); }
+    if (lane == 0) {
+        atomicAdd(&p.counts[0], (unsigned long long)conc);
+        atomicAdd(&p.counts[1], (unsigned long long)tied);
+        atomicAdd(&p.counts[2], (unsigned long long)perm);
+    }
+}
+extern "C" int mms_cindex_counts(const CindexP* pp, hipStream_t s) {
+    if (pp->n <= 0) return MMS_ERR_ARG;
+    hipLaunchKernelGGL(cindex_kernel, dim3((pp->n + 3) / 4), dim3(256), 0, s, *pp);
+    return mms_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------------
+// clip_grad_norm_ + Adam / AdamW over a flat buffer
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grad_sumsq_kernel(const AdamP p) {
+    __shared__ double red[4];
+    const long long n4 = p.n >> 2, stride = (long long)gridDim.x * 256;
+    float a = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const float4 g = ((const float4*)p.g)[i];
+        a = fmaf(g.x, g.x, a); a = fmaf(g.y, g.y, a); a = fmaf(g.z, g.z, a); a = fmaf(g.w, g.w, a);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (p.n & 3)) { const float g = p.g[(n4 << 2) + threadIdx.x]; a = fmaf(g, g, a); }
+    const double t = block_sum_d((double)a, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(p.sumsq, t);
+        if (blockIdx.x == 0 && (p.skip_flag == nullptr || *p.skip_flag != 0.f)) p.step[0] += 1.f;
+    }
+}
+__global__ __launch_bounds__(256) void clip_adam_kernel(const AdamP p) {
+    __shared__ float c[6];
+    if (p.skip_flag != nullptr && *p.skip_flag == 0.f) return;
+    if (threadIdx.x == 0) {
+        const double lr = p.hyper[0], b1 = p.hyper[1], b2 = p.hyper[2], wd = p.hyper[4], maxn = p.hyper[5];
+        const double t = p.step[0];
+        const double norm = sqrt(*p.sumsq);
+        double coef = maxn / (norm + 1e-6);
+        if (coef > 1.0) coef = 1.0;
+        if (maxn <= 0.0) coef = 1.0;
+        const double bc1 = 1.0 - pow(b1, t), bc2 = 1.0 - pow(b2, t);
+        c[0] = (float)coef; c[1] = (float)(lr / bc1); c[2] = (float)(1.0 / sqrt(bc2));
+        c[3] = (float)(1.0 - lr * wd); c[4] = (float)wd;
+    }
+    __syncthreads();
+    const float coef = c[0], step_size = c[1], inv_sqrt_bc2 = c[2], decay = c[3], wd = c[4];
+    const float b1 = p.hyper[1], b2 = p.hyper[2], eps = p.hyper[3];
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.n; i += stride) {
+        float w = p.p[i], g = p.g[i] * coef;
+        if (p.adamw) w *= decay; else g = fmaf(wd, w, g);
+        const float m = fmaf(b1, p.m[i], (1.f - b1) * g);
+        const float v = fmaf(b2, p.v[i], (1.f - b2) * g * g);
+        p.m[i] = m; p.v[i] = v;
+        p.p[i] = w - step_size * m / (sqrtf(v) * inv_sqrt_bc2 + eps);
+    }
+}
+extern "C" int mms_grad_sumsq(const AdamP* pp, hipStream_t s) {
+    if (pp->n <= 0) return MMS_ERR_ARG;
+    long long blocks = (pp->n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(grad_sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, *pp);
+    return mms_check_launch();
+}
+extern "C" int mms_clip_adam(const AdamP* pp, hipStream_t s) {
+    if (pp->n <= 0) return MMS_ERR_ARG;
+    long long blocks = (pp->n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, *pp);
+    return mms_check_launch();
+}

@@ -128,7 +128,7 @@ class DenseNet121(nn.Module):
         out = torch.empty(B, 128, device=x.device, dtype=torch.float32)
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         _lib.check(e["lib"].mms_dn121_forward(e["ws"].data_ptr(), B, D, H, W, x.data_ptr(), e["ptab"], e["btab"],
-                                              out.data_ptr(), 1 if self.training else 0, st), "mms_dn121_forward")
+                                              out.data_ptr(), out.stride(0), 1 if self.training else 0, st), "mms_dn121_forward")
         return out
 
     def _grad_table(self):
@@ -162,7 +162,7 @@ class DenseNet121(nn.Module):
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         dout = dout.contiguous().float()
         _lib.check(e["lib"].mms_dn121_backward(e["ws"].data_ptr(), B, D, H, W, x.data_ptr(), e["ptab"],
-                                               dout.data_ptr(), gtab, st), "mms_dn121_backward")
+                                               dout.data_ptr(), dout.stride(0), gtab, st), "mms_dn121_backward")
 
     def workspace_region(self, name, index=0, dtype=torch.float32):
         """Diagnostic view of a named workspace region (tests)."""

@@ -67,7 +67,7 @@ def pool_fwd(y0, in_dims, out_dims, B, slab, argmax, bn, osum=None, osumsq=None)
 
 
 def head_fwd(slab, C, B, V, bn, w, bias, pooled, out):
-    p = _S()["HeadFwdP"](ptr(slab), slab.stride(0), C, B, V, bn, ptr(w), ptr(bias), w.shape[0], ptr(pooled), ptr(out))
+    p = _S()["HeadFwdP"](ptr(slab), slab.stride(0), C, B, V, bn, ptr(w), ptr(bias), w.shape[0], ptr(pooled), ptr(out), out.stride(0))
     call("mms_head_fwd", p)
 
 
@@ -123,7 +123,7 @@ def bn_bwd_apply(dbn, x, dx, M, C, bn, bb, accumulate, dgamma, dbeta):
 
 
 def head_bwd(dout, pooled, slab, C, B, V, bn, w, dw, dbias, dgamma, dbeta, dslab):
-    p = _S()["HeadBwdP"](ptr(dout), ptr(pooled), ptr(slab), slab.stride(0), C, B, V, bn, ptr(w), w.shape[0],
+    p = _S()["HeadBwdP"](ptr(dout), dout.stride(0), ptr(pooled), ptr(slab), slab.stride(0), C, B, V, bn, ptr(w), w.shape[0],
                          ptr(dw), ptr(dbias), ptr(dgamma), ptr(dbeta), ptr(dslab), dslab.stride(0))
     call("mms_head_bwd", p)
 
@@ -138,3 +138,56 @@ def conv0_bwd_weight(dbn, y0, bn, bb, x, in_dims, out_dims, coords, dw, msplit, 
     p = _S()["Conv0BwdWP"](ptr(dbn), ptr(y0), bn, bb, ptr(x), dims3(in_dims), dims3(out_dims), ptr(coords),
                            y0.shape[0], ptr(dw), msplit, ptr(dgamma), ptr(dbeta))
     call("mms_conv0_bwd_weight", p)
+
+
+# ---- heads ------------------------------------------------------------------------------------------------
+def inprolog(bn=None, train=False, drop_p=0.0, drop_mask=None, rng=None, stream_id=0):
+    """bn: None or a torch.nn.BatchNorm1d-like holder with weight/bias/running_mean/running_var/num_batches_tracked."""
+    S = _S()["InProlog"]
+    if bn is None:
+        return S(0, None, None, None, None, None, 1e-5, 0.1, 1 if train else 0, float(drop_p), ptr(drop_mask), ptr(rng), stream_id)
+    return S(1, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked),
+             float(bn.eps), float(bn.momentum), 1 if train else 0, float(drop_p), ptr(drop_mask), ptr(rng), stream_id)
+
+
+def linear_fwd(x, K, pro, w, bias, y, out_relu):
+    p = _S()["LinearFwdP"](ptr(x), x.stride(0), x.shape[0], K, pro, ptr(w), ptr(bias), w.shape[0], ptr(y), y.stride(0),
+                           1 if out_relu else 0)
+    call("mms_linear_fwd", p)
+
+
+def linear_bwd(dy, y, out_relu, x, K, pro, w, dw, dbias, dx=None, dgamma=None, dbeta=None):
+    p = _S()["LinearBwdP"](ptr(dy), dy.stride(0), ptr(y), y.stride(0), 1 if out_relu else 0, ptr(x), x.stride(0),
+                           x.shape[0], K, pro, ptr(w), w.shape[0], ptr(dw), ptr(dbias), ptr(dx),
+                           dx.stride(0) if dx is not None else 0, ptr(dgamma), ptr(dbeta))
+    call("mms_linear_bwd", p)
+
+
+def gate_params(feats, mask, w1, b1, w2, b2, hidden, gate, fused, dfused=None, ent_weight=0.0, dfeats=None,
+                dw1=None, db1=None, dw2=None, db2=None, entropy=None):
+    return _S()["GateP"](ptr(feats), ptr(mask), feats.shape[0], ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(hidden), ptr(gate),
+                         ptr(fused), ptr(dfused), float(ent_weight), ptr(dfeats), ptr(dw1), ptr(db1), ptr(dw2), ptr(db2),
+                         ptr(entropy))
+
+
+def cox_fwd_bwd(h, time, event, valid=None, scale=1.0, want_grad=True):
+    """h: [n] or [n,1] fp32 on device -> (out[2] = {loss, usable}, dh or None)."""
+    n = h.shape[0]
+    lse = torch.empty(n, device=h.device)
+    out = torch.empty(2, device=h.device)
+    dh = torch.empty(n, device=h.device) if want_grad else None
+    p = _S()["CoxP"](ptr(h), h.stride(0), ptr(time), ptr(event), ptr(valid), n, float(scale), ptr(lse), ptr(dh), 1, ptr(out))
+    call("mms_cox_fwd_bwd", p)
+    return out, dh
+
+
+def cindex_counts(h, time, event):
+    counts = torch.zeros(3, dtype=torch.int64, device=h.device)
+    p = _S()["CindexP"](ptr(h), ptr(time), ptr(event), h.shape[0], ptr(counts))
+    call("mms_cindex_counts", p)
+    return counts
+
+
+def adam_params(p_, g, m, v, hyper, sumsq, step, skip_flag=None, adamw=False):
+    return _S()["AdamP"](ptr(p_), ptr(g), ptr(m), ptr(v), p_.numel(), ptr(hyper), ptr(sumsq), ptr(step), ptr(skip_flag),
+                         1 if adamw else 0)
