@@ -235,6 +235,7 @@ typedef struct GateP {
     // backward
     const float* dfused;            // [M][288]
     float ent_weight;               // lambda * upstream of gate_entropy_loss (R/...:322-331); 0 = none
+    const float* dgate_ext;         // optional [M][3]: external gradient w.r.t. the gate weights (autograd path)
     float* dfeats;                  // [M][288]
     float* dw1; float* db1; float* dw2; float* db2;   // accumulated (atomics)
     float* entropy;                 // optional scalar out (fwd): -mean_b(entropy_b)
@@ -302,6 +303,7 @@ int mms_linear_fwd(const LinearFwdP* p, hipStream_t s);        /* nn.Linear (+ p
 int mms_linear_bwd(const LinearBwdP* p, hipStream_t s);
 int mms_gate_fwd(const GateP* p, hipStream_t s);
 int mms_gate_bwd(const GateP* p, hipStream_t s);
+int mms_gate_entropy(const float* gate, int M, float scale, float* loss, float* dgate, hipStream_t s);  /* gate_entropy_loss value (+= into *loss) and gradient */
 int mms_cox_fwd_bwd(const CoxP* p, hipStream_t s);
 int mms_cindex_counts(const CindexP* p, hipStream_t s);
 int mms_grad_sumsq(const AdamP* p, hipStream_t s);             /* sum of squares of the flat gradient (fp64 atomics) */

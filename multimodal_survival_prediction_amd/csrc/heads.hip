@@ -263,6 +263,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const GateP p) {
         for (int c = 0; c < 3; ++c) {
             dg[c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
             if (p.ent_weight != 0.f) dg[c] += p.ent_weight / (float)p.M * (logf(g[c] + 1e-8f) + g[c] / (g[c] + 1e-8f));
+            if (p.dgate_ext) dg[c] += p.dgate_ext[m * 3 + c];
             dot += g[c] * dg[c];
         }
 #pragma unroll
@@ -288,6 +289,27 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const GateP p) {
         p.dfeats[(size_t)m * GATE_F + i] = (p.dfused[(size_t)m * GATE_F + i] * g[sg] + dG) * p.mask[m * 3 + sg];
     }
 }
+// gate_entropy_loss(gate) = mean_b sum_k g log(g + 1e-8)  (partial_modality_training.py:322-331), value and gradient
+__global__ void gate_entropy_kernel(const float* gate, int M, float scale, float* loss, float* dgate) {
+    const int m = blockIdx.x * 64 + threadIdx.x;
+    float e = 0.f;
+    if (m < M) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float g = gate[m * 3 + c];
+            e += g * logf(g + 1e-8f);
+            if (dgate) dgate[m * 3 + c] = scale / (float)M * (logf(g + 1e-8f) + g / (g + 1e-8f));
+        }
+    }
+    e = wave_sum(e);
+    if (threadIdx.x == 0 && loss) atomicAdd(loss, e / (float)M);
+}
+extern "C" int mms_gate_entropy(const float* gate, int M, float scale, float* loss, float* dgate, hipStream_t s) {
+    if (M <= 0) return MMS_ERR_ARG;
+    hipLaunchKernelGGL(gate_entropy_kernel, dim3((M + 63) / 64), dim3(64), 0, s, gate, M, scale, loss, dgate);
+    return mms_check_launch();
+}
+
 extern "C" int mms_gate_fwd(const GateP* pp, hipStream_t s) {
     if (pp->M <= 0) return MMS_ERR_ARG;
     hipLaunchKernelGGL(gate_fwd_kernel, dim3(pp->M), dim3(256), 0, s, *pp);

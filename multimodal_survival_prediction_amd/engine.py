@@ -1,0 +1,362 @@
+"""Host-side execution engine for the three survival networks.
+
+One `SurvivalEngine` per model instance.  It
+  * re-points every parameter (and creates every gradient) as a view into ONE flat fp32 buffer, so the
+    gradient zeroing, the global-norm reduction and the Adam update are single launches over 14-17 M floats;
+  * keeps, per batch size, a *plan*: static input buffers, the DenseNet workspace, the head activation buffers
+    and the prebuilt C-ABI parameter blocks (ctypes structs holding raw device pointers) for every launch;
+  * runs a plan either eagerly (autograd-compatible path used by the nn.Module's forward/backward) or as a
+    captured HIP graph of the WHOLE training step (zero-grad -> forward -> Cox -> backward -> clip -> Adam),
+    which is what `training.train_epoch_*` and bench.py replay once per batch.
+
+PyTorch supplies device memory, streams and graph capture only; every numeric op is a kernel behind
+include/mmsurv.h.  Nothing here falls back to torch math.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+
+_S = _lib.structs
+
+
+class _Lin:
+    """One nn.Linear application with the neighbouring BN1d/ReLU/Dropout folded in (see InProlog in mmsurv.h)."""
+
+    def __init__(self, lin, src, dst, out_relu, pro_bn=None, pro_drop=None, need_dx=True):
+        self.lin, self.src, self.dst, self.out_relu = lin, src, dst, out_relu
+        self.pro_bn, self.pro_drop, self.need_dx = pro_bn, pro_drop, need_dx
+
+
+def head_program(model):
+    """-> dict(kind, width, ct_cols, lins=[...], gate=(l1, l2) | None, bufs={name: width}, encoder).
+    Buffer/column wiring restates the reference forward()s: final_multimodal.py:122-150,
+    partial_modality_training.py:234-277, simple_fusion.py:217-236."""
+    kind = type(model).__name__
+    if kind in ("MultiModalSurvivalNet", "PartialModalityNet"):
+        r, c, f = model.rna_encoder, model.clinical_encoder, model.fusion
+        rna_dim = r[0].in_features
+        lins = [
+            _Lin(r[0], ("rna", 0), ("r1", 0), False, need_dx=False),
+            _Lin(r[4], ("r1", 0), ("feats", 128), True, pro_bn=r[1], pro_drop=r[3]),
+            _Lin(c[0], ("clin", 0), ("feats", 256), True, need_dx=False),
+            _Lin(f[0], ("fused" if kind == "PartialModalityNet" else "feats", 0), ("f1", 0), False),
+            _Lin(f[4], ("f1", 0), ("f2", 0), True, pro_bn=f[1], pro_drop=f[3]),
+            _Lin(model.cox_head, ("f2", 0), ("hz", 0), False),
+        ]
+        bufs = dict(rna=rna_dim, clin=c[0].in_features, r1=512, feats=288, f1=256, f2=128, hz=1)
+        gate = None
+        if kind == "PartialModalityNet":
+            bufs["fused"] = 288
+            gate = (model.gate[0], model.gate[2])
+        return dict(kind=kind, width=288, ct_cols=0, lins=lins, gate=gate, bufs=bufs, encoder=model.ct_encoder,
+                    n_pre=3)
+    if kind == "SimpleFusionModel":
+        r, f = model.rna_encoder, model.fusion
+        lins = [
+            _Lin(r[0], ("rna", 0), ("r1", 0), False, need_dx=False),
+            _Lin(r[4], ("r1", 0), ("r2", 0), False, pro_bn=r[1], pro_drop=r[3]),
+            _Lin(r[8], ("r2", 0), ("feats", 0), True, pro_bn=r[5], pro_drop=r[7]),
+            _Lin(f[0], ("feats", 0), ("f1", 0), False),
+            _Lin(f[4], ("f1", 0), ("f2", 0), True, pro_bn=f[1], pro_drop=f[3]),
+            _Lin(f[7], ("f2", 0), ("hz", 0), False, pro_drop=f[6]),
+        ]
+        bufs = dict(rna=r[0].in_features, r1=1024, r2=512, feats=384, f1=256, f2=128, hz=1)
+        return dict(kind=kind, width=384, ct_cols=256, lins=lins, gate=None, bufs=bufs, encoder=model.image_encoder,
+                    n_pre=3)
+    raise TypeError("unsupported model %s" % kind)
+
+
+class _Plan:
+    """Everything that depends on the batch size B (and the volume dims)."""
+    pass
+
+
+class SurvivalEngine:
+    def __init__(self, model, adamw=None, lr=1e-4, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0,
+                 gate_entropy_weight=0.01):
+        self.lib = _lib.load_library()
+        self.model = model
+        self.prog = head_program(model)
+        p0 = next(model.parameters())
+        if not p0.is_cuda:
+            raise RuntimeError("SurvivalEngine: move the model to the GPU first (model.to('cuda')); no CPU fallback")
+        self.device = p0.device
+        self.params = list(model.parameters())
+        self._flatten()
+        n = self.flat.numel()
+        self.m = torch.zeros(n, device=self.device)
+        self.v = torch.zeros(n, device=self.device)
+        self.adamw = bool(adamw) if adamw is not None else self.prog["kind"] == "SimpleFusionModel"
+        self.hyper = torch.tensor([lr, betas[0], betas[1], eps, weight_decay, max_norm], device=self.device)
+        self.sumsq = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self.step_count = torch.zeros(1, device=self.device)
+        self.rng = torch.tensor([0x5EED, 0], dtype=torch.int32, device=self.device)
+        self.ent_weight = gate_entropy_weight
+        self.plans = {}
+        self.dropout_masks = {}      # parity mode: {lin index: [B, K] multiplicative mask}
+        # device-side epoch accumulators: [sum loss*usable, n usable, sum entropy, n batches]
+        self.acc = torch.zeros(4, device=self.device)
+        model._mms_engine = self
+
+    # ---- parameters ------------------------------------------------------------------------------
+    def _flatten(self):
+        n = sum(p.numel() for p in self.params)
+        pad = (-n) % 4
+        self.flat = torch.zeros(n + pad, device=self.device)
+        self.gflat = torch.zeros(n + pad, device=self.device)
+        o = 0
+        self.gviews = []
+        with torch.no_grad():
+            for p in self.params:
+                v = self.flat[o:o + p.numel()].view_as(p)
+                v.copy_(p.data)
+                p.data = v
+                g = self.gflat[o:o + p.numel()].view_as(p)
+                self.gviews.append(g)
+                o += p.numel()
+        self._key = (self.params[0].data_ptr(), self.params[-1].data_ptr())
+
+    def _check_params(self):
+        if (self.params[0].data_ptr(), self.params[-1].data_ptr()) != self._key:
+            raise RuntimeError("model parameters were re-allocated (e.g. .to()/.load on another device) after the "
+                               "engine was built; create a new SurvivalEngine")
+
+    def set_lr(self, lr):
+        self.hyper[0] = lr
+
+    def get_lr(self):
+        return float(self.hyper[0])
+
+    def attach_grads(self):
+        """Expose the flat gradient buffer as .grad views (what clip_grad_norm_/torch.optim would read)."""
+        for p, g in zip(self.params, self.gviews):
+            p.grad = g
+
+    # ---- plans -----------------------------------------------------------------------------------
+    def plan(self, B, dims):
+        key = (B,) + tuple(dims)
+        if key in self.plans:
+            return self.plans[key]
+        self._check_params()
+        P = _Plan()
+        P.B, P.dims = B, tuple(dims)
+        dev = self.device
+        prog = self.prog
+        D, H, W = dims
+        P.ct = torch.zeros(B, 1, D, H, W, device=dev)
+        P.buf = {k: torch.zeros(B, w, device=dev) for k, w in prog["bufs"].items()}
+        P.dbuf = {k: torch.zeros(B, w, device=dev) for k, w in prog["bufs"].items() if k not in ("rna", "clin")}
+        P.mask = torch.ones(B, 3, device=dev)
+        P.time = torch.zeros(B, device=dev)
+        P.event = torch.zeros(B, device=dev)
+        P.valid = torch.ones(B, device=dev)
+        P.cox_out = torch.zeros(2, device=dev)
+        P.lse = torch.zeros(B, device=dev)
+        P.entropy = torch.zeros(1, device=dev)
+        # encoder
+        enc = prog["encoder"]
+        nbytes = ctypes.c_size_t(0)
+        _lib.check(self.lib.mms_dn121_workspace_bytes(B, D, H, W, ctypes.byref(nbytes)), "mms_dn121_workspace_bytes")
+        P.ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        eparams = list(enc.parameters())
+        ebufs = list(enc.buffers())
+        P.ptab = (ctypes.c_void_p * 364)(*[p.data_ptr() for p in eparams])
+        P.btab = (ctypes.c_void_p * 363)(*[b.data_ptr() for b in ebufs])
+        gmap = {id(p): g for p, g in zip(self.params, self.gviews)}
+        P.gtab = (ctypes.c_void_p * 364)(*[gmap[id(p)].data_ptr() for p in eparams])
+        _lib.check(self.lib.mms_dn121_init(P.ws.data_ptr(), B, D, H, W, P.ptab, P.btab, ops.stream()), "mms_dn121_init")
+        # head launches (train / eval variants)
+        P.lin_fwd = {True: [], False: []}
+        P.lin_bwd = []
+        for i, L in enumerate(prog["lins"]):
+            xs, xo = L.src
+            ys, yo = L.dst
+            x = P.buf[xs][:, xo:]
+            y = P.buf[ys][:, yo:]
+            K, N = L.lin.in_features, L.lin.out_features
+            for train in (True, False):
+                pro = self._prolog(L, i, train)
+                P.lin_fwd[train].append(_S()["LinearFwdP"](x.data_ptr(), x.stride(0), B, K, pro, L.lin.weight.data_ptr(),
+                                                            L.lin.bias.data_ptr(), N, y.data_ptr(), y.stride(0),
+                                                            1 if L.out_relu else 0))
+            dy = P.dbuf[ys][:, yo:]
+            dx = P.dbuf[xs][:, xo:] if L.need_dx else None
+            pro = self._prolog(L, i, True)
+            P.lin_bwd.append(_S()["LinearBwdP"](
+                dy.data_ptr(), dy.stride(0), y.data_ptr(), y.stride(0), 1 if L.out_relu else 0,
+                x.data_ptr(), x.stride(0), B, K, pro, L.lin.weight.data_ptr(), N,
+                gmap[id(L.lin.weight)].data_ptr(), gmap[id(L.lin.bias)].data_ptr(),
+                dx.data_ptr() if dx is not None else None, dx.stride(0) if dx is not None else 0,
+                gmap[id(L.pro_bn.weight)].data_ptr() if L.pro_bn is not None else None,
+                gmap[id(L.pro_bn.bias)].data_ptr() if L.pro_bn is not None else None))
+        P.gate = None
+        if prog["gate"] is not None:
+            g1, g2 = prog["gate"]
+            P.hidden = torch.zeros(B, 64, device=dev)
+            P.gatew = torch.zeros(B, 3, device=dev)
+            P.gate = ops.gate_params(P.buf["feats"], P.mask, g1.weight, g1.bias, g2.weight, g2.bias, P.hidden, P.gatew,
+                                     P.buf["fused"], P.dbuf["fused"], self.ent_weight, P.dbuf["feats"],
+                                     gmap[id(g1.weight)], gmap[id(g1.bias)], gmap[id(g2.weight)], gmap[id(g2.bias)],
+                                     P.entropy)
+        hz = P.buf["hz"]
+        P.cox = _S()["CoxP"](hz.data_ptr(), 1, P.time.data_ptr(), P.event.data_ptr(), P.valid.data_ptr(), B, 1.0,
+                             P.lse.data_ptr(), P.dbuf["hz"].data_ptr(), 1, P.cox_out.data_ptr())
+        P.adam = ops.adam_params(self.flat, self.gflat, self.m, self.v, self.hyper, self.sumsq, self.step_count,
+                                 None, self.adamw)
+        P.adam_skip = ops.adam_params(self.flat, self.gflat, self.m, self.v, self.hyper, self.sumsq, self.step_count,
+                                      P.cox_out[1:], self.adamw)
+        P.graphs = {}
+        self.plans[key] = P
+        return P
+
+    def _prolog(self, L, idx, train):
+        p = float(L.pro_drop.p) if (L.pro_drop is not None) else 0.0
+        mask = self.dropout_masks.get(idx)
+        return ops.inprolog(L.pro_bn, train=train, drop_p=p, drop_mask=mask, rng=self.rng, stream_id=idx + 1)
+
+    # ---- launches (all on torch's current stream; capturable) ---------------------------------------
+    def _forward(self, P, train):
+        st = ops.stream()
+        lib, prog = self.lib, self.prog
+        B, (D, H, W) = P.B, P.dims
+        feats = P.buf["feats"]
+        out = feats[:, prog["ct_cols"]:]
+        _lib.check(lib.mms_dn121_forward(P.ws.data_ptr(), B, D, H, W, P.ct.data_ptr(), P.ptab, P.btab, out.data_ptr(),
+                                         feats.stride(0), 1 if train else 0, st), "mms_dn121_forward")
+        lf = P.lin_fwd[train]
+        n_pre = prog["n_pre"]
+        for i in range(n_pre):
+            _lib.check(lib.mms_linear_fwd(ctypes.byref(lf[i]), st), "mms_linear_fwd")
+        if P.gate is not None:
+            P.entropy.zero_()
+            _lib.check(lib.mms_gate_fwd(ctypes.byref(P.gate), st), "mms_gate_fwd")
+        for i in range(n_pre, len(lf)):
+            _lib.check(lib.mms_linear_fwd(ctypes.byref(lf[i]), st), "mms_linear_fwd")
+
+    def _backward_from_dhz(self, P):
+        """dbuf['hz'] holds dL/dhazard; accumulates every parameter gradient into gflat."""
+        st = ops.stream()
+        lib, prog = self.lib, self.prog
+        B, (D, H, W) = P.B, P.dims
+        n_pre = prog["n_pre"]
+        for i in range(len(P.lin_bwd) - 1, n_pre - 1, -1):
+            _lib.check(lib.mms_linear_bwd(ctypes.byref(P.lin_bwd[i]), st), "mms_linear_bwd")
+        if P.gate is not None:
+            _lib.check(lib.mms_gate_bwd(ctypes.byref(P.gate), st), "mms_gate_bwd")
+        for i in range(n_pre - 1, -1, -1):
+            _lib.check(lib.mms_linear_bwd(ctypes.byref(P.lin_bwd[i]), st), "mms_linear_bwd")
+        dfe = P.dbuf["feats"]
+        dct = dfe[:, prog["ct_cols"]:]
+        _lib.check(lib.mms_dn121_backward(P.ws.data_ptr(), B, D, H, W, P.ct.data_ptr(), P.ptab, dct.data_ptr(),
+                                          dfe.stride(0), P.gtab, st), "mms_dn121_backward")
+
+    def _train_body(self, P, skip_if_unusable):
+        """zero-grad -> forward -> Cox -> backward -> clip -> Adam, and the epoch accumulators."""
+        st = ops.stream()
+        lib = self.lib
+        self.gflat.zero_()
+        self.sumsq.zero_()
+        self._forward(P, True)
+        _lib.check(lib.mms_cox_fwd_bwd(ctypes.byref(P.cox), st), "mms_cox_fwd_bwd")
+        self._backward_from_dhz(P)
+        ad = P.adam_skip if skip_if_unusable else P.adam
+        _lib.check(lib.mms_grad_sumsq(ctypes.byref(ad), st), "mms_grad_sumsq")
+        _lib.check(lib.mms_clip_adam(ctypes.byref(ad), st), "mms_clip_adam")
+        self.rng[1] += 1
+        self.acc[0] += P.cox_out[0] * P.cox_out[1]
+        self.acc[1] += P.cox_out[1]
+        self.acc[2] += P.entropy[0]
+        self.acc[3] += 1.0
+
+    # ---- public: fused training step ------------------------------------------------------------------
+    def load_batch(self, P, ct, rna, clinical=None, mask=None, time=None, event=None, valid=None):
+        P.ct.copy_(ct.reshape(P.ct.shape), non_blocking=True)
+        P.buf["rna"].copy_(rna, non_blocking=True)
+        if clinical is not None and "clin" in P.buf:
+            P.buf["clin"].copy_(clinical.reshape(P.buf["clin"].shape), non_blocking=True)
+        if mask is not None:
+            P.mask.copy_(mask, non_blocking=True)
+        if time is not None:
+            P.time.copy_(time.reshape(-1), non_blocking=True)
+            P.event.copy_(event.reshape(-1).to(torch.float32), non_blocking=True)
+        if valid is None:
+            P.valid.fill_(1.0)
+        else:
+            P.valid.copy_(valid.reshape(-1).to(torch.float32), non_blocking=True)
+
+    def train_step(self, ct, rna, clinical=None, mask=None, time=None, event=None, valid=None, skip_if_unusable=True,
+                   use_graph=True):
+        """One optimisation step on one batch (inputs may live on host or device).  Returns nothing: losses are
+        accumulated on the device (`epoch_stats()`), exactly one host sync per epoch instead of one per batch."""
+        B = ct.shape[0]
+        P = self.plan(B, tuple(ct.shape[-3:]))
+        self.load_batch(P, ct, rna, clinical, mask, time, event, valid)
+        if not use_graph:
+            self._train_body(P, skip_if_unusable)
+            return
+        key = ("train", skip_if_unusable)
+        if key not in P.graphs:
+            # warm-up on a side stream (first-launch attribute calls, lazy module loads), then capture
+            state = [self.flat.clone(), self.m.clone(), self.v.clone(), self.step_count.clone(), self.rng.clone(),
+                     self.acc.clone(), [b.clone() for b in self.model.buffers()]]
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self._train_body(P, skip_if_unusable)
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            with torch.no_grad():   # undo the warm-up step
+                self.flat.copy_(state[0]); self.m.copy_(state[1]); self.v.copy_(state[2])
+                self.step_count.copy_(state[3]); self.rng.copy_(state[4]); self.acc.copy_(state[5])
+                for b, b0 in zip(self.model.buffers(), state[6]):
+                    b.copy_(b0)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._train_body(P, skip_if_unusable)
+            P.graphs[key] = g
+            with torch.no_grad():   # capture does not execute, but keep state exact regardless
+                self.flat.copy_(state[0]); self.m.copy_(state[1]); self.v.copy_(state[2])
+                self.step_count.copy_(state[3]); self.rng.copy_(state[4]); self.acc.copy_(state[5])
+                for b, b0 in zip(self.model.buffers(), state[6]):
+                    b.copy_(b0)
+        P.graphs[key].replay()
+
+    def forward_eval(self, ct, rna, clinical=None, mask=None, use_graph=True):
+        """Eval-mode forward -> (hazard [B] view of a static buffer, gate [B,3] or None)."""
+        B = ct.shape[0]
+        P = self.plan(B, tuple(ct.shape[-3:]))
+        self.load_batch(P, ct, rna, clinical, mask)
+        if use_graph:
+            if "eval" not in P.graphs:
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    self._forward(P, False)
+                torch.cuda.current_stream().wait_stream(s)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._forward(P, False)
+                P.graphs["eval"] = g
+            P.graphs["eval"].replay()
+        else:
+            self._forward(P, False)
+        return P.buf["hz"][:, 0], (P.gatew if P.gate is not None else None)
+
+    def reset_epoch_stats(self):
+        self.acc.zero_()
+
+    def epoch_stats(self):
+        """-> dict(sum_loss, n_usable, sum_entropy, n_batches) (one device->host sync)."""
+        a = self.acc.tolist()
+        return dict(sum_loss=a[0], n_usable=a[1], sum_entropy=a[2], n_batches=a[3])
+
+
+def engine_of(model, **kw):
+    e = getattr(model, "_mms_engine", None)
+    if e is None:
+        e = SurvivalEngine(model, **kw)
+    return e

@@ -1,0 +1,125 @@
+"""The reference's three survival networks as drop-in nn.Modules whose forward/backward run on the HIP engine.
+
+Constructor signatures, forward signatures, sub-module names (state_dict keys) and parameter creation order are
+the reference's (final_multimodal.py:59-150, partial_modality_training.py:165-277, simple_fusion.py:160-236, MONAI
+branch).  The nn.Sequential containers only own parameters; they are never called.  Parameters stay ordinary
+autograd leaves: `torch.optim.Adam(model.parameters())`, `clip_grad_norm_`, `state_dict()/load_state_dict()` keep
+working (the autograd-compatible path), while `training.train_epoch_*` drive the fused HIP-graph step.
+"""
+import torch
+import torch.nn as nn
+
+from .densenet import DenseNet121
+from .engine import engine_of
+
+
+def _rna_encoder(rna_dim):
+    return nn.Sequential(nn.Linear(rna_dim, 512), nn.BatchNorm1d(512), nn.ReLU(), nn.Dropout(0.3),
+                         nn.Linear(512, 128), nn.ReLU())
+
+
+def _fusion(d):
+    return nn.Sequential(nn.Linear(d, 256), nn.BatchNorm1d(256), nn.ReLU(), nn.Dropout(0.3), nn.Linear(256, 128), nn.ReLU())
+
+
+class _Net(torch.autograd.Function):
+    """forward/backward of a whole network on the engine's eager path."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, ct, rna, clinical, mask):
+        eng = engine_of(model)
+        P = eng.plan(ct.shape[0], tuple(ct.shape[-3:]))
+        eng.load_batch(P, ct, rna, clinical, mask)
+        eng._forward(P, model.training)
+        ctx.eng, ctx.P, ctx.train = eng, P, model.training
+        hz = P.buf["hz"][:, 0].clone()
+        if P.gate is not None:
+            return hz, P.gatew.clone()
+        return hz, None
+
+    @staticmethod
+    def backward(ctx, dhz, dgate):
+        if not ctx.train:
+            raise RuntimeError("backward through an eval-mode forward is not supported (BN batch statistics)")
+        eng, P = ctx.eng, ctx.P
+        if eng.params[0].grad is None:
+            eng.gflat.zero_()
+            eng.attach_grads()
+        if dhz is None:
+            P.dbuf["hz"].zero_()
+        else:
+            P.dbuf["hz"][:, 0].copy_(dhz)
+        if P.gate is not None:
+            ext = dgate.contiguous() if dgate is not None else None
+            P.gate.dgate_ext = ext.data_ptr() if ext is not None else None
+            old, P.gate.ent_weight = P.gate.ent_weight, 0.0      # the entropy term arrives through dgate here
+            eng._backward_from_dhz(P)
+            P.gate.ent_weight, P.gate.dgate_ext = old, None
+        else:
+            eng._backward_from_dhz(P)
+        return None, None, None, None, None, None
+
+
+def _run(model, ct, rna, clinical, mask):
+    if not ct.is_cuda:
+        raise RuntimeError("%s (HIP): inputs must be on an MI355X device; there is no CPU fallback" % type(model).__name__)
+    anchor = next(model.parameters())
+    if torch.is_grad_enabled() and model.training:
+        return _Net.apply(anchor, model, ct, rna, clinical, mask)
+    eng = engine_of(model)
+    P = eng.plan(ct.shape[0], tuple(ct.shape[-3:]))
+    eng.load_batch(P, ct, rna, clinical, mask)
+    eng._forward(P, model.training)
+    return P.buf["hz"][:, 0].clone(), (P.gatew.clone() if P.gate is not None else None)
+
+
+class MultiModalSurvivalNet(nn.Module):
+    def __init__(self, rna_dim=5005, clinical_dim=1):
+        super().__init__()
+        self.ct_encoder = DenseNet121(spatial_dims=3, in_channels=1, out_channels=128, pretrained=False)
+        self.use_monai = True
+        self.ct_pool = nn.AdaptiveAvgPool3d(1)
+        self.rna_encoder = _rna_encoder(rna_dim)
+        self.clinical_encoder = nn.Sequential(nn.Linear(clinical_dim, 32), nn.ReLU())
+        self.fusion = _fusion(128 + 128 + 32)
+        self.cox_head = nn.Linear(128, 1)
+
+    def forward(self, ct, rna, clinical):
+        return _run(self, ct, rna, clinical, None)[0]
+
+
+class PartialModalityNet(nn.Module):
+    def __init__(self, rna_dim=5005, clinical_dim=1):
+        super().__init__()
+        self.ct_encoder = DenseNet121(spatial_dims=3, in_channels=1, out_channels=128, pretrained=False)
+        self.use_monai = True
+        self.ct_pool = nn.AdaptiveAvgPool3d(1)
+        self.rna_encoder = _rna_encoder(rna_dim)
+        self.clinical_encoder = nn.Sequential(nn.Linear(clinical_dim, 32), nn.ReLU())
+        self.gate = nn.Sequential(nn.Linear(128 + 128 + 32 + 3, 64), nn.ReLU(), nn.Linear(64, 3), nn.Softmax(dim=1))
+        self.fusion = _fusion(128 + 128 + 32)
+        self.cox_head = nn.Linear(128, 1)
+
+    def forward(self, ct, rna, clinical, mask):
+        hz, gate = _run(self, ct, rna, clinical, mask)
+        return hz, gate
+
+
+class SimpleFusionModel(nn.Module):
+    def __init__(self, rna_dim=5005, img_feature_dim=128, rna_feature_dim=256):
+        super().__init__()
+        if img_feature_dim != 128 or rna_feature_dim != 256:
+            raise ValueError("kernel widths are fixed to the reference defaults (img 128, rna 256)")
+        self.rna_encoder = nn.Sequential(
+            nn.Linear(rna_dim, 1024), nn.BatchNorm1d(1024), nn.ReLU(), nn.Dropout(0.3),
+            nn.Linear(1024, 512), nn.BatchNorm1d(512), nn.ReLU(), nn.Dropout(0.3),
+            nn.Linear(512, rna_feature_dim), nn.ReLU())
+        self.image_encoder = DenseNet121(spatial_dims=3, in_channels=1, out_channels=img_feature_dim, pretrained=False)
+        self.use_monai = True
+        self.image_pool = nn.AdaptiveAvgPool3d(1)
+        self.fusion = nn.Sequential(
+            nn.Linear(rna_feature_dim + img_feature_dim, 256), nn.BatchNorm1d(256), nn.ReLU(), nn.Dropout(0.3),
+            nn.Linear(256, 128), nn.ReLU(), nn.Dropout(0.2), nn.Linear(128, 1))
+
+    def forward(self, image, rnaseq):
+        return _run(self, image, rnaseq, None, None)[0]

@@ -164,10 +164,10 @@ def linear_bwd(dy, y, out_relu, x, K, pro, w, dw, dbias, dx=None, dgamma=None, d
 
 
 def gate_params(feats, mask, w1, b1, w2, b2, hidden, gate, fused, dfused=None, ent_weight=0.0, dfeats=None,
-                dw1=None, db1=None, dw2=None, db2=None, entropy=None):
+                dw1=None, db1=None, dw2=None, db2=None, entropy=None, dgate_ext=None):
     return _S()["GateP"](ptr(feats), ptr(mask), feats.shape[0], ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(hidden), ptr(gate),
-                         ptr(fused), ptr(dfused), float(ent_weight), ptr(dfeats), ptr(dw1), ptr(db1), ptr(dw2), ptr(db2),
-                         ptr(entropy))
+                         ptr(fused), ptr(dfused), float(ent_weight), ptr(dgate_ext), ptr(dfeats), ptr(dw1), ptr(db1),
+                         ptr(dw2), ptr(db2), ptr(entropy))
 
 
 def cox_fwd_bwd(h, time, event, valid=None, scale=1.0, want_grad=True):

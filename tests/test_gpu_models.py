@@ -1,0 +1,148 @@
+"""GPU parity of the three networks (DenseNet121 encoder + heads + Cox) against the CPU oracle restatement:
+eval hazards, train hazards/gate, loss, gradients (autograd-compatible path) and the fused HIP-graph step."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import DEV, assert_close, rel_err
+from test_gpu_densenet import structured_volumes
+
+
+def _pair(cls, seed, rna_dim):
+    from oracle import models as OM
+    from multimodal_survival_prediction_amd import models as HM
+    torch.manual_seed(seed)
+    ref = getattr(OM, cls)(rna_dim=rna_dim, use_monai=True)
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, (torch.nn.BatchNorm3d, torch.nn.BatchNorm1d)):
+                m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.1)
+                m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+    net = getattr(HM, cls)(rna_dim=rna_dim)
+    net.load_state_dict(ref.state_dict())
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    return ref, net.to(DEV)
+
+
+def _batch(B, dims, rna_dim, seed):
+    rng = np.random.default_rng(seed)
+    ct = structured_volumes(B, dims, seed)
+    rna = torch.tensor(rng.normal(0, 1, (B, rna_dim)).astype(np.float32))
+    clin = torch.tensor((np.clip(rng.normal(60, 11, (B, 1)), 30, 90) / 100).astype(np.float32))
+    t = torch.tensor((rng.exponential(1000, B) + 1 + np.arange(B) * 1e-3).astype(np.float32))
+    e = torch.tensor((rng.random(B) < 0.6).astype(np.float32)); e[0] = 1
+    mask = torch.tensor([[1, 1, 1], [0, 1, 1], [1, 0, 1], [1, 1, 0], [0, 1, 0], [1, 1, 1], [0, 0, 1], [1, 0, 0]], dtype=torch.float32)[:B]
+    return ct, rna, clin, t, e, mask
+
+
+def _grad_stats(ref, net):
+    errs, num, den = [], 0.0, 0.0
+    for (k, p), (k2, q) in zip(ref.named_parameters(), net.named_parameters()):
+        assert k == k2
+        a, b = p.grad.double(), q.grad.double().cpu()
+        errs.append(rel_err(b, a))
+        num += float(((a - b) ** 2).sum()); den += float((a ** 2).sum())
+    return float(np.median(errs)), max(errs), (num / den) ** 0.5
+
+
+@pytest.mark.parametrize("cls", ["MultiModalSurvivalNet", "PartialModalityNet", "SimpleFusionModel"])
+def test_model_parity_autograd_path(cls):
+    from oracle import losses as OL
+    from multimodal_survival_prediction_amd import losses as HL
+    B, dims, rna_dim = 4, (64, 64, 32), 5005
+    ref, net = _pair(cls, 3, rna_dim)
+    ct, rna, clin, t, e, mask = _batch(B, dims, rna_dim, 9)
+    d = lambda x: x.to(DEV)
+    args_ref = {"MultiModalSurvivalNet": (ct, rna, clin), "PartialModalityNet": (ct, rna, clin, mask), "SimpleFusionModel": (ct, rna)}[cls]
+    args_net = tuple(d(a) for a in args_ref)
+    # eval
+    ref.eval(); net.eval()
+    with torch.no_grad():
+        w, g = ref(*args_ref), net(*args_net)
+    if cls == "PartialModalityNet":
+        assert_close(g[0], w[0], 1e-4, "eval hazard"); assert_close(g[1], w[1], 1e-4, "eval gate")
+    else:
+        assert_close(g, w, 1e-4, "eval hazard")
+    # train: forward + loss + backward
+    ref.train(); net.train()
+    w, g = ref(*args_ref), net(*args_net)
+    if cls == "PartialModalityNet":
+        lw = OL.cox_loss(w[0], e, t) + 0.01 * OL.gate_entropy_loss(w[1])
+        lg = HL.cox_loss(g[0], d(e), d(t)) + 0.01 * HL.gate_entropy_loss(g[1])
+        assert_close(g[0], w[0], 1e-4, "train hazard"); assert_close(g[1], w[1], 1e-4, "train gate")
+    else:
+        lw, lg = OL.cox_loss(w, e, t), HL.cox_loss(g, d(e), d(t))
+        assert_close(g, w, 1e-4, "train hazard")
+    assert abs(lg.item() - lw.item()) <= 1e-4 * max(1.0, abs(lw.item()))
+    lw.backward(); lg.backward()
+    torch.cuda.synchronize()
+    med, mx, l2 = _grad_stats(ref, net)
+    print(f"{cls}: grad parity median {med:.2e} max {mx:.2e} L2 {l2:.2e}")
+    assert med <= 5e-5 and mx <= 5e-2 and l2 <= 2e-3      # criteria: see test_gpu_densenet.py
+    # the heads see no ReLU-flip noise from the encoder in their own weights' direct gradient: strict check
+    for k in ("cox_head.weight", "fusion.0.weight") if cls != "SimpleFusionModel" else ("fusion.7.weight", "fusion.0.weight"):
+        assert_close(dict(net.named_parameters())[k].grad, dict(ref.named_parameters())[k].grad, 2e-4, k)
+
+
+@pytest.mark.parametrize("cls", ["MultiModalSurvivalNet", "PartialModalityNet", "SimpleFusionModel"])
+def test_fused_graph_step_matches_reference_loop_body(cls):
+    """Two optimisation steps of the fused HIP-graph step == two iterations of the reference loop body
+    (zero_grad, backward, clip_grad_norm_(1.0), Adam/AdamW step) run with torch on the CPU oracle."""
+    from oracle import losses as OL
+    from multimodal_survival_prediction_amd.training import FusedOptimizer
+    B, dims, rna_dim = 4, (64, 64, 32), 5005
+    ref, net = _pair(cls, 4, rna_dim)
+    adamw = cls == "SimpleFusionModel"
+    opt_ref = (torch.optim.AdamW(ref.parameters(), lr=1e-4, weight_decay=1e-3) if adamw
+               else torch.optim.Adam(ref.parameters(), lr=1e-4, weight_decay=1e-4))
+    fo = FusedOptimizer(net, lr=1e-4, weight_decay=1e-3 if adamw else 1e-4, adamw=adamw)
+    eng = fo.engine
+    ref.train(); net.train()
+    losses_ref = []
+    for it in range(2):
+        ct, rna, clin, t, e, mask = _batch(B, dims, rna_dim, 20 + it)
+        valid = torch.tensor([1, 1, 0, 1], dtype=torch.float32) if cls != "MultiModalSurvivalNet" else None
+        if cls == "MultiModalSurvivalNet":
+            hz = ref(ct, rna, clin); loss = OL.cox_loss(hz, e, t)
+            eng.train_step(ct, rna, clin, time=t, event=e, skip_if_unusable=True)
+        elif cls == "PartialModalityNet":
+            hz, gw = ref(ct, rna, clin, mask)
+            sm = valid.bool()
+            loss = OL.cox_loss(hz[sm], e[sm], t[sm]) + 0.01 * OL.gate_entropy_loss(gw)
+            eng.train_step(ct, rna, clin, mask=mask, time=t, event=e, valid=valid, skip_if_unusable=False)
+        else:
+            hz = ref(ct, rna)
+            sm = valid.bool()
+            loss = OL.neg_partial_log_likelihood(hz[sm], e[sm].bool(), t[sm])
+            eng.train_step(ct, rna, time=t, event=e, valid=valid, skip_if_unusable=True)
+        opt_ref.zero_grad(); loss.backward()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0)
+        opt_ref.step()
+        losses_ref.append(loss.item())
+    torch.cuda.synchronize()
+    st = eng.epoch_stats()
+    assert st["n_batches"] == 2 and st["n_usable"] == 2
+    # Adam's first steps move every weight by ~lr regardless of gradient scale: compare the UPDATE, not the weight
+    ref0, _ = _pair(cls, 4, rna_dim)
+    worst = 0.0
+    for (k, p), (_, q), (_, p0) in zip(ref.named_parameters(), net.named_parameters(), ref0.named_parameters()):
+        du_ref, du_net = (p.detach() - p0.detach()).double(), (q.detach().cpu() - p0.detach()).double()
+        worst = max(worst, float((du_ref - du_net).abs().max()))
+    assert worst <= 2.5e-4, worst        # <= 1.25 x the maximum possible 2-step movement (2*lr): sign flips of ~0 grads only
+    frac_close = np.mean([float(((p.detach() - q.detach().cpu()).abs() <= 2e-5).double().mean())
+                          for (k, p), (_, q) in zip(ref.named_parameters(), net.named_parameters())])
+    assert frac_close >= 0.95, frac_close
+    # BN running statistics after two training forwards
+    for (k, b), (_, c) in zip(ref.named_buffers(), net.named_buffers()):
+        if "num_batches" in k:
+            assert int(b) == int(c), k
+        else:
+            assert_close(c, b, 1e-4, k)
