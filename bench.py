@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Headline benchmark: patients/sec of the multimodal survival training hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): full MultiModalSurvivalNet (DenseNet121-3D CT 64x64x32 + RNA-seq 5005 +
+clinical), 109 synthetic complete-modality patients, batch 4, fold 1 of a 5-fold split, Adam(lr 1e-4, wd 1e-4),
+clip_grad_norm_(1.0).  A "step" is one pass of the hot path over one batch of 4 patients: zero-grad, forward,
+Cox partial likelihood, backward, clip, Adam -- all inside one replayed HIP graph.  The cohort is resident in HBM
+before the timed region; per step the batch is gathered device-to-device into the graph's static buffers.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]            (N>1: launched by torch.distributed.run)
+N>1 shards K-fold units over ranks (fold k -> rank k mod N, no data-path collective): weak scaling.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  "roofline":     dominant kernel, algorithmic FLOPs / measured average launch duration vs the fp32 MFMA peak
+  "cpu_baseline": the CPU oracle (torch fp32 restatement of the same model/loop) timed on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
+BLOCKS = ((6, 64), (12, 128), (24, 256), (16, 512))     # (layers, first-layer input channels) of DenseNet121
+
+
+def conv3_launch_table(B, dims):
+    """(rows M, algorithmic FLOPs) of every conv2 (3x3x3, 128->32) launch of one forward, in launch order.
+    FLOPs = 2 * M * 27 * 128 * 32 (the dense-layer 3^3 conv; zero-padding taps included,
+    as in the survey's MAC count)."""
+    D, H, W = dims
+    rows = []
+    vox = (D // 4) * (H // 4) * (W // 4)
+    for i, (layers, _) in enumerate(BLOCKS):
+        M = B * vox // (8 ** i)
+        rows += [(M, 2.0 * M * 27 * 128 * 32)] * layers
+    return rows
+
+
+def measure_dominant_kernel(B, dims, device, reps=20):
+    """Average launch duration of the conv3 forward kernel (tile_gemm_kernel<Conv3FwdOp>) over the 58 launches of
+    one forward, timed live with HIP events on the launch stream (torch's current stream), shape by shape."""
+    from multimodal_survival_prediction_amd import ops
+    tot_t, tot_f, n = 0.0, 0.0, 0
+    D, H, W = dims
+    wp = torch.randn(32 * 27 * 128, device=device) * 0.02
+    g, b = torch.ones(128, device=device), torch.zeros(128, device=device)
+    for i, (layers, _) in enumerate(BLOCKS):
+        gd = (D // 4 >> i, H // 4 >> i, W // 4 >> i)
+        M = B * gd[0] * gd[1] * gd[2]
+        y1 = torch.randn(M, 128, device=device)
+        s, q = y1.double().sum(0), (y1.double() ** 2).sum(0)
+        bn = ops.bnsrc(g, b, M, True, s, q)
+        coords = ops.init_coords(B, gd, device)
+        slab = torch.zeros(M, 256, device=device)
+        os_, oq = torch.zeros(32, dtype=torch.float64, device=device), torch.zeros(32, dtype=torch.float64, device=device)
+        for _ in range(3):
+            ops.conv3_fwd(y1, coords, gd, wp, slab[:, 64:96], bn, os_, oq)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.conv3_fwd(y1, coords, gd, wp, slab[:, 64:96], bn, os_, oq)
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / reps
+        tot_t += t * layers
+        tot_f += 2.0 * M * 27 * 128 * 32 * layers
+        n += layers
+    return tot_t / n, tot_f / n
+
+
+def cpu_baseline(cohort, train_idx, steps, B):
+    """The CPU oracle (same model, same loop body) on this box's host cores: bounded sample of `steps` batches."""
+    from oracle import losses as OL
+    from oracle import models as OM
+    torch.manual_seed(0)
+    model = OM.MultiModalSurvivalNet(rna_dim=cohort["rnaseq"].shape[1], use_monai=True)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-4)
+    model.train()
+    cores = torch.get_num_threads()
+
+    def one(i):
+        j = train_idx[i * B:(i + 1) * B]
+        hz = model(cohort["image"][j], cohort["rnaseq"][j], cohort["clinical"][j])
+        loss = OL.cox_loss(hz, cohort["label"][j, 1], cohort["label"][j, 0])
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+
+    one(0)
+    t0 = time.perf_counter()
+    for i in range(1, steps + 1):
+        one(i)
+    dt = time.perf_counter() - t0
+    return dict(value=steps * B / dt, unit="patients/s", cores=cores, kind="port",
+                sample=f"{steps} training steps (batch {B}) of the torch-fp32 CPU oracle after 1 warm-up step, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    from multimodal_survival_prediction_amd import distributed as D
+    world, rank, local = D.init()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from multimodal_survival_prediction_amd import _build, _lib
+    if not os.path.exists(_lib.lib_path()):
+        _build.build()
+    from multimodal_survival_prediction_amd import data, models
+    from multimodal_survival_prediction_amd.training import FusedOptimizer
+
+    B, dims, rna_dim = args.batch, (64, 64, 32), 5005
+    cohort_cpu = data.make_cohort(n=109, dims=dims, rna_dim=rna_dim, seed=608, complete=True)
+    cohort = data.cohort_to(cohort_cpu, dev)                      # resident in HBM before the timed region
+    folds = data.kfold_indices(cohort["n"], 5, seed=42)
+    train_idx = torch.as_tensor(folds[rank % 5][0])
+    torch.manual_seed(42 + rank)
+    model = models.MultiModalSurvivalNet(rna_dim=rna_dim).to(dev)
+    opt = FusedOptimizer(model, lr=1e-4, weight_decay=1e-4, adamw=False)
+    eng = opt.engine
+    model.train()
+    nb = len(train_idx) // B                                      # full batches of the fold's train split
+    gen = torch.Generator().manual_seed(7)
+    order = train_idx[torch.randperm(len(train_idx), generator=gen)].to(dev)
+
+    def step(i):
+        j = order[(i % nb) * B:(i % nb) * B + B]
+        lab = cohort["label"][j]
+        eng.train_step(cohort["image"][j], cohort["rnaseq"][j], cohort["clinical"][j], time=lab[:, 0], event=lab[:, 1],
+                       skip_if_unusable=True, use_graph=not args.no_graph)
+
+    for i in range(max(args.warmup, 2)):
+        step(i)
+    torch.cuda.synchronize()
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    D.barrier()
+    torch.cuda.synchronize()
+    dt = D.max_over_ranks(time.perf_counter() - t0, dev)
+    stats = eng.epoch_stats()
+
+    if rank == 0:
+        out = {
+            "metric": "patients/sec per epoch (training: fwd + Cox + bwd + clip + Adam)",
+            "value": world * args.steps * B / dt, "unit": "patients/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "MultiModalSurvivalNet (DenseNet121-3D CT 64x64x32 + RNA-seq 5005 + clinical), "
+                                   "109 synthetic complete patients, 5-fold split, batch 4, Adam lr 1e-4 wd 1e-4, clip 1.0",
+                       "global_batch": world * B, "parallelism": f"kfold-shard x{world} (fold k -> rank k mod N, no collective)",
+                       "hip_graph": not args.no_graph, "mean_train_loss": stats["sum_loss"] / max(stats["n_batches"], 1)},
+        }
+        avg_t, avg_f = measure_dominant_kernel(B, dims, dev)
+        out["roofline"] = {"bound": "mfma", "kernel": "tile_gemm_kernel<Conv3FwdOp> (dense-layer 3x3x3 conv, 58 launches/forward)",
+                           "achieved": avg_f / avg_t / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": avg_f / avg_t / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                           "avg_launch_us": avg_t * 1e6, "avg_flops_per_launch": avg_f}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cohort_cpu, torch.as_tensor(folds[0][0]), args.cpu_steps, B)
+        print(json.dumps(out), flush=True)
+    D.barrier()
+
+
+if __name__ == "__main__":
+    main()

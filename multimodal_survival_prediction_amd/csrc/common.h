@@ -75,6 +75,10 @@ __device__ __forceinline__ float dropout_scale(uint32_t seed, uint32_t stream, u
     return u < p ? 0.0f : 1.0f / (1.0f - p);
 }
 
+// Launch with a clean error slate: hipGetLastError() is sticky per thread and the host framework may leave benign
+// errors behind (e.g. attribute probes), which must not be reported as ours.
+#define MMS_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 static inline int mms_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MMS_OK : MMS_ERR_LAUNCH;

@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyP p) 
 extern "C" int mms_bn_bwd_apply(const BnBwdApplyP* pp, hipStream_t s) {
     const BnBwdApplyP& p = *pp;
     if (p.M <= 0 || p.C % 4 != 0 || p.C > 2048 || p.lddbn % 4 || p.ldx % 4 || p.lddx % 4) return MMS_ERR_ARG;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((p.M + 31) / 32), dim3(256), 5 * p.C * sizeof(float), s, p);
+    MMS_LAUNCH(bn_bwd_apply_kernel, dim3((p.M + 31) / 32), dim3(256), 5 * p.C * sizeof(float), s, p);
     return mms_check_launch();
 }
 
@@ -450,8 +450,8 @@ __global__ __launch_bounds__(256) void head_bwd_w_kernel(const HeadBwdP p) {
 extern "C" int mms_head_bwd(const HeadBwdP* pp, hipStream_t s) {
     const HeadBwdP& p = *pp;
     if (p.B <= 0) return MMS_ERR_ARG;
-    hipLaunchKernelGGL(head_bwd_feat_kernel, dim3((p.C + 255) / 256), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(head_bwd_w_kernel, dim3((p.N * p.C + 255) / 256), dim3(256), 0, s, p);
+    MMS_LAUNCH(head_bwd_feat_kernel, dim3((p.C + 255) / 256), dim3(256), 0, s, p);
+    MMS_LAUNCH(head_bwd_w_kernel, dim3((p.N * p.C + 255) / 256), dim3(256), 0, s, p);
     return mms_check_launch();
 }
 
@@ -502,7 +502,7 @@ extern "C" int mms_pool_bwd(const PoolBwdP* pp, hipStream_t s) {
     const PoolBwdP& p = *pp;
     const int Min = p.B * p.in.D * p.in.H * p.in.W;
     if (Min <= 0) return MMS_ERR_ARG;
-    hipLaunchKernelGGL(pool_bwd_kernel, dim3((Min + 255) / 256), dim3(256), 0, s, p);
+    MMS_LAUNCH(pool_bwd_kernel, dim3((Min + 255) / 256), dim3(256), 0, s, p);
     return mms_check_launch();
 }
 

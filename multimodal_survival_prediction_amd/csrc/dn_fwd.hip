@@ -267,7 +267,7 @@ extern "C" int mms_pool_fwd(const PoolFwdP* pp, hipStream_t s) {
     const PoolFwdP& p = *pp;
     int Mout = p.B * p.out.D * p.out.H * p.out.W;
     if (Mout <= 0) return MMS_ERR_ARG;
-    hipLaunchKernelGGL(pool_fwd_kernel, dim3((Mout + 31) / 32), dim3(256), 0, s, p);
+    MMS_LAUNCH(pool_fwd_kernel, dim3((Mout + 31) / 32), dim3(256), 0, s, p);
     return mms_check_launch();
 }
 
@@ -303,7 +303,7 @@ extern "C" int mms_head_fwd(const HeadFwdP* pp, hipStream_t s) {
     const HeadFwdP& p = *pp;
     size_t smem = (size_t)p.B * p.C * sizeof(float);
     if (smem > 64 * 1024 || p.B <= 0) return MMS_ERR_ARG;
-    hipLaunchKernelGGL(head_fwd_kernel, dim3((p.N + 3) / 4), dim3(256), smem, s, p);
+    MMS_LAUNCH(head_fwd_kernel, dim3((p.N + 3) / 4), dim3(256), smem, s, p);
     return mms_check_launch();
 }
 
@@ -320,7 +320,7 @@ extern "C" int mms_init_coords(int* coords, int B, int D, int H, int W, hipStrea
     if (D > 1023 || H > 1023 || W > 1023) return MMS_ERR_ARG;
     int M = B * D * H * W;
     Dims3 g{D, H, W};
-    hipLaunchKernelGGL(init_coords_kernel, dim3((M + 255) / 256), dim3(256), 0, s, coords, M, g);
+    MMS_LAUNCH(init_coords_kernel, dim3((M + 255) / 256), dim3(256), 0, s, coords, M, g);
     return mms_check_launch();
 }
 
@@ -334,7 +334,7 @@ __global__ void pack_conv3_kernel(const float* __restrict__ w, float* __restrict
     wpb[(cin * 27 + tap) * 32 + cout] = v;
 }
 extern "C" int mms_pack_conv3(const float* w, float* wpf, float* wpb, hipStream_t s) {
-    hipLaunchKernelGGL(pack_conv3_kernel, dim3(32 * 27 * 128 / 256), dim3(256), 0, s, w, wpf, wpb);
+    MMS_LAUNCH(pack_conv3_kernel, dim3(32 * 27 * 128 / 256), dim3(256), 0, s, w, wpf, wpb);
     return mms_check_launch();
 }
 
@@ -349,7 +349,7 @@ __global__ void pack_conv3_table_kernel(const PackEntry* tab) {
     e.wpb[(cin * 27 + tap) * 32 + cout] = v;
 }
 extern "C" int mms_pack_conv3_table(const void* table_dev, int nlayers, hipStream_t s) {
-    hipLaunchKernelGGL(pack_conv3_table_kernel, dim3(32 * 27 * 128 / 256, nlayers), dim3(256), 0, s,
+    MMS_LAUNCH(pack_conv3_table_kernel, dim3(32 * 27 * 128 / 256, nlayers), dim3(256), 0, s,
                        (const PackEntry*)table_dev);
     return mms_check_launch();
 }
@@ -369,6 +369,6 @@ __global__ void bn_running_update_kernel(const BnRunEntry* tab, float momentum) 
 }
 extern "C" int mms_bn_running_update(const void* table_dev, int n, float momentum, hipStream_t s) {
     if (n <= 0) return MMS_OK;
-    hipLaunchKernelGGL(bn_running_update_kernel, dim3(n), dim3(256), 0, s, (const BnRunEntry*)table_dev, momentum);
+    MMS_LAUNCH(bn_running_update_kernel, dim3(n), dim3(256), 0, s, (const BnRunEntry*)table_dev, momentum);
     return mms_check_launch();
 }

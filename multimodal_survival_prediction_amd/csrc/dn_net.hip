@@ -169,6 +169,7 @@ extern "C" int mms_dn121_init(void* ws, int B, int D, int H, int W, const void* 
     if (!make_plan(P, B, D, H, W) || !ws || !params || !buffers) return MMS_ERR_ARG;
     TRY(mms_init_coords(at<int>(ws, P.coords0), B, P.g0.D, P.g0.H, P.g0.W, s));
     for (int b = 0; b < NB; ++b) TRY(mms_init_coords(at<int>(ws, P.coords[b]), B, P.g[b].D, P.g[b].H, P.g[b].W, s));
+    (void)hipGetLastError();
     PackEntry pk[NLAYER];
     BnRunEntry bn[NBN];
     auto set_bn = [&](int ord, size_t st, int Ctot_, int C, int count) {

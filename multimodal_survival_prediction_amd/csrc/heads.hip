@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const LinearFwdP p) {
 
 template <int MM>
 static int launch_linear_fwd(const LinearFwdP& p, hipStream_t s) {
-    hipLaunchKernelGGL(linear_fwd_kernel<MM>, dim3((p.N + 3) / 4), dim3(256), 0, s, p);
+    MMS_LAUNCH(linear_fwd_kernel<MM>, dim3((p.N + 3) / 4), dim3(256), 0, s, p);
     return mms_check_launch();
 }
 extern "C" int mms_linear_fwd(const LinearFwdP* pp, hipStream_t s) {
@@ -192,8 +192,8 @@ __global__ __launch_bounds__(256) void linear_bwd_x_kernel(const LinearBwdP p) {
 
 template <int MM>
 static int launch_linear_bwd(const LinearBwdP& p, hipStream_t s) {
-    if (p.dw) hipLaunchKernelGGL(linear_bwd_w_kernel<MM>, dim3((p.N + 3) / 4), dim3(256), 0, s, p);
-    if (p.dx) hipLaunchKernelGGL(linear_bwd_x_kernel<MM>, dim3((p.K + 255) / 256), dim3(256), 0, s, p);
+    if (p.dw) MMS_LAUNCH(linear_bwd_w_kernel<MM>, dim3((p.N + 3) / 4), dim3(256), 0, s, p);
+    if (p.dx) MMS_LAUNCH(linear_bwd_x_kernel<MM>, dim3((p.K + 255) / 256), dim3(256), 0, s, p);
     return mms_check_launch();
 }
 extern "C" int mms_linear_bwd(const LinearBwdP* pp, hipStream_t s) {
@@ -306,18 +306,18 @@ __global__ void gate_entropy_kernel(const float* gate, int M, float scale, float
 }
 extern "C" int mms_gate_entropy(const float* gate, int M, float scale, float* loss, float* dgate, hipStream_t s) {
     if (M <= 0) return MMS_ERR_ARG;
-    hipLaunchKernelGGL(gate_entropy_kernel, dim3((M + 63) / 64), dim3(64), 0, s, gate, M, scale, loss, dgate);
+    MMS_LAUNCH(gate_entropy_kernel, dim3((M + 63) / 64), dim3(64), 0, s, gate, M, scale, loss, dgate);
     return mms_check_launch();
 }
 
 extern "C" int mms_gate_fwd(const GateP* pp, hipStream_t s) {
     if (pp->M <= 0) return MMS_ERR_ARG;
-    hipLaunchKernelGGL(gate_fwd_kernel, dim3(pp->M), dim3(256), 0, s, *pp);
+    MMS_LAUNCH(gate_fwd_kernel, dim3(pp->M), dim3(256), 0, s, *pp);
     return mms_check_launch();
 }
 extern "C" int mms_gate_bwd(const GateP* pp, hipStream_t s) {
     if (pp->M <= 0) return MMS_ERR_ARG;
-    hipLaunchKernelGGL(gate_bwd_kernel, dim3(pp->M), dim3(256), 0, s, *pp);
+    MMS_LAUNCH(gate_bwd_kernel, dim3(pp->M), dim3(256), 0, s, *pp);
     return mms_check_launch();
 }
 
@@ -381,8 +381,8 @@ __global__ __launch_bounds__(256) void cox_grad_kernel(const CoxP p) {
 extern "C" int mms_cox_fwd_bwd(const CoxP* pp, hipStream_t s) {
     const CoxP& p = *pp;
     if (p.n <= 0 || !p.lse || !p.out) return MMS_ERR_ARG;
-    hipLaunchKernelGGL(cox_lse_kernel, dim3((p.n + 3) / 4), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(cox_grad_kernel, dim3((p.n + 3) / 4), dim3(256), 0, s, p);
+    MMS_LAUNCH(cox_lse_kernel, dim3((p.n + 3) / 4), dim3(256), 0, s, p);
+    MMS_LAUNCH(cox_grad_kernel, dim3((p.n + 3) / 4), dim3(256), 0, s, p);
     return mms_check_launch();
 }
 
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void cindex_kernel(const CindexP p) {
 }
 extern "C" int mms_cindex_counts(const CindexP* pp, hipStream_t s) {
     if (pp->n <= 0) return MMS_ERR_ARG;
-    hipLaunchKernelGGL(cindex_kernel, dim3((pp->n + 3) / 4), dim3(256), 0, s, *pp);
+    MMS_LAUNCH(cindex_kernel, dim3((pp->n + 3) / 4), dim3(256), 0, s, *pp);
     return mms_check_launch();
 }
 
@@ -464,13 +464,13 @@ extern "C" int mms_grad_sumsq(const AdamP* pp, hipStream_t s) {
     long long blocks = (pp->n / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(grad_sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, *pp);
+    MMS_LAUNCH(grad_sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, *pp);
     return mms_check_launch();
 }
 extern "C" int mms_clip_adam(const AdamP* pp, hipStream_t s) {
     if (pp->n <= 0) return MMS_ERR_ARG;
     long long blocks = (pp->n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, *pp);
+    MMS_LAUNCH(clip_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, *pp);
     return mms_check_launch();
 }

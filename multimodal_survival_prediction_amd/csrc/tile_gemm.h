@@ -208,6 +208,6 @@ static inline int launch_tile_gemm(const typename Op::Params& p, dim3 grid, hipS
         attr_set = true;
     }
     if (grid.x == 0 || grid.y == 0 || grid.z == 0) return MMS_OK;
-    hipLaunchKernelGGL(tile_gemm_kernel<Op>, grid, dim3(256), smem, s, p);
+    MMS_LAUNCH(tile_gemm_kernel<Op>, grid, dim3(256), smem, s, p);
     return mms_check_launch();
 }

@@ -1,0 +1,62 @@
+"""Multi-GPU: one process per GPU, torch.distributed (backend "nccl" == RCCL over xGMI on ROCm; "gloo" on CPU tests).
+
+Two ways the path shards:
+  * K-fold level -- independent units, zero data-path exchange: fold k runs on rank k mod world; only the per-fold
+    result records are gathered at the end (`gather_fold_results`).  Reproduces single-GPU results exactly.
+  * patient/batch level (DDP): each rank steps on its shard of the global batch; the flat gradient buffer is
+    all-reduced (SUM then /world) between backward and the clip+Adam kernels (`allreduce_mean_`), one collective of
+    56 MB instead of 364 small ones.  BatchNorm statistics and the Cox risk set stay rank-local in this round
+    (documented difference to a single-process batch of world*B).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend=None):
+    world, rank, local = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank, world_size=world)
+    return world, rank, local
+
+
+def folds_of_rank(n_folds, world, rank):
+    """fold k -> rank k mod world."""
+    return [k for k in range(n_folds) if k % world == rank]
+
+
+def gather_fold_results(local_results, world):
+    """local_results: list of dicts (each with a 'fold' key) -> all folds' records, ordered by fold, on every rank."""
+    if world <= 1:
+        return sorted(local_results, key=lambda r: r["fold"])
+    out = [None] * world
+    dist.all_gather_object(out, local_results)
+    return sorted([r for part in out for r in part], key=lambda r: r["fold"])
+
+
+def allreduce_mean_(flat, world):
+    """In-place mean of a flat gradient buffer over ranks (one bucket: the buffer is already contiguous)."""
+    if world > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(world)
+    return flat
+
+
+def max_over_ranks(x, device):
+    if not dist.is_initialized():
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
