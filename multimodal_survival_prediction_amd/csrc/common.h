@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "../../include/mmsurv.h"
 
@@ -81,5 +82,6 @@ __device__ __forceinline__ float dropout_scale(uint32_t seed, uint32_t stream, u
 
 static inline int mms_check_launch() {
     hipError_t e = hipGetLastError();
+    if (e != hipSuccess) fprintf(stderr, "mmsurv: kernel launch failed: %s\n", hipGetErrorString(e));
     return e == hipSuccess ? MMS_OK : MMS_ERR_LAUNCH;
 }

@@ -11,6 +11,7 @@
 // Buffer table order: per BatchNorm in module order {running_mean, running_var, num_batches_tracked} (121 BNs).
 #include "dn_ops.h"
 #include <string.h>
+#include <stdio.h>
 
 namespace {
 
@@ -190,9 +191,13 @@ extern "C" int mms_dn121_init(void* ws, int B, int D, int H, int W, const void* 
         if (b < 3) set_bn(IDX.bn_trans[b], P.st_slab[b], CTOT[b], CTOT[b], P.M[b]);
         else set_bn(IDX.bn5, P.st_slab[b], CTOT[b], CTOT[b], P.M[b]);
     }
-    if (hipMemcpyAsync(at<void>(ws, P.tab_pack), pk, sizeof(pk), hipMemcpyHostToDevice, s) != hipSuccess) return MMS_ERR_LAUNCH;
-    if (hipMemcpyAsync(at<void>(ws, P.tab_bn), bn, sizeof(bn), hipMemcpyHostToDevice, s) != hipSuccess) return MMS_ERR_LAUNCH;
-    if (hipStreamSynchronize(s) != hipSuccess) return MMS_ERR_LAUNCH;   // pk/bn are stack arrays
+    hipError_t e1 = hipMemcpyAsync(at<void>(ws, P.tab_pack), pk, sizeof(pk), hipMemcpyHostToDevice, s);
+    hipError_t e2 = hipMemcpyAsync(at<void>(ws, P.tab_bn), bn, sizeof(bn), hipMemcpyHostToDevice, s);
+    hipError_t e3 = hipStreamSynchronize(s);   // pk/bn are stack arrays
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+        fprintf(stderr, "mms_dn121_init: memcpy/sync failed: %s / %s / %s\n", hipGetErrorString(e1), hipGetErrorString(e2), hipGetErrorString(e3));
+        return MMS_ERR_LAUNCH;
+    }
     return MMS_OK;
 }
 
