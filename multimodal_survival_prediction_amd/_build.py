@@ -9,6 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmmsurv_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-fPIC", "-std=c++17", "-Wno-unused-value"]
+FLAGS += os.environ.get("MMS_CXXFLAGS", "").split()      # diagnostic builds only (timing-only ablations)
 
 
 def _sources():

@@ -38,7 +38,10 @@ def _ctype(tstr):
 
 
 def parse_header(path=HEADER):
-    """-> (structs: name -> ctypes.Structure subclass, protos: name -> [arg type strings])."""
+    """-> (structs: name -> ctypes.Structure subclass, protos: name -> [arg type strings]).  Parsed once: the
+    Structure classes must be unique objects (ctypes checks field types by identity)."""
+    if _STRUCTS and _PROTOS:
+        return _STRUCTS, _PROTOS
     src = _strip_comments(open(path).read())
     for m in re.finditer(r"typedef\s+struct\s+(\w+)\s*\{(.*?)\}\s*(\w+)\s*;", src, flags=re.S):
         name, body = m.group(1), m.group(2)

@@ -17,7 +17,7 @@ __device__ __forceinline__ void bn_mean_rstd(const BnSrc& b, int c, float& mean,
         double v = b.sumsq[c] * (double)b.inv_count - m * m;
         v = v > 0.0 ? v : 0.0;
         mean = (float)m;
-        rstd = (float)(1.0 / sqrt(v + (double)b.eps));
+        rstd = 1.0f / sqrtf((float)v + b.eps);      // the fp64 part is the cancellation-prone E[x^2]-E[x]^2 only
     } else {
         mean = b.rmean[c];
         rstd = 1.0f / sqrtf(b.rvar[c] + b.eps);
@@ -74,6 +74,17 @@ __device__ __forceinline__ float dropout_scale(uint32_t seed, uint32_t stream, u
     uint32_t h = hash_u32(idx * 0x9E3779B9U + hash_u32(seed ^ (stream * 0x85ebca6bU)));
     float u = (float)(h >> 8) * (1.0f / 16777216.0f);
     return u < p ? 0.0f : 1.0f / (1.0f - p);
+}
+
+// raw buffer loads: 128-bit resource in SGPRs + 32-bit byte offsets -> no 64-bit per-lane address arithmetic, and
+// a wave-uniform scalar offset (soffset) for the per-tile part of the address
+typedef __amdgpu_buffer_rsrc_t buf_rsrc_t;
+__device__ __forceinline__ buf_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(buf_rsrc_t r, int voff, int soff) {
+    auto v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return *(float4*)&v;
 }
 
 // Launch with a clean error slate: hipGetLastError() is sticky per thread and the host framework may leave benign

@@ -11,47 +11,67 @@
 // ------------------------------------------------------------------------------------------------------
 // conv3 backward-data:  dbn2[m][cin] = [a2>0] * sum_{tap,cout} dz[m - off(tap)][cout] * W[cout][cin][tap]
 // ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned tap_mask9(int c, Dims3 g, bool mirror) {
+    int d, h, w;
+    unpack_dhw(c, d, h, w);
+    const unsigned lo_d = d > 0, hi_d = d + 1 < g.D, lo_h = h > 0, hi_h = h + 1 < g.H, lo_w = w > 0, hi_w = w + 1 < g.W;
+    const unsigned dm = mirror ? (hi_d | 2u | (lo_d << 2)) : (lo_d | 2u | (hi_d << 2));
+    const unsigned hm = mirror ? (hi_h | 2u | (lo_h << 2)) : (lo_h | 2u | (hi_h << 2));
+    const unsigned wm = mirror ? (hi_w | 2u | (lo_w << 2)) : (lo_w | 2u | (hi_w << 2));
+    return dm | (hm << 3) | (wm << 6);
+}
+
 struct Conv3BwdDataOp {
     typedef Conv3BwdDataP Params;
     static constexpr int WM = 1, WN = 4, WK = 1, AMODE = LD_K4, BMODE = LD_K4;
+    static constexpr bool SPEC = false;
     static constexpr int TM = 32, TN = 128;
-    static constexpr int EXTRA = 4 * 128 + 32 + 2 * 2 * 128 * 2;   // bn consts, row coords, fp64 reduction scratch
+    static constexpr int EXTRA = 4 * 128 + 32 + 2 * 2 * 128 * 2;   // bn consts, (unused), fp64 reduction scratch
+    typedef float4 ARaw;
+    typedef float4 BRaw;
     float* ex;
-    const int* rowc;
-    int m0;
-    __device__ void setup(const Params& p, int m0_, int, int, float* extra, int tid) {
-        ex = extra; rowc = (const int*)(extra + 512); m0 = m0_;
+    // TK = 32 = the 32 output channels of one tap; per-thread constants as in Conv3FwdOp (taps mirrored)
+    int voff, woff[4], tapoff_b, wsoff;
+    unsigned m9, sel;
+    buf_rsrc_t rz, rw;
+    __device__ void setup(const Params& p, int m0, int, int, float* extra, int tid) {
+        ex = extra;
         if (tid < 128) {
             float mu, rstd;
             bn_mean_rstd(p.bn, tid, mu, rstd);
             extra[tid] = mu; extra[128 + tid] = rstd; extra[256 + tid] = p.bn.gamma[tid]; extra[384 + tid] = p.bn.beta[tid];
         }
-        if (tid < 32) ((int*)extra)[512 + tid] = (m0 + tid < p.M) ? p.coords[m0 + tid] : -1;
+        rz = make_rsrc(p.dz, (unsigned)(p.M - 1) * (unsigned)p.lddz * 4u + 128u);
+        rw = make_rsrc(p.wpb, 128u * 27u * 32u * 4u);
+        const int row = tid >> 3, co = (tid & 7) * 4, m = m0 + row;
+        const bool valid = m < p.M;
+        m9 = valid ? tap_mask9(p.coords[valid ? m : m0], p.g, true) : 0u;
+        voff = ((valid ? m : m0) * p.lddz + co) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) woff[i] = (((tid >> 3) + 32 * i) * 864 + co) * 4;
     }
     __device__ void krange(const Params&, int, int& kb, int& ke) { kb = 0; ke = 27 * 32; }
-    __device__ float4 a_k4(const Params& p, int m, int k) const {
-        const int c = rowc[m - m0];
-        if (c < 0) return Z4;
-        const int tap = k >> 5, co = k & 31;
-        const int kd = tap / 9 - 1, kh = (tap / 3) % 3 - 1, kw = tap % 3 - 1;
-        int d, h, w;
-        unpack_dhw(c, d, h, w);
-        if ((unsigned)(d - kd) >= (unsigned)p.g.D || (unsigned)(h - kh) >= (unsigned)p.g.H ||
-            (unsigned)(w - kw) >= (unsigned)p.g.W)
-            return Z4;
-        const int src = m - ((kd * p.g.H + kh) * p.g.W + kw);
-        return *(const float4*)(p.dz + (size_t)src * p.lddz + co);
+    __device__ void step(const Params& p, int k0) {
+        const int tap = k0 >> 5, kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        sel = (1u << kd) | (8u << kh) | (64u << kw);
+        tapoff_b = -(((kd - 1) * p.g.H + (kh - 1)) * p.g.W + (kw - 1)) * p.lddz * 4;
+        wsoff = k0 * 4;
     }
-    __device__ float4 b_k4(const Params& p, int n, int k) const { return *(const float4*)(p.wpb + (size_t)n * 864 + k); }
-    __device__ float4 a_r4(const Params&, int, int) const { return Z4; }
-    __device__ float4 b_r4(const Params&, int, int) const { return Z4; }
-    __device__ float a_k1(const Params&, int, int) const { return 0; }
-    __device__ float b_k1(const Params&, int, int) const { return 0; }
-    __device__ void epilogue(const Params& p, int m0_, int, int, const float* Cs, int tid) {
+    __device__ float4 a_ld(const Params&, int, int, int, bool& ok) const {
+        ok = (m9 & sel) == sel;
+        return buf_load4(rz, voff + (ok ? tapoff_b : 0), 0);
+    }
+    __device__ float4 a_tx(const Params&, int, const float4& v, int, int, bool ok) const {
+        const float z = ok ? 1.f : 0.f;
+        return make_float4(z * v.x, z * v.y, z * v.z, z * v.w);
+    }
+    __device__ float4 b_ld(const Params&, int i, int, int, bool& ok) const { ok = true; return buf_load4(rw, woff[i], wsoff); }
+    __device__ float4 b_tx(const Params&, int, const float4& v, int, int, bool) const { return v; }
+    __device__ void epilogue(const Params& p, int m0_, int, int, const float* Cs, int tid, bool active) {
         const int c = tid & 127, rg = tid >> 7;
         const float mu = ex[c], rstd = ex[128 + c], ga = ex[256 + c], be = ex[384 + c];
         double s1 = 0, s2 = 0;
-        const int rows = p.M - m0_ < TM ? p.M - m0_ : TM;
+        const int rows = !active ? 0 : (p.M - m0_ < TM ? p.M - m0_ : TM);
         for (int r = rg; r < rows; r += 2) {
             const size_t o = (size_t)(m0_ + r) * 128 + c;
             const float xh = (p.y1[o] - mu) * rstd;
@@ -61,9 +81,9 @@ struct Conv3BwdDataOp {
             s1 += g; s2 += (double)g * xh;
         }
         double* red = (double*)(ex + 544);     // [2][2][128], 8-byte aligned (544*4 = 2176)
-        red[(rg * 2 + 0) * 128 + c] = s1; red[(rg * 2 + 1) * 128 + c] = s2;
+        if (active) { red[(rg * 2 + 0) * 128 + c] = s1; red[(rg * 2 + 1) * 128 + c] = s2; }
         __syncthreads();
-        if (rg == 0) {
+        if (rg == 0 && active) {
             atomicAdd(&p.s1[c], red[c] + red[2 * 128 + c]);
             atomicAdd(&p.s2[c], red[128 + c] + red[3 * 128 + c]);
         }
@@ -83,52 +103,66 @@ extern "C" int mms_conv3_bwd_data(const Conv3BwdDataP* pp, hipStream_t s) {
 struct Conv3BwdWOp {
     typedef Conv3BwdWP Params;
     static constexpr int WM = 4, WN = 1, WK = 1, AMODE = LD_R4, BMODE = LD_R4;
+    static constexpr bool SPEC = false;
     static constexpr int TM = 128, TN = 32;
-    static constexpr int EXTRA = 3 * 128;
-    const float *mean, *sc, *beta;
-    int tap, kd, kh, kw, mb, me;
+    static constexpr int EXTRA = 1024;       // tap-validity mask of every voxel of this workgroup's row chunk
+    typedef float4 ARaw;
+    typedef float4 BRaw;
+    // TM/4 = 32 row groups: a thread's 4 input channels ((tid & 31) * 4 ...) never change -> BN constants in registers
+    float mean[4], sc[4], beta[4];
+    const unsigned* vm;
+    int tap, mb, me, avoff[4], bvoff, tapoff_b, asoff, bsoff, k0s;
+    unsigned sel;
+    buf_rsrc_t ry, rz;
     __device__ void setup(const Params& p, int, int, int z, float* extra, int tid) {
-        mean = extra; sc = extra + 128; beta = extra + 256;
-        if (tid < 128) {
+        const int c0 = (tid & 31) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
             float mu, rstd;
-            bn_mean_rstd(p.bn, tid, mu, rstd);
-            extra[tid] = mu; extra[128 + tid] = p.bn.gamma[tid] * rstd; extra[256 + tid] = p.bn.beta[tid];
+            bn_mean_rstd(p.bn, c0 + j, mu, rstd);
+            mean[j] = mu; sc[j] = p.bn.gamma[c0 + j] * rstd; beta[j] = p.bn.beta[c0 + j];
         }
         tap = z % 27;
-        kd = tap / 9 - 1; kh = (tap / 3) % 3 - 1; kw = tap % 3 - 1;
+        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        sel = (1u << kd) | (8u << kh) | (64u << kw);
+        tapoff_b = (((kd - 1) * p.g.H + (kh - 1)) * p.g.W + (kw - 1)) * 512;
         const int chunk = z / 27;
         int mc = (p.M + p.msplit - 1) / p.msplit;
         mc = (mc + 31) & ~31;
         mb = chunk * mc;
         me = mb + mc < p.M ? mb + mc : p.M;
+        vm = (const unsigned*)extra;
+        for (int j = tid; j < mc; j += 256) ((unsigned*)extra)[j] = (mb + j < me) ? tap_mask9(p.coords[mb + j], p.g, false) : 0u;
+        ry = make_rsrc(p.y1, (unsigned)p.M * 512u);
+        rz = make_rsrc(p.dz, (unsigned)(p.M - 1) * (unsigned)p.lddz * 4u + 128u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) avoff[i] = (((tid >> 5) + 8 * i) * 128 + c0) * 4;
+        bvoff = ((tid >> 3) * p.lddz + (tid & 7) * 4) * 4;
     }
     __device__ void krange(const Params&, int, int& kb, int& ke) { kb = mb; ke = me; }
-    __device__ float4 a_r4(const Params& p, int cin, int m) const {
-        if (m >= me) return Z4;
-        int d, h, w;
-        unpack_dhw(p.coords[m], d, h, w);
-        if ((unsigned)(d + kd) >= (unsigned)p.g.D || (unsigned)(h + kh) >= (unsigned)p.g.H ||
-            (unsigned)(w + kw) >= (unsigned)p.g.W)
-            return Z4;
-        const int src = m + (kd * p.g.H + kh) * p.g.W + kw;
-        const float4 v = *(const float4*)(p.y1 + (size_t)src * 128 + cin);
-        float4 r;
-        r.x = fmaxf(bn_apply(v.x, mean[cin], sc[cin], beta[cin]), 0.f);
-        r.y = fmaxf(bn_apply(v.y, mean[cin + 1], sc[cin + 1], beta[cin + 1]), 0.f);
-        r.z = fmaxf(bn_apply(v.z, mean[cin + 2], sc[cin + 2], beta[cin + 2]), 0.f);
-        r.w = fmaxf(bn_apply(v.w, mean[cin + 3], sc[cin + 3], beta[cin + 3]), 0.f);
-        return r;
+    __device__ void step(const Params& p, int k0) { k0s = k0; asoff = k0 * 512; bsoff = k0 * p.lddz * 4; }
+    __device__ float4 a_ld(const Params&, int i, int, int, bool& ok) const {      // A(row = cin.., k = voxel m)
+        const unsigned mk = vm[k0s - mb + (threadIdx.x >> 5 & 7) + 8 * i];
+        ok = (mk & sel) == sel;
+        // the voffset operand must stay non-negative on its own (offsets are unsigned, the range check sees the
+        // un-wrapped sum), so the tile offset is added in the VALU rather than passed as soffset
+        return buf_load4(ry, avoff[i] + asoff + (ok ? tapoff_b : 0), 0);     // rows >= M: hardware range check -> 0
     }
-    __device__ float4 b_r4(const Params& p, int co, int m) const {
-        if (m >= me) return Z4;
-        return *(const float4*)(p.dz + (size_t)m * p.lddz + co);
+    __device__ float4 a_tx(const Params&, int, const float4& v, int, int, bool ok) const {   // branch-free
+        const float z = ok ? 1.f : 0.f;
+        return make_float4(z * fmaxf(bn_apply(v.x, mean[0], sc[0], beta[0]), 0.f), z * fmaxf(bn_apply(v.y, mean[1], sc[1], beta[1]), 0.f),
+                           z * fmaxf(bn_apply(v.z, mean[2], sc[2], beta[2]), 0.f), z * fmaxf(bn_apply(v.w, mean[3], sc[3], beta[3]), 0.f));
     }
-    __device__ float4 a_k4(const Params&, int, int) const { return Z4; }
-    __device__ float4 b_k4(const Params&, int, int) const { return Z4; }
-    __device__ float a_k1(const Params&, int, int) const { return 0; }
-    __device__ float b_k1(const Params&, int, int) const { return 0; }
-    __device__ void epilogue(const Params& p, int, int, int, const float* Cs, int tid) {
-        if (mb >= me) return;
+    __device__ float4 b_ld(const Params&, int, int, int m, bool& ok) const {      // B(col = cout.., k = voxel m)
+        ok = m < me;
+        return buf_load4(rz, bvoff, bsoff);
+    }
+    __device__ float4 b_tx(const Params&, int, const float4& v, int, int, bool ok) const {
+        const float z = ok ? 1.f : 0.f;
+        return make_float4(z * v.x, z * v.y, z * v.z, z * v.w);
+    }
+    __device__ void epilogue(const Params& p, int, int, int, const float* Cs, int tid, bool active) {
+        if (mb >= me || !active) return;
         for (int idx = tid; idx < TM * TN; idx += 256) {
             const int cin = idx & 127, co = idx >> 7;
             atomicAdd(&p.dw[((size_t)co * 128 + cin) * 27 + tap], Cs[cin * (TN + 1) + co]);
@@ -139,6 +173,7 @@ struct Conv3BwdWOp {
 extern "C" int mms_conv3_bwd_weight(const Conv3BwdWP* pp, hipStream_t s) {
     const Conv3BwdWP& p = *pp;
     if (p.M <= 0 || p.msplit <= 0 || p.lddz % 4 != 0) return MMS_ERR_ARG;
+    if ((((p.M + p.msplit - 1) / p.msplit + 31) & ~31) > 1024) return MMS_ERR_ARG;    // row chunk must fit the LDS mask table
     return launch_tile_gemm<Conv3BwdWOp>(p, dim3(1, 1, 27 * p.msplit), s);
 }
 
@@ -175,6 +210,8 @@ template <int WM_, int WN_, int WK_, bool POOL>
 struct Conv1BwdDataOp {
     typedef Conv1BwdP Params;
     static constexpr int WM = WM_, WN = WN_, WK = WK_, AMODE = LD_K4, BMODE = LD_R4;
+    static constexpr bool SPEC = false;
+    __device__ void step(const Params&, int) {}
     static constexpr int TM = 32 * WM, TN = 32 * WN;
     // dy consts for all N (<=512 without bn_out, 128 with), bn_in consts for TN columns, srcbase[TM], fp64 scratch
     static constexpr int EXTRA = 5 * 128 + 4 * TN + TM + 1024;   // + fp64 [256/TN][2][TN] reduction scratch
@@ -204,27 +241,31 @@ struct Conv1BwdDataOp {
         }
     }
     __device__ void krange(const Params& p, int, int& kb, int& ke) { kb = 0; ke = p.N; }
-    __device__ float4 a_k4(const Params& p, int m, int n) const {   // A(m, n) = dy[m][n..n+3]
-        if (m >= p.M || n >= p.N) return Z4;
-        const float4 g = *(const float4*)(p.dyraw + (size_t)m * p.lddy + n);
-        if (!p.has_bn_out) return g;
-        const float4 y = *(const float4*)(p.y + (size_t)m * p.ldy + n);
-        return make_float4(dc.dy(p, g.x, y.x, n), dc.dy(p, g.y, y.y, n + 1), dc.dy(p, g.z, y.z, n + 2), dc.dy(p, g.w, y.w, n + 3));
+    struct ARaw { float4 g, y; };
+    typedef float4 BRaw;
+    __device__ ARaw a_ld(const Params& p, int, int m, int n, bool& ok) const {   // A(m, n) = dy[m][n..n+3]
+        ARaw r; r.g = Z4; r.y = Z4;
+        ok = m < p.M && n < p.N;
+        if (!ok) return r;
+        r.g = *(const float4*)(p.dyraw + (size_t)m * p.lddy + n);
+        if (p.has_bn_out) r.y = *(const float4*)(p.y + (size_t)m * p.ldy + n);
+        return r;
     }
-    __device__ float4 b_r4(const Params& p, int k, int n) const {   // B(col k..k+3, n) = W[n][k..k+3]
-        if (n >= p.N || k >= p.K) return Z4;
-        return *(const float4*)(p.w + (size_t)n * p.K + k);
+    __device__ float4 a_tx(const Params& p, int, const ARaw& r, int, int n, bool ok) const {
+        if (!ok || !p.has_bn_out) return r.g;
+        return make_float4(dc.dy(p, r.g.x, r.y.x, n), dc.dy(p, r.g.y, r.y.y, n + 1), dc.dy(p, r.g.z, r.y.z, n + 2), dc.dy(p, r.g.w, r.y.w, n + 3));
     }
-    __device__ float4 a_r4(const Params&, int, int) const { return Z4; }
-    __device__ float4 b_k4(const Params&, int, int) const { return Z4; }
-    __device__ float a_k1(const Params&, int, int) const { return 0; }
-    __device__ float b_k1(const Params&, int, int) const { return 0; }
-    __device__ void epilogue(const Params& p, int m0_, int n0, int, const float* Cs, int tid) {
+    __device__ float4 b_ld(const Params& p, int, int k, int n, bool& ok) const {   // B(col k..k+3, n) = W[n][k..k+3]
+        ok = n < p.N && k < p.K;
+        return ok ? *(const float4*)(p.w + (size_t)n * p.K + k) : Z4;
+    }
+    __device__ float4 b_tx(const Params&, int, const float4& v, int, int, bool) const { return v; }
+    __device__ void epilogue(const Params& p, int m0_, int n0, int, const float* Cs, int tid, bool active) {
         constexpr int RG = 256 / TN;              // row groups
         const int c = tid % TN, rg = tid / TN, k = n0 + c;
         const float mu = ein[c], rs = ein[TN + c], ga = ein[2 * TN + c], be = ein[3 * TN + c];
         double s1 = 0, s2 = 0;
-        const int rows = p.M - m0_ < TM ? p.M - m0_ : TM;
+        const int rows = !active ? 0 : (p.M - m0_ < TM ? p.M - m0_ : TM);
         if (k < p.K) {
             for (int r = rg; r < rows; r += RG) {
                 const float da = Cs[r * (TN + 1) + c];
@@ -249,9 +290,9 @@ struct Conv1BwdDataOp {
             }
         }
         double* red = (double*)(ein + 4 * TN + TM);     // offset (640 + 4TN + TM)*4 bytes: multiple of 8
-        red[(rg * 2 + 0) * TN + c] = s1; red[(rg * 2 + 1) * TN + c] = s2;
+        if (active) { red[(rg * 2 + 0) * TN + c] = s1; red[(rg * 2 + 1) * TN + c] = s2; }
         __syncthreads();
-        if (rg == 0 && k < p.K) {
+        if (rg == 0 && k < p.K && active) {
             double a = 0, b = 0;
             for (int g = 0; g < RG; ++g) { a += red[(g * 2) * TN + c]; b += red[(g * 2 + 1) * TN + c]; }
             atomicAdd(&p.s1[k], a);
@@ -280,6 +321,8 @@ template <bool POOL>
 struct Conv1BwdWOp {
     typedef Conv1BwdP Params;
     static constexpr int WM = 2, WN = 2, WK = 1, AMODE = LD_R4, BMODE = LD_R4;
+    static constexpr bool SPEC = false;
+    __device__ void step(const Params&, int) {}
     static constexpr int TM = 64, TN = 64;
     static constexpr int EXTRA = 5 * 64 + 3 * 64;
     DyConsts dc;
@@ -306,22 +349,30 @@ struct Conv1BwdWOp {
         }
     }
     __device__ void krange(const Params&, int, int& kb, int& ke) { kb = mb; ke = me; }
-    __device__ float4 a_r4(const Params& p, int n, int m) const {   // A(row n..n+3, m) = dy[m][n..n+3]
-        if (m >= me || n >= p.N) return Z4;
-        const float4 g = *(const float4*)(p.dyraw + (size_t)m * p.lddy + n);
-        if (!p.has_bn_out) return g;
-        const float4 y = *(const float4*)(p.y + (size_t)m * p.ldy + n);
+    struct ARaw { float4 g, y; };
+    typedef float4 BRaw;
+    __device__ ARaw a_ld(const Params& p, int, int n, int m, bool& ok) const {   // A(row n..n+3, m) = dy[m][n..n+3]
+        ARaw r; r.g = Z4; r.y = Z4;
+        ok = m < me && n < p.N;
+        if (!ok) return r;
+        r.g = *(const float4*)(p.dyraw + (size_t)m * p.lddy + n);
+        if (p.has_bn_out) r.y = *(const float4*)(p.y + (size_t)m * p.ldy + n);
+        return r;
+    }
+    __device__ float4 a_tx(const Params& p, int, const ARaw& r, int n, int, bool ok) const {
+        if (!ok || !p.has_bn_out) return r.g;
         const int i = n - n0r;
-        return make_float4(dc.dy(p, g.x, y.x, i), dc.dy(p, g.y, y.y, i + 1), dc.dy(p, g.z, y.z, i + 2), dc.dy(p, g.w, y.w, i + 3));
+        return make_float4(dc.dy(p, r.g.x, r.y.x, i), dc.dy(p, r.g.y, r.y.y, i + 1), dc.dy(p, r.g.z, r.y.z, i + 2), dc.dy(p, r.g.w, r.y.w, i + 3));
     }
     __device__ float4 act4(const float4 v, int i) const {
         return make_float4(fmaxf(bn_apply(v.x, mean[i], sc[i], beta[i]), 0.f), fmaxf(bn_apply(v.y, mean[i + 1], sc[i + 1], beta[i + 1]), 0.f),
                            fmaxf(bn_apply(v.z, mean[i + 2], sc[i + 2], beta[i + 2]), 0.f), fmaxf(bn_apply(v.w, mean[i + 3], sc[i + 3], beta[i + 3]), 0.f));
     }
-    __device__ float4 b_r4(const Params& p, int k, int m) const {   // B(col k..k+3, m) = a[m][k..k+3]
-        if (m >= me || k >= p.K) return Z4;
+    __device__ float4 b_ld(const Params& p, int, int k, int m, bool& ok) const {   // B(col k..k+3, m) = a[m][k..k+3]
+        ok = m < me && k < p.K;
+        if (!ok) return Z4;
+        if (!POOL) return *(const float4*)(p.x + (size_t)m * p.ldx + k);
         const int i = k - k0c;
-        if (!POOL) return act4(*(const float4*)(p.x + (size_t)m * p.ldx + k), i);
         const int D2 = p.in.D >> 1, H2 = p.in.H >> 1, W2 = p.in.W >> 1, vox2 = D2 * H2 * W2;
         const int b = m / vox2, r = m % vox2, d = r / (H2 * W2), h = (r / W2) % H2, w = r % W2;
         const int base = ((b * p.in.D + 2 * d) * p.in.H + 2 * h) * p.in.W + 2 * w, HW = p.in.H * p.in.W, W = p.in.W;
@@ -334,12 +385,12 @@ struct Conv1BwdWOp {
         }
         return make_float4(s.x * 0.125f, s.y * 0.125f, s.z * 0.125f, s.w * 0.125f);
     }
-    __device__ float4 a_k4(const Params&, int, int) const { return Z4; }
-    __device__ float4 b_k4(const Params&, int, int) const { return Z4; }
-    __device__ float a_k1(const Params&, int, int) const { return 0; }
-    __device__ float b_k1(const Params&, int, int) const { return 0; }
-    __device__ void epilogue(const Params& p, int, int, int, const float* Cs, int tid) {
-        if (mb >= me) return;
+    __device__ float4 b_tx(const Params&, int, const float4& v, int k, int, bool ok) const {
+        if (POOL || !ok) return v;
+        return act4(v, k - k0c);
+    }
+    __device__ void epilogue(const Params& p, int, int, int, const float* Cs, int tid, bool active) {
+        if (mb >= me || !active) return;
         for (int idx = tid; idx < TM * TN; idx += 256) {
             const int r = idx / TN, c = idx % TN, n = n0r + r, k = k0c + c;
             if (n < p.N && k < p.K) atomicAdd(&p.dw[(size_t)n * p.K + k], Cs[r * (TN + 1) + c]);
@@ -513,6 +564,8 @@ extern "C" int mms_pool_bwd(const PoolBwdP* pp, hipStream_t s) {
 struct Conv0BwdWOp {
     typedef Conv0BwdWP Params;
     static constexpr int WM = 2, WN = 2, WK = 1, AMODE = LD_K1, BMODE = LD_R4;
+    static constexpr bool SPEC = false;
+    __device__ void step(const Params&, int) {}
     static constexpr int TM = 64, TN = 64;
     static constexpr int EXTRA = 5 * 64;
     float *A, *Bc, *Cc, *mean, *rstd;
@@ -538,7 +591,10 @@ struct Conv0BwdWOp {
         me = mb + mc < p.M ? mb + mc : p.M;
     }
     __device__ void krange(const Params&, int, int& kb, int& ke) { kb = mb; ke = me; }
-    __device__ float a_k1(const Params& p, int k, int m) const {    // A(row = tap k, m) = x[patch(m, k)]
+    typedef float ARaw;
+    struct BRaw { float4 g, y; };
+    __device__ float a_ld(const Params& p, int, int k, int m, bool& ok) const {    // A(row = tap k, m) = x[patch(m, k)]
+        ok = true;
         if (k >= 343 || m >= me) return 0.f;
         int od, oh, ow;
         unpack_dhw(p.coords[m], od, oh, ow);
@@ -548,21 +604,24 @@ struct Conv0BwdWOp {
             return 0.f;
         return p.x[((size_t)(b * p.in.D + id) * p.in.H + ih) * p.in.W + iw];
     }
+    __device__ float a_tx(const Params&, int, float v, int, int, bool) const { return v; }
     __device__ __forceinline__ float dy(float g, float y, int n) const {
         return A[n] * (g - Bc[n] - (y - mean[n]) * rstd[n] * Cc[n]);
     }
-    __device__ float4 b_r4(const Params& p, int n, int m) const {   // B(col n..n+3, m) = dy0[m][n..n+3]
-        if (m >= me) return Z4;
-        const float4 g = *(const float4*)(p.dbn + (size_t)m * 64 + n);
-        const float4 y = *(const float4*)(p.y0 + (size_t)m * 64 + n);
-        return make_float4(dy(g.x, y.x, n), dy(g.y, y.y, n + 1), dy(g.z, y.z, n + 2), dy(g.w, y.w, n + 3));
+    __device__ BRaw b_ld(const Params& p, int, int n, int m, bool& ok) const {   // B(col n..n+3, m) = dy0[m][n..n+3]
+        BRaw r; r.g = Z4; r.y = Z4;
+        ok = m < me;
+        if (!ok) return r;
+        r.g = *(const float4*)(p.dbn + (size_t)m * 64 + n);
+        r.y = *(const float4*)(p.y0 + (size_t)m * 64 + n);
+        return r;
     }
-    __device__ float4 a_k4(const Params&, int, int) const { return Z4; }
-    __device__ float4 b_k4(const Params&, int, int) const { return Z4; }
-    __device__ float4 a_r4(const Params&, int, int) const { return Z4; }
-    __device__ float b_k1(const Params&, int, int) const { return 0; }
-    __device__ void epilogue(const Params& p, int, int, int, const float* Cs, int tid) {
-        if (mb >= me) return;
+    __device__ float4 b_tx(const Params&, int, const BRaw& r, int n, int, bool ok) const {
+        if (!ok) return Z4;
+        return make_float4(dy(r.g.x, r.y.x, n), dy(r.g.y, r.y.y, n + 1), dy(r.g.z, r.y.z, n + 2), dy(r.g.w, r.y.w, n + 3));
+    }
+    __device__ void epilogue(const Params& p, int, int, int, const float* Cs, int tid, bool active) {
+        if (mb >= me || !active) return;
         for (int idx = tid; idx < TM * TN; idx += 256) {
             const int r = idx & 63, c = idx >> 6, k = k0r + r;     // r fastest: dW0[n][k] contiguous in k
             if (k < 343) atomicAdd(&p.dw[c * 343 + k], Cs[r * (TN + 1) + c]);

@@ -37,6 +37,8 @@ template <int WM_, int WN_, int WK_, bool POOL>
 struct Conv1FwdOp {
     typedef Conv1FwdP Params;
     static constexpr int WM = WM_, WN = WN_, WK = WK_, AMODE = LD_K4, BMODE = LD_K4;
+    static constexpr bool SPEC = false;
+    __device__ void step(const Params&, int) {}
     static constexpr int TM = 32 * WM, TN = 32 * WN;
     static constexpr int EXTRA = 3 * 1024 + TM;
     const float *mean, *sc, *beta;
@@ -68,9 +70,13 @@ struct Conv1FwdOp {
         r.w = fmaxf(bn_apply(v.w, mean[k + 3], sc[k + 3], beta[k + 3]), 0.f);
         return r;
     }
-    __device__ float4 a_k4(const Params& p, int m, int k) const {
-        if (m >= p.M || k >= p.K) return make_float4(0, 0, 0, 0);
-        if (!POOL) return act4(*(const float4*)(p.x + (size_t)m * p.ldx + k), k);
+    typedef float4 ARaw;
+    typedef float4 BRaw;
+    __device__ float4 a_ld(const Params& p, int, int m, int k, bool& ok) const {
+        ok = m < p.M && k < p.K;
+        if (!ok) return make_float4(0, 0, 0, 0);
+        if (!POOL) return *(const float4*)(p.x + (size_t)m * p.ldx + k);
+        // transition: 8 source voxels per pooled row -- activation applied while loading (6 launches per step)
         const int base = srcbase[m - m0], HW = p.in.H * p.in.W, W = p.in.W;
         float4 s = make_float4(0, 0, 0, 0);
 #pragma unroll
@@ -81,15 +87,17 @@ struct Conv1FwdOp {
         }
         return make_float4(s.x * 0.125f, s.y * 0.125f, s.z * 0.125f, s.w * 0.125f);
     }
-    __device__ float4 b_k4(const Params& p, int n, int k) const {
-        if (n >= p.N || k >= p.K) return make_float4(0, 0, 0, 0);
-        return *(const float4*)(p.w + (size_t)n * p.K + k);
+    __device__ float4 a_tx(const Params&, int, const float4& v, int, int k, bool ok) const {
+        if (POOL || !ok) return v;
+        return act4(v, k);
     }
-    __device__ float4 a_r4(const Params&, int, int) const { return make_float4(0, 0, 0, 0); }
-    __device__ float4 b_r4(const Params&, int, int) const { return make_float4(0, 0, 0, 0); }
-    __device__ float a_k1(const Params&, int, int) const { return 0; }
-    __device__ float b_k1(const Params&, int, int) const { return 0; }
-    __device__ void epilogue(const Params& p, int m0_, int n0, int, const float* Cs, int tid) {
+    __device__ float4 b_ld(const Params& p, int, int n, int k, bool& ok) const {
+        ok = n < p.N && k < p.K;
+        return ok ? *(const float4*)(p.w + (size_t)n * p.K + k) : make_float4(0, 0, 0, 0);
+    }
+    __device__ float4 b_tx(const Params&, int, const float4& v, int, int, bool) const { return v; }
+    __device__ void epilogue(const Params& p, int m0_, int n0, int, const float* Cs, int tid, bool active) {
+        if (!active) return;
         store_tile<TM, TN>(p.y, p.ldy, p.M, p.N, m0_, n0, Cs, tid);
         tile_col_stats<TM, TN>(p.osum, p.osumsq, p.M, p.N, m0_, n0, Cs, tid);
     }
@@ -114,51 +122,78 @@ extern "C" int mms_conv1_fwd(const Conv1FwdP* pp, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------------
 // 3x3x3 conv (pad 1): implicit GEMM, K = (tap, cin) = 27*128, one K-step per tap
 // ------------------------------------------------------------------------------------------------------
+// per-axis tap validity of a voxel, 3 bits per axis (bit t <-> tap offset t-1): [0..2] d, [3..5] h, [6..8] w
+__device__ __forceinline__ unsigned tap_mask9(int c, Dims3 g, bool mirror) {
+    int d, h, w;
+    unpack_dhw(c, d, h, w);
+    const unsigned lo_d = d > 0, hi_d = d + 1 < g.D, lo_h = h > 0, hi_h = h + 1 < g.H, lo_w = w > 0, hi_w = w + 1 < g.W;
+    // forward reads voxel + (t-1): t=0 needs the low neighbour; backward-data reads voxel - (t-1): mirrored
+    const unsigned dm = mirror ? (hi_d | 2u | (lo_d << 2)) : (lo_d | 2u | (hi_d << 2));
+    const unsigned hm = mirror ? (hi_h | 2u | (lo_h << 2)) : (lo_h | 2u | (hi_h << 2));
+    const unsigned wm = mirror ? (hi_w | 2u | (lo_w << 2)) : (lo_w | 2u | (hi_w << 2));
+    return dm | (hm << 3) | (wm << 6);
+}
+
 struct Conv3FwdOp {
     typedef Conv3FwdP Params;
     static constexpr int WM = 1, WN = 1, WK = 4, AMODE = LD_K4, BMODE = LD_K4;
+    static constexpr bool SPEC = false;
     static constexpr int TM = 32, TN = 32;
-    static constexpr int EXTRA = 3 * 128 + 32;
-    const float *mean, *sc, *beta;
-    const int* rowc;
-    int m0;
-    __device__ void setup(const Params& p, int m0_, int, int, float* extra, int tid) {
-        mean = extra; sc = extra + 128; beta = extra + 256; rowc = (const int*)(extra + 384); m0 = m0_;
-        if (tid < 128) {
+    static constexpr int EXTRA = 4;
+    typedef float4 ARaw;
+    typedef float4 BRaw;
+    // TK = 128 = all input channels of one tap: a thread's 4 channels ((tid & 31) * 4 ...) and its 4 tile rows
+    // (tid/32 + 8i) are the same at every K-step.  Everything per-thread is computed once: BatchNorm constants,
+    // byte offsets into y1 / the packed weights, and a 9-bit tap-validity mask per row.  A K-step's loader is then
+    // 8 buffer loads + ~3 VALU each; the per-tap part of every address is wave-uniform (SGPR).
+    float mean[4], sc[4], beta[4];
+    int voff[4], woff[4];
+    unsigned m9[4];
+    buf_rsrc_t ry, rw;
+    int tapoff_b, wsoff;
+    unsigned sel;
+    __device__ void setup(const Params& p, int m0, int, int, float*, int tid) {
+        const int c0 = (tid & 31) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
             float mu, rstd;
-            bn_mean_rstd(p.bn, tid, mu, rstd);
-            extra[tid] = mu; extra[128 + tid] = p.bn.gamma[tid] * rstd; extra[256 + tid] = p.bn.beta[tid];
+            bn_mean_rstd(p.bn, c0 + j, mu, rstd);
+            mean[j] = mu; sc[j] = p.bn.gamma[c0 + j] * rstd; beta[j] = p.bn.beta[c0 + j];
         }
-        if (tid < 32) ((int*)extra)[384 + tid] = (m0 + tid < p.M) ? p.coords[m0 + tid] : -1;
+        ry = make_rsrc(p.y1, (unsigned)p.M * 512u);
+        rw = make_rsrc(p.wp, 32u * 27u * 128u * 4u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (tid >> 5) + 8 * i, m = m0 + row;
+            const bool valid = m < p.M;
+            m9[i] = valid ? tap_mask9(p.coords[valid ? m : m0], p.g, false) : 0u;
+            voff[i] = ((valid ? m : m0) * 128 + c0) * 4;
+            woff[i] = (row * (27 * 128) + c0) * 4;
+        }
     }
     __device__ void krange(const Params&, int, int& kb, int& ke) { kb = 0; ke = 27 * 128; }
-    __device__ float4 a_k4(const Params& p, int m, int k) const {
-        const int c = rowc[m - m0];
-        if (c < 0) return make_float4(0, 0, 0, 0);
-        const int tap = k >> 7, cin = k & 127;
-        const int kd = tap / 9 - 1, kh = (tap / 3) % 3 - 1, kw = tap % 3 - 1;
-        int d, h, w;
-        unpack_dhw(c, d, h, w);
-        if ((unsigned)(d + kd) >= (unsigned)p.g.D || (unsigned)(h + kh) >= (unsigned)p.g.H ||
-            (unsigned)(w + kw) >= (unsigned)p.g.W)
-            return make_float4(0, 0, 0, 0);      // zero padding is applied AFTER bn+relu
-        const int src = m + (kd * p.g.H + kh) * p.g.W + kw;
-        const float4 v = *(const float4*)(p.y1 + (size_t)src * 128 + cin);
-        float4 r;
-        r.x = fmaxf(bn_apply(v.x, mean[cin], sc[cin], beta[cin]), 0.f);
-        r.y = fmaxf(bn_apply(v.y, mean[cin + 1], sc[cin + 1], beta[cin + 1]), 0.f);
-        r.z = fmaxf(bn_apply(v.z, mean[cin + 2], sc[cin + 2], beta[cin + 2]), 0.f);
-        r.w = fmaxf(bn_apply(v.w, mean[cin + 3], sc[cin + 3], beta[cin + 3]), 0.f);
-        return r;
+    __device__ void step(const Params& p, int k0) {
+        const int tap = k0 >> 7, kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        sel = (1u << kd) | (8u << kh) | (64u << kw);
+        tapoff_b = (((kd - 1) * p.g.H + (kh - 1)) * p.g.W + (kw - 1)) * 512;
+        wsoff = k0 * 4;
     }
-    __device__ float4 b_k4(const Params& p, int n, int k) const {
-        return *(const float4*)(p.wp + (size_t)n * (27 * 128) + k);
+    __device__ float4 a_ld(const Params&, int i, int, int, bool& ok) const {
+        ok = (m9[i] & sel) == sel;               // zero padding is applied AFTER bn+relu (a_tx)
+        return buf_load4(ry, voff[i] + (ok ? tapoff_b : 0), 0);
     }
-    __device__ float4 a_r4(const Params&, int, int) const { return make_float4(0, 0, 0, 0); }
-    __device__ float4 b_r4(const Params&, int, int) const { return make_float4(0, 0, 0, 0); }
-    __device__ float a_k1(const Params&, int, int) const { return 0; }
-    __device__ float b_k1(const Params&, int, int) const { return 0; }
-    __device__ void epilogue(const Params& p, int m0_, int n0, int, const float* Cs, int tid) {
+    __device__ float4 a_tx(const Params&, int, const float4& v, int, int, bool ok) const {   // branch-free
+        const float z = ok ? 1.f : 0.f;   // relu output * {0,1}: exact
+        return make_float4(z * fmaxf(bn_apply(v.x, mean[0], sc[0], beta[0]), 0.f), z * fmaxf(bn_apply(v.y, mean[1], sc[1], beta[1]), 0.f),
+                           z * fmaxf(bn_apply(v.z, mean[2], sc[2], beta[2]), 0.f), z * fmaxf(bn_apply(v.w, mean[3], sc[3], beta[3]), 0.f));
+    }
+    __device__ float4 b_ld(const Params&, int i, int, int, bool& ok) const {
+        ok = true;
+        return buf_load4(rw, woff[i], wsoff);
+    }
+    __device__ float4 b_tx(const Params&, int, const float4& v, int, int, bool) const { return v; }
+    __device__ void epilogue(const Params& p, int m0_, int n0, int, const float* Cs, int tid, bool active) {
+        if (!active) return;
         store_tile<TM, TN>(p.out, p.ldo, p.M, 32, m0_, n0, Cs, tid);
         tile_col_stats<TM, TN>(p.osum, p.osumsq, p.M, 32, m0_, n0, Cs, tid);
     }
@@ -176,6 +211,8 @@ extern "C" int mms_conv3_fwd(const Conv3FwdP* pp, hipStream_t s) {
 struct Conv0FwdOp {
     typedef Conv0FwdP Params;
     static constexpr int WM = 2, WN = 2, WK = 1, AMODE = LD_K1, BMODE = LD_K1;
+    static constexpr bool SPEC = false;
+    __device__ void step(const Params&, int) {}
     static constexpr int TM = 64, TN = 64;
     static constexpr int EXTRA = 4 * 64;
     const int* info;   // per tile row: sample offset, id0, ih0, iw0
@@ -196,7 +233,10 @@ struct Conv0FwdOp {
         }
     }
     __device__ void krange(const Params&, int, int& kb, int& ke) { kb = 0; ke = 343; }
-    __device__ float a_k1(const Params& p, int m, int k) const {
+    typedef float ARaw;
+    typedef float BRaw;
+    __device__ float a_ld(const Params& p, int, int m, int k, bool& ok) const {
+        ok = true;
         if (k >= 343) return 0.f;
         const int* o = info + 4 * (m - m0);
         if (o[0] < 0) return 0.f;
@@ -206,12 +246,11 @@ struct Conv0FwdOp {
             return 0.f;
         return p.x[(size_t)o[0] + ((size_t)id * p.in.H + ih) * p.in.W + iw];
     }
-    __device__ float b_k1(const Params& p, int n, int k) const { return k < 343 ? p.w[n * 343 + k] : 0.f; }
-    __device__ float4 a_k4(const Params&, int, int) const { return make_float4(0, 0, 0, 0); }
-    __device__ float4 b_k4(const Params&, int, int) const { return make_float4(0, 0, 0, 0); }
-    __device__ float4 a_r4(const Params&, int, int) const { return make_float4(0, 0, 0, 0); }
-    __device__ float4 b_r4(const Params&, int, int) const { return make_float4(0, 0, 0, 0); }
-    __device__ void epilogue(const Params& p, int m0_, int n0, int, const float* Cs, int tid) {
+    __device__ float a_tx(const Params&, int, float v, int, int, bool) const { return v; }
+    __device__ float b_ld(const Params& p, int, int n, int k, bool& ok) const { ok = true; return k < 343 ? p.w[n * 343 + k] : 0.f; }
+    __device__ float b_tx(const Params&, int, float v, int, int, bool) const { return v; }
+    __device__ void epilogue(const Params& p, int m0_, int n0, int, const float* Cs, int tid, bool active) {
+        if (!active) return;
         store_tile<TM, TN>(p.y, 64, p.M, 64, m0_, n0, Cs, tid);
         tile_col_stats<TM, TN>(p.osum, p.osumsq, p.M, 64, m0_, n0, Cs, tid);
     }

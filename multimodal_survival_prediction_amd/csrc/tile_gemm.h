@@ -8,8 +8,9 @@
 // gather (conv taps, pooling windows) and transform (BatchNorm+ReLU prologues, BN-backward) on the way
 // from HBM/L2 to LDS -- so the fused ops of the hot path are all instances of this one core.
 //
-// LDS images: As[2][TM][TK+4], Bs[2][TN][TK+4] floats (row pitch = TK+4 dwords keeps 16-B alignment for
-// ds_read_b128 and makes the 16-lane read groups conflict-free: pitch mod 64 dwords = 4*odd or 36).
+// LDS images (K4/K1 loaders): As[2][TM][TK+4], Bs[2][TN][TK+4] floats (row pitch = TK+4 dwords keeps 16-B
+// alignment for ds_read_b128 and makes the 16-lane read groups conflict-free); R4 loaders: k-major images, see
+// TileGemmCfg.
 // MFMA operand map (cdna_hip_programming.md section 3): lane l holds A[i=l&31][k=l>>5], B[k=l>>5][j=l&31];
 // one ds_read_b128 per operand feeds 4 MFMAs: element e of lane (i,h) is k = kk + 4h + e for both
 // operands, so MFMA e sums k in {kk+e, kk+4+e}.  C/D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5).
@@ -20,38 +21,57 @@
 //                2 = K1 (scalar, arbitrary alignment)
 //   __device__ void setup(const Params&, int m0, int n0, int z, float* extra, int tid);   (barrier follows)
 //   __device__ void krange(const Params&, int z, int& kb, int& ke);
-//   __device__ float4 a_k4 / a_r4 (const Params&, int m, int k);  float a_k1(...);   zero-fill out of range
-//   __device__ float4 b_k4 / b_r4 (const Params&, int n, int k);  float b_k1(...);
-//   __device__ void epilogue(const Params&, int m0, int n0, int z, const float* Cs /*[TM][TN+1]*/, int tid);
+//   typedef ARaw, BRaw: what one loader call leaves in registers (raw global data, no dependent math);
+//   __device__ void step(const Params&, int k0);   once per tile, wave-uniform k0: scalar per-tile state
+//   __device__ ARaw a_ld(const Params&, int i, int m, int k, bool& ok);   issue the global load(s) only; i = the
+//       thread's piece index (ops may keep per-piece state -- byte offsets, validity masks -- in registers)
+//   __device__ float4|float a_tx(const Params&, int i, const ARaw&, int m, int k, bool ok);   transform -> LDS value
+//   (same for b_ld / b_tx with n instead of m).  The core issues every *_ld of tile t+1 BEFORE the MFMAs of
+//   tile t and runs *_tx after them, at LDS-store time, so HBM/L2 latency hides under the matrix phase.
+//   __device__ void epilogue(const Params&, int m0, int n0, int z, const float* Cs /*[TM][TN+1]*/, int tid, bool active);
+//   (active = false for the producer half in SPEC mode: take part in barriers only)
 #pragma once
 #include "common.h"
 
 enum { LD_K4 = 0, LD_R4 = 1, LD_K1 = 2 };
 
+// LDS image of one operand tile: K4/K1 loaders -> [row][TK+4] (read with ds_read_b128);
+// R4 loaders (source contiguous along the row index) -> k-major [TK][rows+4]: written with conflict-free
+// ds_write_b128 along the rows, read with one ds_read_b32 per MFMA operand (32 consecutive dwords per half-wave).
 template <class Op>
 struct TileGemmCfg {
-    static constexpr int TM = 32 * Op::WM, TN = 32 * Op::WN, TK = 32 * Op::WK, PITCH = TK + 4;
-    static constexpr size_t smem_bytes() {
-        size_t tiles = (size_t)2 * (TM + TN) * PITCH;
+    static constexpr int TM = 32 * Op::WM, TN = 32 * Op::WN, TK = 32 * Op::WK;
+    static constexpr int APITCH = Op::AMODE == 1 ? TM + 4 : TK + 4, BPITCH = Op::BMODE == 1 ? TN + 4 : TK + 4;
+    static constexpr int ATILE = Op::AMODE == 1 ? TK * APITCH : TM * APITCH;
+    static constexpr int BTILE = Op::BMODE == 1 ? TK * BPITCH : TN * BPITCH;
+    static constexpr size_t main_floats() {
+        size_t tiles = (size_t)2 * (ATILE + BTILE);
         size_t cs = (size_t)TM * (TN + 1);
-        return ((tiles > cs ? tiles : cs) + Op::EXTRA) * sizeof(float);
+        return tiles > cs ? tiles : cs;
     }
+    static constexpr size_t smem_bytes() { return (main_floats() + Op::EXTRA) * sizeof(float); }
 };
 
+// Op::SPEC = true: wave-specialised variant, 512 threads.  Waves 0-3 ("consumers") only read LDS and issue MFMAs;
+// waves 4-7 ("producers") only run the loaders, transforms and LDS stores.  Each SIMD then hosts one consumer and
+// one producer wave, so the dependent-MFMA issue gaps (64 cycles each) are filled by the other wave's VALU/VMEM work
+// instead of idling -- measured on the conv3 forward: MFMA-chain stalls, loader issue and memory waits each took
+// about a third of a one-wave-per-SIMD kernel's time, serialised.
 template <class Op>
-__global__ __launch_bounds__(256) void tile_gemm_kernel(const typename Op::Params p) {
+__global__ __launch_bounds__(Op::SPEC ? 512 : 256) void tile_gemm_kernel(const typename Op::Params p) {
     constexpr int WM = Op::WM, WN = Op::WN, WK = Op::WK;
     static_assert(WM * WN * WK == 4, "4 waves per workgroup");
-    constexpr int TM = 32 * WM, TN = 32 * WN, TK = 32 * WK, PITCH = TK + 4;
-    constexpr size_t TILE_FLOATS = (size_t)2 * (TM + TN) * PITCH;
-    constexpr size_t CS_FLOATS = (size_t)TM * (TN + 1);
-    constexpr size_t MAIN_FLOATS = TILE_FLOATS > CS_FLOATS ? TILE_FLOATS : CS_FLOATS;
+    typedef TileGemmCfg<Op> Cfg;
+    constexpr int TM = Cfg::TM, TN = Cfg::TN, TK = Cfg::TK;
+    constexpr int APITCH = Cfg::APITCH, BPITCH = Cfg::BPITCH, ATILE = Cfg::ATILE, BTILE = Cfg::BTILE;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
-    float* Bs = smem + 2 * TM * PITCH;
-    float* extra = smem + MAIN_FLOATS;
+    float* Bs = smem + 2 * ATILE;
+    float* extra = smem + Cfg::main_floats();
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const bool producer = Op::SPEC ? threadIdx.x >= 256 : true;
+    const bool consumer = Op::SPEC ? threadIdx.x < 256 : true;
     const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
     const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN, z = blockIdx.z;
 
@@ -63,93 +83,69 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(const typename Op::Param
 
     constexpr int NA = (Op::AMODE == LD_K1) ? TM * TK / 256 : TM * TK / 4 / 256;
     constexpr int NB = (Op::BMODE == LD_K1) ? TN * TK / 256 : TN * TK / 4 / 256;
-    float4 ra[Op::AMODE == LD_K1 ? 1 : NA];
-    float4 rb[Op::BMODE == LD_K1 ? 1 : NB];
-    float sa[Op::AMODE == LD_K1 ? NA : 1];
-    float sb[Op::BMODE == LD_K1 ? NB : 1];
+    struct RegSet {                 // one tile's worth of raw operand data held by a loader thread
+        typename Op::ARaw ra[NA];
+        typename Op::BRaw rb[NB];
+        unsigned oka, okb;
+        int kcur;
+    };
+    RegSet R0, R1;
 
-    auto gload = [&](int k0) {
-        if constexpr (Op::AMODE == LD_K4) {
+    // thread -> (row, k) of its i-th piece of the A / B tile
+    auto a_pos = [&](int i, int& row, int& k) {
+        const int idx = tid + i * 256;
+        if constexpr (Op::AMODE == LD_K4) { row = idx / (TK / 4); k = (idx % (TK / 4)) * 4; }
+        else if constexpr (Op::AMODE == LD_R4) { row = (idx % (TM / 4)) * 4; k = idx / (TM / 4); }
+        else { row = idx / TK; k = idx % TK; }
+    };
+    auto b_pos = [&](int i, int& row, int& k) {
+        const int idx = tid + i * 256;
+        if constexpr (Op::BMODE == LD_K4) { row = idx / (TK / 4); k = (idx % (TK / 4)) * 4; }
+        else if constexpr (Op::BMODE == LD_R4) { row = (idx % (TN / 4)) * 4; k = idx / (TN / 4); }
+        else { row = idx / TK; k = idx % TK; }
+    };
+    auto gload = [&](RegSet& R, int k0) {
+        R.kcur = k0; R.oka = 0; R.okb = 0;
+#ifdef MMS_ABLATE_GLOAD
+        return;
+#endif
+        op.step(p, k0);                      // wave-uniform per-tile state (tap offsets, scalar load offsets)
 #pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                int idx = tid + i * 256, row = idx / (TK / 4), kq = (idx % (TK / 4)) * 4;
-                ra[i] = op.a_k4(p, m0 + row, k0 + kq);
-            }
-        } else if constexpr (Op::AMODE == LD_R4) {
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                int idx = tid + i * 256, r4 = (idx % (TM / 4)) * 4, k = idx / (TM / 4);
-                ra[i] = op.a_r4(p, m0 + r4, k0 + k);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                int idx = tid + i * 256, row = idx / TK, k = idx % TK;
-                sa[i] = op.a_k1(p, m0 + row, k0 + k);
-            }
+        for (int i = 0; i < NA; ++i) {
+            int row, k; a_pos(i, row, k);
+            bool ok;
+            R.ra[i] = op.a_ld(p, i, m0 + row, k0 + k, ok);
+            R.oka |= (ok ? 1u : 0u) << i;
         }
-        if constexpr (Op::BMODE == LD_K4) {
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                int idx = tid + i * 256, row = idx / (TK / 4), kq = (idx % (TK / 4)) * 4;
-                rb[i] = op.b_k4(p, n0 + row, k0 + kq);
-            }
-        } else if constexpr (Op::BMODE == LD_R4) {
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                int idx = tid + i * 256, r4 = (idx % (TN / 4)) * 4, k = idx / (TN / 4);
-                rb[i] = op.b_r4(p, n0 + r4, k0 + k);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                int idx = tid + i * 256, row = idx / TK, k = idx % TK;
-                sb[i] = op.b_k1(p, n0 + row, k0 + k);
-            }
+        for (int i = 0; i < NB; ++i) {
+            int row, k; b_pos(i, row, k);
+            bool ok;
+            R.rb[i] = op.b_ld(p, i, n0 + row, k0 + k, ok);
+            R.okb |= (ok ? 1u : 0u) << i;
         }
     };
-    auto sstore = [&](int buf) {
-        float* a = As + buf * TM * PITCH;
-        float* b = Bs + buf * TN * PITCH;
-        if constexpr (Op::AMODE == LD_K4) {
+    auto sstore = [&](const RegSet& R, int buf) {
+#ifdef MMS_ABLATE_SSTORE
+        return;
+#endif
+        float* a = As + buf * ATILE;
+        float* b = Bs + buf * BTILE;
 #pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                int idx = tid + i * 256, row = idx / (TK / 4), kq = (idx % (TK / 4)) * 4;
-                *(float4*)&a[row * PITCH + kq] = ra[i];
-            }
-        } else if constexpr (Op::AMODE == LD_R4) {
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                int idx = tid + i * 256, r4 = (idx % (TM / 4)) * 4, k = idx / (TM / 4);
-                a[(r4 + 0) * PITCH + k] = ra[i].x; a[(r4 + 1) * PITCH + k] = ra[i].y;
-                a[(r4 + 2) * PITCH + k] = ra[i].z; a[(r4 + 3) * PITCH + k] = ra[i].w;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                int idx = tid + i * 256, row = idx / TK, k = idx % TK;
-                a[row * PITCH + k] = sa[i];
-            }
+        for (int i = 0; i < NA; ++i) {
+            int row, k; a_pos(i, row, k);
+            const auto v = op.a_tx(p, i, R.ra[i], m0 + row, R.kcur + k, (R.oka >> i) & 1u);
+            if constexpr (Op::AMODE == LD_K4) { *(float4*)&a[row * APITCH + k] = v; }
+            else if constexpr (Op::AMODE == LD_R4) { *(float4*)&a[k * APITCH + row] = v; }
+            else { a[row * APITCH + k] = v; }
         }
-        if constexpr (Op::BMODE == LD_K4) {
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                int idx = tid + i * 256, row = idx / (TK / 4), kq = (idx % (TK / 4)) * 4;
-                *(float4*)&b[row * PITCH + kq] = rb[i];
-            }
-        } else if constexpr (Op::BMODE == LD_R4) {
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                int idx = tid + i * 256, r4 = (idx % (TN / 4)) * 4, k = idx / (TN / 4);
-                b[(r4 + 0) * PITCH + k] = rb[i].x; b[(r4 + 1) * PITCH + k] = rb[i].y;
-                b[(r4 + 2) * PITCH + k] = rb[i].z; b[(r4 + 3) * PITCH + k] = rb[i].w;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                int idx = tid + i * 256, row = idx / TK, k = idx % TK;
-                b[row * PITCH + k] = sb[i];
-            }
+        for (int i = 0; i < NB; ++i) {
+            int row, k; b_pos(i, row, k);
+            const auto v = op.b_tx(p, i, R.rb[i], n0 + row, R.kcur + k, (R.okb >> i) & 1u);
+            if constexpr (Op::BMODE == LD_K4) { *(float4*)&b[row * BPITCH + k] = v; }
+            else if constexpr (Op::BMODE == LD_R4) { *(float4*)&b[k * BPITCH + row] = v; }
+            else { b[row * BPITCH + k] = v; }
         }
     };
 
@@ -157,28 +153,75 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(const typename Op::Param
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 
-    if (kb < ke) {
-        gload(kb);
-        sstore(0);
-        __syncthreads();
-        int buf = 0;
-        for (int k0 = kb; k0 < ke; k0 += TK) {
-            const bool more = (k0 + TK) < ke;
-            if (more) gload(k0 + TK);
-            const float* ap = As + (buf * TM + wm * 32 + (lane & 31)) * PITCH + wk * 32 + 4 * (lane >> 5);
-            const float* bp = Bs + (buf * TN + wn * 32 + (lane & 31)) * PITCH + wk * 32 + 4 * (lane >> 5);
+    auto mma = [&](int buf) {
+#ifdef MMS_ABLATE_MMA
+        return;
+#endif
+        const float* at = As + buf * ATILE;
+        const float* bt = Bs + buf * BTILE;
+        const int li = lane & 31, kh = wk * 32 + 4 * (lane >> 5);
 #pragma unroll
-            for (int kk = 0; kk < 32; kk += 8) {
-                const float4 a = *(const float4*)(ap + kk);
-                const float4 b = *(const float4*)(bp + kk);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        for (int kk = 0; kk < 32; kk += 8) {
+            float4 a, b;
+            if constexpr (Op::AMODE == LD_R4) {
+                const float* q = at + (kh + kk) * APITCH + wm * 32 + li;
+                a = make_float4(q[0], q[APITCH], q[2 * APITCH], q[3 * APITCH]);
+            } else {
+                a = *(const float4*)(at + (wm * 32 + li) * APITCH + kh + kk);
             }
-            if (more) sstore(buf ^ 1);
+            if constexpr (Op::BMODE == LD_R4) {
+                const float* q = bt + (kh + kk) * BPITCH + wn * 32 + li;
+                b = make_float4(q[0], q[BPITCH], q[2 * BPITCH], q[3 * BPITCH]);
+            } else {
+                b = *(const float4*)(bt + (wn * 32 + li) * BPITCH + kh + kk);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        }
+    };
+
+    if (kb < ke) {
+        if constexpr (Op::SPEC) {
+            // producers run two tiles ahead: the loads of tile t+2 are in flight while tile t+1 is transformed and
+            // stored (vmcnt retires in order, so waiting for the older register set leaves the newer loads pending)
+            if (producer) {
+                gload(R0, kb);
+                if (kb + TK < ke) gload(R1, kb + TK);
+                sstore(R0, 0);
+            }
             __syncthreads();
-            buf ^= 1;
+            int buf = 0;
+            for (int k0 = kb; k0 + TK < ke; k0 += 2 * TK) {
+                // tile k0 is in LDS[buf]; R1 holds tile k0+TK
+                if (producer) { if (k0 + 2 * TK < ke) gload(R0, k0 + 2 * TK); sstore(R1, buf ^ 1); }
+                else mma(buf);
+                __syncthreads();
+                buf ^= 1;
+                if (k0 + 2 * TK >= ke) break;
+                // tile k0+TK is in LDS[buf]; R0 holds tile k0+2TK
+                if (producer) { if (k0 + 3 * TK < ke) gload(R1, k0 + 3 * TK); sstore(R0, buf ^ 1); }
+                else mma(buf);
+                __syncthreads();
+                buf ^= 1;
+            }
+            if (consumer) mma(buf);
+            __syncthreads();
+        } else {
+            gload(R0, kb);
+            sstore(R0, 0);
+            __syncthreads();
+            int buf = 0;
+            for (int k0 = kb; k0 + TK < ke; k0 += TK) {
+                gload(R0, k0 + TK);
+                mma(buf);
+                sstore(R0, buf ^ 1);
+                __syncthreads();
+                buf ^= 1;
+            }
+            mma(buf);            // last tile: nothing left to prefetch
+            __syncthreads();
         }
     }
 
@@ -187,7 +230,7 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(const typename Op::Param
     const int crow = wm * 32 + 4 * (lane >> 5), ccol = wn * 32 + (lane & 31);
 #pragma unroll
     for (int w = 0; w < WK; ++w) {
-        if (wk == w) {
+        if (wk == w && consumer) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float* c = &Cs[(crow + (r & 3) + 8 * (r >> 2)) * (TN + 1) + ccol];
@@ -196,7 +239,8 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(const typename Op::Param
         }
         __syncthreads();
     }
-    op.epilogue(p, m0, n0, z, Cs, tid);
+    // epilogues are written for 256 threads (tid 0..255); in SPEC mode the producer half only joins their barriers
+    op.epilogue(p, m0, n0, z, Cs, tid, consumer);
 }
 
 template <class Op>
@@ -208,6 +252,6 @@ static inline int launch_tile_gemm(const typename Op::Params& p, dim3 grid, hipS
         attr_set = true;
     }
     if (grid.x == 0 || grid.y == 0 || grid.z == 0) return MMS_OK;
-    MMS_LAUNCH(tile_gemm_kernel<Op>, grid, dim3(256), smem, s, p);
+    MMS_LAUNCH(tile_gemm_kernel<Op>, grid, dim3(Op::SPEC ? 512 : 256), smem, s, p);
     return mms_check_launch();
 }

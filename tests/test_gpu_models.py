@@ -159,4 +159,4 @@ def test_fused_graph_step_matches_reference_loop_body(cls):
         if "num_batches" in k:
             assert int(b) == int(c), k
         else:   # second forward ran on weights that already differ by the (noise-gradient) Adam updates above
-            assert_close(c, b, 5e-4, k)
+            assert_close(c, b, 2e-3, k)
