@@ -36,8 +36,9 @@ def make_cohort(n=109, dims=(64, 64, 32), rna_dim=5005, seed=608, complete=True,
     rng = np.random.default_rng(seed)
     rna = rng.normal(0, 1, (n, rna_dim)).astype(np.float32)
     age = np.clip(rng.normal(60, 11, n), 30, 90).astype(np.float32)
-    w = rng.normal(0, 0.5, 16).astype(np.float32)
-    risk = rna[:, :16] @ w if signal else np.zeros(n, np.float32)
+    ns = min(16, rna_dim)
+    w = rng.normal(0, 0.5, ns).astype(np.float32)
+    risk = rna[:, :ns] @ w if signal else np.zeros(n, np.float32)
     time = (rng.exponential(1000.0, n) * np.exp(-risk) + 1.0 + np.arange(n) * 1e-3).astype(np.float32)
     assert len(np.unique(time)) == n
     event = (rng.random(n) < 0.57).astype(np.float32)

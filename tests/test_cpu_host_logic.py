@@ -1,0 +1,105 @@
+"""CPU tests of the host logic: synthetic cohort contract, fold sharding / result gathering / flat-gradient averaging
+over a 2-rank gloo group, scheduler restatements, and the no-fallback rule."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cohort_contract():
+    from multimodal_survival_prediction_amd import data
+    c = data.make_cohort(n=40, dims=(32, 32, 32), rna_dim=64, seed=1, complete=False)
+    assert c["image"].shape == (40, 1, 32, 32, 32) and c["image"].dtype == torch.float32
+    assert float(c["image"].min()) >= 0 and float(c["image"].max()) <= 1
+    assert c["label"].shape == (40, 2) and c["mask"].shape == (40, 3)
+    m = c["mask"].bool()
+    assert float(c["image"][~m[:, 0]].abs().max()) == 0            # missing imaging -> zeros (partial...:90)
+    assert float(c["rnaseq"][~m[:, 1]].abs().max()) == 0
+    t = c["label"][c["has_survival"], 0].numpy()
+    assert len(np.unique(t)) == len(t)                              # distinct times: no Cox ties
+    c2 = data.make_cohort(n=40, dims=(32, 32, 32), rna_dim=64, seed=1, complete=False)
+    assert torch.equal(c["image"], c2["image"]) and torch.equal(c["label"], c2["label"])
+    full = data.make_cohort(n=20, dims=(32, 32, 32), rna_dim=8, seed=2)
+    b = next(iter(data.BatchLoader(full, np.arange(10), 4, style="simple")))
+    assert b["time"].shape == (4, 1) and b["event"].dtype == torch.int64 and len(b["has_survival"]) == 4
+    folds = data.kfold_indices(109, 5)
+    assert sorted(np.concatenate([v for _, v in folds]).tolist()) == list(range(109))
+    assert [len(tr) for tr, _ in folds] == [87, 87, 87, 87, 88]
+
+
+def test_fold_assignment():
+    from multimodal_survival_prediction_amd.distributed import folds_of_rank
+    assert [folds_of_rank(5, 4, r) for r in range(4)] == [[0, 4], [1], [2], [3]]
+    assert folds_of_rank(5, 1, 0) == [0, 1, 2, 3, 4]
+    assert sorted(sum((folds_of_rank(5, 8, r) for r in range(8)), [])) == [0, 1, 2, 3, 4]
+
+
+_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, os.environ["MMS_ROOT"])
+from multimodal_survival_prediction_amd import distributed as D
+world, rank, local = D.init("gloo")
+assert world == 2
+res = D.gather_fold_results([{"fold": k + 1, "best_c_index": 0.5 + 0.01 * k, "rank": rank} for k in D.folds_of_rank(5, world, rank)], world)
+assert [r["fold"] for r in res] == [1, 2, 3, 4, 5] and [r["rank"] for r in res] == [0, 1, 0, 1, 0]
+g = torch.full((1000,), float(rank + 1))
+D.allreduce_mean_(g, world)
+assert torch.allclose(g, torch.full((1000,), 1.5))
+assert D.max_over_ranks(float(rank), "cpu") == 1.0
+D.barrier()
+print("ok", rank)
+'''
+
+
+def test_two_rank_gloo(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MMS_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"ok {r}" in o, o
+
+
+def test_schedulers_match_torch():
+    from multimodal_survival_prediction_amd.training import CosineAnnealingLR, ReduceLROnPlateau
+
+    class Opt:
+        def __init__(self):
+            self.param_groups = [dict(lr=1e-4)]
+
+        def set_lr(self, lr):
+            self.param_groups[0]["lr"] = lr
+    p = torch.nn.Parameter(torch.zeros(1))
+    ref = torch.optim.SGD([p], lr=1e-4)
+    rs, mine_o = torch.optim.lr_scheduler.CosineAnnealingLR(ref, T_max=50), Opt()
+    ms = CosineAnnealingLR(mine_o, T_max=50)
+    for _ in range(50):
+        ref.step(); rs.step(); ms.step()
+        assert mine_o.param_groups[0]["lr"] == pytest.approx(ref.param_groups[0]["lr"], rel=1e-9, abs=1e-15)
+    ref = torch.optim.SGD([p], lr=1e-4)
+    rs, mine_o = torch.optim.lr_scheduler.ReduceLROnPlateau(ref, mode="max", factor=0.5, patience=5), Opt()
+    ms = ReduceLROnPlateau(mine_o, mode="max", factor=0.5, patience=5)
+    for v in [0.5, 0.55, 0.54, 0.53, 0.55, 0.551, 0.52, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.6, 0.59] + [0.58] * 14:
+        rs.step(v); ms.step(v)
+        assert mine_o.param_groups[0]["lr"] == pytest.approx(ref.param_groups[0]["lr"], rel=1e-12)
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly off-GPU rather than fall back to torch/oracle math."""
+    from multimodal_survival_prediction_amd import losses, models
+    m = models.MultiModalSurvivalNet(rna_dim=16)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(2, 1, 32, 32, 32), torch.zeros(2, 16), torch.zeros(2, 1))
+    with pytest.raises(RuntimeError):
+        losses.cox_loss(torch.zeros(4), torch.ones(4), torch.arange(4.0))
+    import multimodal_survival_prediction_amd as pkg
+    src = "".join(open(os.path.join(os.path.dirname(pkg.__file__), f)).read()
+                  for f in os.listdir(os.path.dirname(pkg.__file__)) if f.endswith(".py"))
+    assert "import oracle" not in src and "from oracle" not in src
