@@ -21,6 +21,14 @@ __device__ __forceinline__ unsigned tap_mask9(int c, Dims3 g, bool mirror) {
     return dm | (hm << 3) | (wm << 6);
 }
 
+__device__ __forceinline__ void store_tile_bwd(float* y, int M, int m0, const float* Cs, int tid) {
+    for (int idx = tid; idx < 32 * 128; idx += 256) {
+        const int r = idx >> 7, c = idx & 127, m = m0 + r;
+        if (m < M) y[(size_t)m * 128 + c] = Cs[r * 129 + c];
+    }
+}
+
+template <bool SPLIT>
 struct Conv3BwdDataOp {
     typedef Conv3BwdDataP Params;
     static constexpr int WM = 1, WN = 4, WK = 1, AMODE = LD_K4, BMODE = LD_K4;
@@ -50,7 +58,9 @@ struct Conv3BwdDataOp {
 #pragma unroll
         for (int i = 0; i < 4; ++i) woff[i] = (((tid >> 3) + 32 * i) * 864 + co) * 4;
     }
-    __device__ void krange(const Params&, int, int& kb, int& ke) { kb = 0; ke = 27 * 32; }
+    __device__ void krange(const Params&, int z, int& kb, int& ke) {
+        if (SPLIT) { kb = z * 32; ke = kb + 32; } else { kb = 0; ke = 27 * 32; }
+    }
     __device__ void step(const Params& p, int k0) {
         const int tap = k0 >> 5, kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
         sel = (1u << kd) | (8u << kh) | (64u << kw);
@@ -67,7 +77,11 @@ struct Conv3BwdDataOp {
     }
     __device__ float4 b_ld(const Params&, int i, int, int, bool& ok) const { ok = true; return buf_load4(rw, woff[i], wsoff); }
     __device__ float4 b_tx(const Params&, int, const float4& v, int, int, bool) const { return v; }
-    __device__ void epilogue(const Params& p, int m0_, int, int, const float* Cs, int tid, bool active) {
+    __device__ void epilogue(const Params& p, int m0_, int, int z, const float* Cs, int tid, bool active) {
+        if (SPLIT) {       // raw partial tile; mask + BN sums happen in conv3_bwd_data_reduce_kernel
+            if (active) store_tile_bwd(p.partial + (size_t)z * p.M * 128, p.M, m0_, Cs, tid);
+            return;
+        }
         const int c = tid & 127, rg = tid >> 7;
         const float mu = ex[c], rstd = ex[128 + c], ga = ex[256 + c], be = ex[384 + c];
         double s1 = 0, s2 = 0;
@@ -90,10 +104,43 @@ struct Conv3BwdDataOp {
     }
 };
 
+// tap-split variant: sum the 27 partials, apply the relu2 mask, write dbn2 and the BN2-backward sums
+__global__ __launch_bounds__(256) void conv3_bwd_data_reduce_kernel(const Conv3BwdDataP p) {
+    __shared__ double red[2][2][128];
+    const int c = threadIdx.x & 127, rg = threadIdx.x >> 7;
+    float mu, rstd;
+    bn_mean_rstd(p.bn, c, mu, rstd);
+    const float ga = p.bn.gamma[c], be = p.bn.beta[c];
+    double s1 = 0, s2 = 0;
+    const int mend = blockIdx.x * 16 + 16 < p.M ? blockIdx.x * 16 + 16 : p.M;
+    for (int m = blockIdx.x * 16 + rg; m < mend; m += 2) {
+        float a = 0.f;
+#pragma unroll 9
+        for (int t = 0; t < 27; ++t) a += p.partial[((size_t)t * p.M + m) * 128 + c];
+        const size_t o = (size_t)m * 128 + c;
+        const float xh = (p.y1[o] - mu) * rstd;
+        const float g = fmaf(ga, xh, be) > 0.f ? a : 0.f;
+        p.dbn[o] = g;
+        s1 += g; s2 += (double)g * xh;
+    }
+    red[0][rg][c] = s1; red[1][rg][c] = s2;
+    __syncthreads();
+    if (rg == 0) {
+        atomicAdd(&p.s1[c], red[0][0][c] + red[0][1][c]);
+        atomicAdd(&p.s2[c], red[1][0][c] + red[1][1][c]);
+    }
+}
+
 extern "C" int mms_conv3_bwd_data(const Conv3BwdDataP* pp, hipStream_t s) {
     const Conv3BwdDataP& p = *pp;
     if (p.M <= 0 || p.lddz % 4 != 0) return MMS_ERR_ARG;
-    return launch_tile_gemm<Conv3BwdDataOp>(p, dim3((p.M + 31) / 32, 1, 1), s);
+    if (p.partial) {
+        int rc = launch_tile_gemm<Conv3BwdDataOp<true>>(p, dim3((p.M + 31) / 32, 1, 27), s);
+        if (rc != MMS_OK) return rc;
+        MMS_LAUNCH(conv3_bwd_data_reduce_kernel, dim3((p.M + 15) / 16), dim3(256), 0, s, p);
+        return mms_check_launch();
+    }
+    return launch_tile_gemm<Conv3BwdDataOp<false>>(p, dim3((p.M + 31) / 32, 1, 1), s);
 }
 
 // ------------------------------------------------------------------------------------------------------

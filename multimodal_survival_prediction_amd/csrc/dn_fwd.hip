@@ -134,6 +134,7 @@ __device__ __forceinline__ unsigned tap_mask9(int c, Dims3 g, bool mirror) {
     return dm | (hm << 3) | (wm << 6);
 }
 
+template <bool SPLIT>
 struct Conv3FwdOp {
     typedef Conv3FwdP Params;
     static constexpr int WM = 1, WN = 1, WK = 4, AMODE = LD_K4, BMODE = LD_K4;
@@ -171,7 +172,9 @@ struct Conv3FwdOp {
             woff[i] = (row * (27 * 128) + c0) * 4;
         }
     }
-    __device__ void krange(const Params&, int, int& kb, int& ke) { kb = 0; ke = 27 * 128; }
+    __device__ void krange(const Params&, int z, int& kb, int& ke) {
+        if (SPLIT) { kb = z * 128; ke = kb + 128; } else { kb = 0; ke = 27 * 128; }
+    }
     __device__ void step(const Params& p, int k0) {
         const int tap = k0 >> 7, kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
         sel = (1u << kd) | (8u << kh) | (64u << kw);
@@ -192,17 +195,51 @@ struct Conv3FwdOp {
         return buf_load4(rw, woff[i], wsoff);
     }
     __device__ float4 b_tx(const Params&, int, const float4& v, int, int, bool) const { return v; }
-    __device__ void epilogue(const Params& p, int m0_, int n0, int, const float* Cs, int tid, bool active) {
+    __device__ void epilogue(const Params& p, int m0_, int n0, int z, const float* Cs, int tid, bool active) {
         if (!active) return;
+        if (SPLIT) {
+            store_tile<TM, TN>(p.partial + (size_t)z * p.M * 32, 32, p.M, 32, m0_, n0, Cs, tid);
+            return;
+        }
         store_tile<TM, TN>(p.out, p.ldo, p.M, 32, m0_, n0, Cs, tid);
         tile_col_stats<TM, TN>(p.osum, p.osumsq, p.M, 32, m0_, n0, Cs, tid);
     }
 };
 
+// sums the 27 tap partials (fixed order: deterministic), writes the slab columns, accumulates the batch statistics
+__global__ __launch_bounds__(256) void conv3_fwd_reduce_kernel(const Conv3FwdP p) {
+    __shared__ double red[2][8][32];
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    double s = 0, q = 0;
+    for (int m = blockIdx.x * 32 + rg; m < p.M && m < blockIdx.x * 32 + 32; m += 8) {
+        float a = 0.f;
+#pragma unroll 9
+        for (int t = 0; t < 27; ++t) a += p.partial[((size_t)t * p.M + m) * 32 + c];
+        p.out[(size_t)m * p.ldo + c] = a;
+        s += a; q += (double)a * a;
+    }
+    if (p.osum == nullptr) return;
+    red[0][rg][c] = s; red[1][rg][c] = q;
+    __syncthreads();
+    if (rg == 0) {
+        double a = 0, b = 0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) { a += red[0][g][c]; b += red[1][g][c]; }
+        atomicAdd(&p.osum[c], a);
+        atomicAdd(&p.osumsq[c], b);
+    }
+}
+
 extern "C" int mms_conv3_fwd(const Conv3FwdP* pp, hipStream_t s) {
     const Conv3FwdP& p = *pp;
     if (p.M <= 0 || p.ldo % 4 != 0) return MMS_ERR_ARG;
-    return launch_tile_gemm<Conv3FwdOp>(p, dim3((p.M + 31) / 32, 1, 1), s);
+    if (p.partial) {
+        int rc = launch_tile_gemm<Conv3FwdOp<true>>(p, dim3((p.M + 31) / 32, 1, 27), s);
+        if (rc != MMS_OK) return rc;
+        MMS_LAUNCH(conv3_fwd_reduce_kernel, dim3((p.M + 31) / 32), dim3(256), 0, s, p);
+        return mms_check_launch();
+    }
+    return launch_tile_gemm<Conv3FwdOp<false>>(p, dim3((p.M + 31) / 32, 1, 1), s);
 }
 
 // ------------------------------------------------------------------------------------------------------

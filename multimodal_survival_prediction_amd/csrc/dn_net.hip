@@ -31,7 +31,7 @@ struct Plan {
     int M0, M[NB];
     // byte offsets into the workspace
     size_t coords0, coords[NB], y0, argmax, slab[NB], dslab[NB], y1[NLAYER], wpf[NLAYER], wpb[NLAYER];
-    size_t dbn_mid, dbn_in, dbn0, pooled, tab_pack, tab_bn;
+    size_t dbn_mid, dbn_in, dbn0, pooled, tab_pack, tab_bn, partial;
     // fp64 statistic accumulators (one contiguous region, zeroed once per step)
     size_t stats_begin, stats_end;
     size_t st_y0, st_slab[NB], st_y1[NLAYER];          // forward (sum | sumsq), each 2*C doubles
@@ -71,6 +71,7 @@ bool make_plan(Plan& P, int B, int D, int H, int W) {
     P.dbn_in = take(mx);
     P.dbn0 = take((size_t)P.M0 * 64 * 4);
     P.pooled = take((size_t)B * 1024 * 4);
+    P.partial = take((size_t)27 * (P.M[1] > 1024 ? 1024 : P.M[1]) * 128 * 4);     // tap-split scratch (blocks with M <= 1024)
     P.tab_pack = take(sizeof(PackEntry) * NLAYER);
     P.tab_bn = take(sizeof(BnRunEntry) * NBN);
     P.stats_begin = o;
@@ -234,7 +235,8 @@ extern "C" int mms_dn121_forward(void* ws, int B, int D, int H, int W, const flo
             TRY(mms_conv1_fwd(&c1, s));
             Conv3FwdP c3{at<float>(ws, P.y1[l]), at<int>(ws, P.coords[b]), P.g[b], P.M[b], at<float>(ws, P.wpf[l]),
                          slab + C, CTOT[b], mk_bn(ws, P.st_y1[l], 128, prm, ip + 3, buffers, IDX.bn_layer2[l], P.M[b], train),
-                         st(P.st_slab[b], CTOT[b], C, false), st(P.st_slab[b], CTOT[b], C, true)};
+                         st(P.st_slab[b], CTOT[b], C, false), st(P.st_slab[b], CTOT[b], C, true),
+                         (b > 0 && P.M[b] <= 1024) ? at<float>(ws, P.partial) : nullptr};
             TRY(mms_conv3_fwd(&c3, s));
         }
         if (b < 3) {
@@ -281,7 +283,8 @@ extern "C" int mms_dn121_backward(void* ws, int B, int D, int H, int W, const fl
             const BnSrc bn2 = mk_bn(ws, P.st_y1[l], 128, prm, ip + 3, nullptr, 0, M, 1);
             Conv3BwdDataP bd{dslab + C, CTOT[b], at<int>(ws, P.coords[b]), P.g[b], M, at<float>(ws, P.wpb[l]),
                              at<float>(ws, P.y1[l]), bn2, at<float>(ws, P.dbn_mid),
-                             at<double>(ws, P.bb_y1[l]), at<double>(ws, P.bb_y1[l]) + 128};
+                             at<double>(ws, P.bb_y1[l]), at<double>(ws, P.bb_y1[l]) + 128,
+                             (b > 0 && M <= 1024) ? at<float>(ws, P.partial) : nullptr};
             TRY(mms_conv3_bwd_data(&bd, s));
             int ms3 = (M + 511) / 512; if (ms3 < 1) ms3 = 1;
             Conv3BwdWP bw{at<float>(ws, P.y1[l]), at<int>(ws, P.coords[b]), P.g[b], M, bn2, dslab + C, CTOT[b],
