@@ -133,8 +133,10 @@ typedef struct Conv3BwdWP {
     const float* y1; const int* coords; Dims3 g; int M;
     BnSrc bn;
     const float* dz; int lddz;
-    float* dw;                      // canonical torch layout [32][128][27], accumulated with atomics
+    float* dw;                      // canonical torch layout [32][128][27], accumulated with atomics (dw_tapmajor = 0)
     int msplit;                     // grid.z = 27 * msplit
+    int dw_tapmajor;                // 1: dw is a zeroed scratch in [27][32][128] (tap, cout, cin) layout: contiguous
+                                    // atomics at full rate; mms_unpack_conv3_grads adds it into the canonical gradient
 } Conv3BwdWP;
 
 // 1x1 conv backward (dense conv1 and transition conv).
@@ -296,6 +298,7 @@ int mms_bn_bwd_apply(const BnBwdApplyP* p, hipStream_t s);       /* norm1 backwa
 int mms_head_bwd(const HeadBwdP* p, hipStream_t s);              /* class_layers + norm5 backward */
 int mms_pool_bwd(const PoolBwdP* p, hipStream_t s);              /* pool0 + relu0 backward */
 int mms_conv0_bwd_weight(const Conv0BwdWP* p, hipStream_t s);    /* norm0 backward + conv0 wrt weight */
+int mms_unpack_conv3_grads(const void* table_host, int nlayers, hipStream_t s);   /* host array of {scratch [27][32][128], dw canonical}, <= 64 layers */
 int mms_pack_conv3(const float* w, float* wpf, float* wpb, hipStream_t s);
 int mms_pack_conv3_table(const void* table_dev, int nlayers, hipStream_t s);
 int mms_bn_running_update(const void* table_dev, int n, float momentum, hipStream_t s);

@@ -5,6 +5,7 @@
 // the next kernel's operand prologue, so dx of the inner BN (norm2) is never materialised.
 #include "dn_ops.h"
 #include "tile_gemm.h"
+#include <string.h>
 
 #define Z4 make_float4(0, 0, 0, 0)
 
@@ -112,11 +113,14 @@ __global__ __launch_bounds__(256) void conv3_bwd_data_reduce_kernel(const Conv3B
     bn_mean_rstd(p.bn, c, mu, rstd);
     const float ga = p.bn.gamma[c], be = p.bn.beta[c];
     double s1 = 0, s2 = 0;
-    const int mend = blockIdx.x * 16 + 16 < p.M ? blockIdx.x * 16 + 16 : p.M;
-    for (int m = blockIdx.x * 16 + rg; m < mend; m += 2) {
+    const int mend = blockIdx.x * 4 + 4 < p.M ? blockIdx.x * 4 + 4 : p.M;
+    for (int m = blockIdx.x * 4 + rg; m < mend; m += 2) {
+        float v[27];
+#pragma unroll
+        for (int t = 0; t < 27; ++t) v[t] = p.partial[((size_t)t * p.M + m) * 128 + c];    // 27 loads in flight
         float a = 0.f;
-#pragma unroll 9
-        for (int t = 0; t < 27; ++t) a += p.partial[((size_t)t * p.M + m) * 128 + c];
+#pragma unroll
+        for (int t = 0; t < 27; ++t) a += v[t];
         const size_t o = (size_t)m * 128 + c;
         const float xh = (p.y1[o] - mu) * rstd;
         const float g = fmaf(ga, xh, be) > 0.f ? a : 0.f;
@@ -137,7 +141,7 @@ extern "C" int mms_conv3_bwd_data(const Conv3BwdDataP* pp, hipStream_t s) {
     if (p.partial) {
         int rc = launch_tile_gemm<Conv3BwdDataOp<true>>(p, dim3((p.M + 31) / 32, 1, 27), s);
         if (rc != MMS_OK) return rc;
-        MMS_LAUNCH(conv3_bwd_data_reduce_kernel, dim3((p.M + 15) / 16), dim3(256), 0, s, p);
+        MMS_LAUNCH(conv3_bwd_data_reduce_kernel, dim3((p.M + 3) / 4), dim3(256), 0, s, p);
         return mms_check_launch();
     }
     return launch_tile_gemm<Conv3BwdDataOp<false>>(p, dim3((p.M + 31) / 32, 1, 1), s);
@@ -212,10 +216,39 @@ struct Conv3BwdWOp {
         if (mb >= me || !active) return;
         for (int idx = tid; idx < TM * TN; idx += 256) {
             const int cin = idx & 127, co = idx >> 7;
-            atomicAdd(&p.dw[((size_t)co * 128 + cin) * 27 + tap], Cs[cin * (TN + 1) + co]);
+            const size_t dst = p.dw_tapmajor ? ((size_t)tap * 32 + co) * 128 + cin : ((size_t)co * 128 + cin) * 27 + tap;
+            atomicAdd(&p.dw[dst], Cs[cin * (TN + 1) + co]);
         }
     }
 };
+
+// tap-major gradient scratch -> canonical torch layout, through LDS so both sides are coalesced.
+// one workgroup per (layer, cout): 27 x 128 floats
+struct UnpackEntry { const float* scratch; float* dw; };
+struct UnpackTable { UnpackEntry e[64]; };      // passed BY VALUE as a kernel argument (1 KB): capture-safe, no device table
+__global__ __launch_bounds__(256) void unpack_conv3_grads_kernel(const UnpackTable tab) {
+    __shared__ float t[27 * 129];
+    const UnpackEntry e = tab.e[blockIdx.y];
+    const int co = blockIdx.x;
+    for (int idx = threadIdx.x; idx < 27 * 128; idx += 256) {
+        const int tap = idx >> 7, cin = idx & 127;
+        t[tap * 129 + cin] = e.scratch[((size_t)tap * 32 + co) * 128 + cin];
+    }
+    __syncthreads();
+    float* dst = e.dw + (size_t)co * 128 * 27;
+    for (int idx = threadIdx.x; idx < 27 * 128; idx += 256) {
+        const int cin = idx / 27, tap = idx % 27;
+        dst[idx] += t[tap * 129 + cin];
+    }
+}
+extern "C" int mms_unpack_conv3_grads(const void* table_host, int nlayers, hipStream_t s) {
+    if (nlayers <= 0) return MMS_OK;
+    if (nlayers > 64) return MMS_ERR_ARG;
+    UnpackTable t;
+    memcpy(t.e, table_host, sizeof(UnpackEntry) * nlayers);
+    MMS_LAUNCH(unpack_conv3_grads_kernel, dim3(32, nlayers), dim3(256), 0, s, t);
+    return mms_check_launch();
+}
 
 extern "C" int mms_conv3_bwd_weight(const Conv3BwdWP* pp, hipStream_t s) {
     const Conv3BwdWP& p = *pp;
@@ -456,45 +489,40 @@ extern "C" int mms_conv1_bwd_weight(const Conv1BwdP* pp, hipStream_t s) {
 // BN backward apply into the gradient slab: dx[:, 0:C] (+)= g*rstd*(dbn - s1/M - xhat*s2/M)
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyP p) {
-    extern __shared__ float cst[];    // [4][C]: mean, rstd, g*rstd, s1/M ; s2/M in a 5th row
-    const int tid = threadIdx.x, C = p.C;
-    for (int c = tid; c < C; c += 256) {
-        float mu, rs;
-        bn_mean_rstd(p.bn, c, mu, rs);
-        cst[c] = mu; cst[C + c] = rs; cst[2 * C + c] = p.bn.gamma[c] * rs;
-        cst[3 * C + c] = (float)(p.bb.s1[c] * (double)p.bn.inv_count);
-        cst[4 * C + c] = (float)(p.bb.s2[c] * (double)p.bn.inv_count);
-        if (blockIdx.x == 0 && p.dgamma) {
-            p.dgamma[c] += (float)p.bb.s2[c];
-            p.dbeta[c] += (float)p.bb.s1[c];
+    // workgroup = 32 rows x one 256-channel chunk; each thread owns 4 channels and keeps their constants in registers
+    const int tid = threadIdx.x, c = blockIdx.y * 256 + (tid & 63) * 4, rg = tid >> 6;
+    if (c >= p.C) return;
+    float mu[4], rs[4], gr[4], m1[4], m2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        bn_mean_rstd(p.bn, c + j, mu[j], rs[j]);
+        gr[j] = p.bn.gamma[c + j] * rs[j];
+        m1[j] = (float)(p.bb.s1[c + j] * (double)p.bn.inv_count);
+        m2[j] = (float)(p.bb.s2[c + j] * (double)p.bn.inv_count);
+        if (blockIdx.x == 0 && rg == 0 && p.dgamma) {
+            p.dgamma[c + j] += (float)p.bb.s2[c + j];
+            p.dbeta[c + j] += (float)p.bb.s1[c + j];
         }
     }
-    __syncthreads();
     const int r0 = blockIdx.x * 32, rows = p.M - r0 < 32 ? p.M - r0 : 32;
-    const int C4 = C >> 2;
-    for (int idx = tid; idx < rows * C4; idx += 256) {
-        const int r = idx / C4, c = (idx % C4) * 4;
+    for (int r = rg; r < rows; r += 4) {
         const size_t m = r0 + r;
         const float4 g = *(const float4*)(p.dbn + m * p.lddbn + c);
         const float4 x = *(const float4*)(p.x + m * p.ldx + c);
         float4* dst = (float4*)(p.dx + m * p.lddx + c);
         float4 o = p.accumulate ? *dst : make_float4(0, 0, 0, 0);
-        const float gv[4] = {g.x, g.y, g.z, g.w}, xv[4] = {x.x, x.y, x.z, x.w};
-        float ov[4] = {o.x, o.y, o.z, o.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int cc = c + j;
-            const float xh = (xv[j] - cst[cc]) * cst[C + cc];
-            ov[j] += cst[2 * C + cc] * (gv[j] - cst[3 * C + cc] - xh * cst[4 * C + cc]);
-        }
-        *dst = make_float4(ov[0], ov[1], ov[2], ov[3]);
+        o.x += gr[0] * (g.x - m1[0] - (x.x - mu[0]) * rs[0] * m2[0]);
+        o.y += gr[1] * (g.y - m1[1] - (x.y - mu[1]) * rs[1] * m2[1]);
+        o.z += gr[2] * (g.z - m1[2] - (x.z - mu[2]) * rs[2] * m2[2]);
+        o.w += gr[3] * (g.w - m1[3] - (x.w - mu[3]) * rs[3] * m2[3]);
+        *dst = o;
     }
 }
 
 extern "C" int mms_bn_bwd_apply(const BnBwdApplyP* pp, hipStream_t s) {
     const BnBwdApplyP& p = *pp;
-    if (p.M <= 0 || p.C % 4 != 0 || p.C > 2048 || p.lddbn % 4 || p.ldx % 4 || p.lddx % 4) return MMS_ERR_ARG;
-    MMS_LAUNCH(bn_bwd_apply_kernel, dim3((p.M + 31) / 32), dim3(256), 5 * p.C * sizeof(float), s, p);
+    if (p.M <= 0 || p.C % 4 != 0 || p.lddbn % 4 || p.ldx % 4 || p.lddx % 4) return MMS_ERR_ARG;
+    MMS_LAUNCH(bn_bwd_apply_kernel, dim3((p.M + 31) / 32, (p.C + 255) / 256), dim3(256), 0, s, p);
     return mms_check_launch();
 }
 

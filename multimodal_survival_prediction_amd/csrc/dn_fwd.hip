@@ -211,10 +211,13 @@ __global__ __launch_bounds__(256) void conv3_fwd_reduce_kernel(const Conv3FwdP p
     __shared__ double red[2][8][32];
     const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
     double s = 0, q = 0;
-    for (int m = blockIdx.x * 32 + rg; m < p.M && m < blockIdx.x * 32 + 32; m += 8) {
+    for (int m = blockIdx.x * 8 + rg; m < p.M && m < blockIdx.x * 8 + 8; m += 8) {
+        float v[27];
+#pragma unroll
+        for (int t = 0; t < 27; ++t) v[t] = p.partial[((size_t)t * p.M + m) * 32 + c];    // 27 loads in flight
         float a = 0.f;
-#pragma unroll 9
-        for (int t = 0; t < 27; ++t) a += p.partial[((size_t)t * p.M + m) * 32 + c];
+#pragma unroll
+        for (int t = 0; t < 27; ++t) a += v[t];
         p.out[(size_t)m * p.ldo + c] = a;
         s += a; q += (double)a * a;
     }
@@ -236,7 +239,7 @@ extern "C" int mms_conv3_fwd(const Conv3FwdP* pp, hipStream_t s) {
     if (p.partial) {
         int rc = launch_tile_gemm<Conv3FwdOp<true>>(p, dim3((p.M + 31) / 32, 1, 27), s);
         if (rc != MMS_OK) return rc;
-        MMS_LAUNCH(conv3_fwd_reduce_kernel, dim3((p.M + 31) / 32), dim3(256), 0, s, p);
+        MMS_LAUNCH(conv3_fwd_reduce_kernel, dim3((p.M + 7) / 8), dim3(256), 0, s, p);
         return mms_check_launch();
     }
     return launch_tile_gemm<Conv3FwdOp<false>>(p, dim3((p.M + 31) / 32, 1, 1), s);
@@ -416,16 +419,23 @@ extern "C" int mms_pack_conv3(const float* w, float* wpf, float* wpb, hipStream_
 
 // batched variant over a device table of layer pointers (one launch per forward)
 struct PackEntry { const float* w; float* wpf; float* wpb; };
-__global__ void pack_conv3_table_kernel(const PackEntry* tab) {
+// one workgroup per (layer, cout): the 128 x 27 canonical slice goes through LDS so reads and writes are coalesced
+__global__ __launch_bounds__(256) void pack_conv3_table_kernel(const PackEntry* tab) {
+    __shared__ float t[128 * 28];
     const PackEntry e = tab[blockIdx.y];
-    int idx = blockIdx.x * 256 + threadIdx.x;
-    int cin = idx & 127, tap = (idx >> 7) % 27, cout = idx / (27 * 128);
-    float v = e.w[(cout * 128 + cin) * 27 + tap];
-    e.wpf[idx] = v;
-    e.wpb[(cin * 27 + tap) * 32 + cout] = v;
+    const int co = blockIdx.x;
+    const float* src = e.w + (size_t)co * 128 * 27;
+    for (int idx = threadIdx.x; idx < 128 * 27; idx += 256) t[(idx / 27) * 28 + idx % 27] = src[idx];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 27 * 128; idx += 256) {
+        const int tap = idx >> 7, cin = idx & 127;
+        const float v = t[cin * 28 + tap];
+        e.wpf[((size_t)co * 27 + tap) * 128 + cin] = v;
+        e.wpb[((size_t)cin * 27 + tap) * 32 + co] = v;       // 4-byte scatter at stride 128 B: 442 KB per layer, L2-absorbed
+    }
 }
 extern "C" int mms_pack_conv3_table(const void* table_dev, int nlayers, hipStream_t s) {
-    MMS_LAUNCH(pack_conv3_table_kernel, dim3(32 * 27 * 128 / 256, nlayers), dim3(256), 0, s,
+    MMS_LAUNCH(pack_conv3_table_kernel, dim3(32, nlayers), dim3(256), 0, s,
                        (const PackEntry*)table_dev);
     return mms_check_launch();
 }

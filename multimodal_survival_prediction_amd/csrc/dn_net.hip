@@ -24,6 +24,7 @@ constexpr int NBN = 121;
 constexpr int NPARAM = 364;
 
 struct PackEntry { const float* w; float* wpf; float* wpb; };
+struct UnpackEntry { const float* scratch; float* dw; };
 struct BnRunEntry { const double* sum; const double* sumsq; float* rmean; float* rvar; long long* nbt; int C; float count; };
 
 struct Plan {
@@ -31,7 +32,7 @@ struct Plan {
     int M0, M[NB];
     // byte offsets into the workspace
     size_t coords0, coords[NB], y0, argmax, slab[NB], dslab[NB], y1[NLAYER], wpf[NLAYER], wpb[NLAYER];
-    size_t dbn_mid, dbn_in, dbn0, pooled, tab_pack, tab_bn, partial;
+    size_t dbn_mid, dbn_in, dbn0, pooled, tab_pack, tab_bn, partial, dwp[NLAYER];
     // fp64 statistic accumulators (one contiguous region, zeroed once per step)
     size_t stats_begin, stats_end;
     size_t st_y0, st_slab[NB], st_y1[NLAYER];          // forward (sum | sumsq), each 2*C doubles
@@ -75,6 +76,7 @@ bool make_plan(Plan& P, int B, int D, int H, int W) {
     P.tab_pack = take(sizeof(PackEntry) * NLAYER);
     P.tab_bn = take(sizeof(BnRunEntry) * NBN);
     P.stats_begin = o;
+    for (int i = 0; i < NLAYER; ++i) P.dwp[i] = take((size_t)27 * 32 * 128 * 4);    // tap-major conv2 gradient scratch (zeroed with the stats)
     P.st_y0 = take(2 * 64 * 8);
     for (int b = 0; b < NB; ++b) P.st_slab[b] = take((size_t)2 * CTOT[b] * 8);
     for (int i = 0; i < NLAYER; ++i) P.st_y1[i] = take(2 * 128 * 8);
@@ -123,6 +125,7 @@ inline BnSrc mk_bn(void* ws, size_t st_off, int Ctot_, const float* const* prm, 
 
 extern "C" int mms_init_coords(int*, int, int, int, int, hipStream_t);
 extern "C" int mms_pack_conv3_table(const void*, int, hipStream_t);
+extern "C" int mms_unpack_conv3_grads(const void*, int, hipStream_t);
 extern "C" int mms_bn_running_update(const void*, int, float, hipStream_t);
 extern "C" int mms_conv0_fwd(const Conv0FwdP*, hipStream_t);
 extern "C" int mms_pool_fwd(const PoolFwdP*, hipStream_t);
@@ -288,7 +291,7 @@ extern "C" int mms_dn121_backward(void* ws, int B, int D, int H, int W, const fl
             TRY(mms_conv3_bwd_data(&bd, s));
             int ms3 = (M + 511) / 512; if (ms3 < 1) ms3 = 1;
             Conv3BwdWP bw{at<float>(ws, P.y1[l]), at<int>(ws, P.coords[b]), P.g[b], M, bn2, dslab + C, CTOT[b],
-                          grd[ip + 5], ms3};
+                          at<float>(ws, P.dwp[l]), ms3, 1};
             TRY(mms_conv3_bwd_weight(&bw, s));
             int ms1 = M / 256; if (ms1 < 1) ms1 = 1; if (ms1 > 32) ms1 = 32;
             Conv1BwdP c1{};
@@ -338,5 +341,8 @@ extern "C" int mms_dn121_backward(void* ws, int B, int D, int H, int W, const fl
             TRY(mms_conv0_bwd_weight(&cw, s));
         }
     }
+    UnpackEntry up[NLAYER];
+    for (int i = 0; i < NLAYER; ++i) { up[i].scratch = at<float>(ws, P.dwp[i]); up[i].dw = grd[IDX.layer[i] + 5]; }
+    TRY(mms_unpack_conv3_grads(up, NLAYER, s));
     return MMS_OK;
 }

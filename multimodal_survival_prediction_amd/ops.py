@@ -89,8 +89,9 @@ def conv3_bwd_data(dz, coords, dims, wpb, y1, bn, dbn, s1, s2, partial=None):
     call("mms_conv3_bwd_data", p)
 
 
-def conv3_bwd_weight(y1, coords, dims, bn, dz, dw, msplit=1):
-    p = _S()["Conv3BwdWP"](ptr(y1), ptr(coords), dims3(dims), y1.shape[0], bn, ptr(dz), dz.stride(0), ptr(dw), msplit)
+def conv3_bwd_weight(y1, coords, dims, bn, dz, dw, msplit=1, tapmajor=False):
+    p = _S()["Conv3BwdWP"](ptr(y1), ptr(coords), dims3(dims), y1.shape[0], bn, ptr(dz), dz.stride(0), ptr(dw), msplit,
+                           1 if tapmajor else 0)
     call("mms_conv3_bwd_weight", p)
 
 
