@@ -29,42 +29,31 @@ PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 BLOCKS = ((6, 64), (12, 128), (24, 256), (16, 512))     # (layers, first-layer input channels) of DenseNet121
 
 
-def conv3_launch_table(B, dims):
-    """(rows M, algorithmic FLOPs) of every conv2 (3x3x3, 128->32) launch of one forward, in launch order.
-    FLOPs = 2 * M * 27 * 128 * 32 (the dense-layer 3^3 conv; zero-padding taps included,
-    as in the survey's MAC count)."""
-    D, H, W = dims
-    rows = []
-    vox = (D // 4) * (H // 4) * (W // 4)
-    for i, (layers, _) in enumerate(BLOCKS):
-        M = B * vox // (8 ** i)
-        rows += [(M, 2.0 * M * 27 * 128 * 32)] * layers
-    return rows
-
-
 def measure_dominant_kernel(B, dims, device, reps=20):
-    """Average launch duration of the conv3 forward kernel (tile_gemm_kernel<Conv3FwdOp>) over the 58 launches of
-    one forward, timed live with HIP events on the launch stream (torch's current stream), shape by shape."""
+    """Average launch duration of the dominant kernel -- tile_gemm_kernel<Conv3BwdWOp>, the weight gradient of the
+    dense-layer 3x3x3 conv (58 launches per step, the largest share of GPU time in profiles/r01_*) -- timed live with
+    HIP events on the launch stream (torch's current stream), shape by shape with the driver's own split factors,
+    weighted by the launch counts.  Algorithmic FLOPs per launch = 2 * M * 27 * 128 * 32."""
     from multimodal_survival_prediction_amd import ops
     tot_t, tot_f, n = 0.0, 0.0, 0
     D, H, W = dims
-    wp = torch.randn(32 * 27 * 128, device=device) * 0.02
     g, b = torch.ones(128, device=device), torch.zeros(128, device=device)
     for i, (layers, _) in enumerate(BLOCKS):
         gd = (D // 4 >> i, H // 4 >> i, W // 4 >> i)
         M = B * gd[0] * gd[1] * gd[2]
+        ms = (M + 511) // 512 if M > 1024 else max((M + 127) // 128, 1)        # dn_net.hip: ms3
         y1 = torch.randn(M, 128, device=device)
         s, q = y1.double().sum(0), (y1.double() ** 2).sum(0)
         bn = ops.bnsrc(g, b, M, True, s, q)
         coords = ops.init_coords(B, gd, device)
-        slab = torch.zeros(M, 256, device=device)
-        os_, oq = torch.zeros(32, dtype=torch.float64, device=device), torch.zeros(32, dtype=torch.float64, device=device)
+        dslab = torch.randn(M, 256, device=device)
+        dwp = torch.zeros(27 * 32 * 128, device=device)
         for _ in range(3):
-            ops.conv3_fwd(y1, coords, gd, wp, slab[:, 64:96], bn, os_, oq)
+            ops.conv3_bwd_weight(y1, coords, gd, bn, dslab[:, 64:96], dwp, ms, tapmajor=True)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            ops.conv3_fwd(y1, coords, gd, wp, slab[:, 64:96], bn, os_, oq)
+            ops.conv3_bwd_weight(y1, coords, gd, bn, dslab[:, 64:96], dwp, ms, tapmajor=True)
         e1.record()
         torch.cuda.synchronize()
         t = e0.elapsed_time(e1) * 1e-3 / reps
@@ -174,7 +163,7 @@ def main():
                        "hip_graph": not args.no_graph, "mean_train_loss": stats["sum_loss"] / max(stats["n_batches"], 1)},
         }
         avg_t, avg_f = measure_dominant_kernel(B, dims, dev)
-        out["roofline"] = {"bound": "mfma", "kernel": "tile_gemm_kernel<Conv3FwdOp> (dense-layer 3x3x3 conv, 58 launches/forward)",
+        out["roofline"] = {"bound": "mfma", "kernel": "tile_gemm_kernel<Conv3BwdWOp> (weight gradient of the dense-layer 3x3x3 conv, 58 launches/step)",
                            "achieved": avg_f / avg_t / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": avg_f / avg_t / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                            "avg_launch_us": avg_t * 1e6, "avg_flops_per_launch": avg_f}

@@ -25,6 +25,7 @@
 
 #ifndef HIP_INCLUDE_HIP_HIP_RUNTIME_API_H
 typedef struct ihipStream_t* hipStream_t;
+typedef struct ihipEvent_t* hipEvent_t;
 #endif
 
 #define MMS_OK 0
@@ -327,6 +328,11 @@ int mms_dn121_forward(void* ws, int B, int D, int H, int W, const float* x, cons
                       const void* const* buffers, float* out, int ldo, int train, hipStream_t s);
 int mms_dn121_backward(void* ws, int B, int D, int H, int W, const float* x, const void* const* params,
                        const float* dout, int lddout, void* const* grads, hipStream_t s);
+/* same, with the per-layer weight-gradient kernels forked onto `side` (caller-created stream and two events): they
+ * are off the critical path dslab -> dbn2 -> dbn1 -> dslab, so under graph capture they become parallel branches. */
+int mms_dn121_backward_mt(void* ws, int B, int D, int H, int W, const float* x, const void* const* params,
+                          const float* dout, int lddout, void* const* grads, hipStream_t s, hipStream_t side,
+                          hipEvent_t ev_fork, hipEvent_t ev_join);
 
 #ifdef __cplusplus
 }

@@ -24,6 +24,35 @@ __device__ __forceinline__ void bn_mean_rstd(const BnSrc& b, int c, float& mean,
     }
 }
 
+// BN constants of channels tid, tid+256, ... (< C <= 256*NJ) into LDS arrays; all global loads are issued before any
+// dependent math so a workgroup pays ONE memory round trip for its constants instead of NJ serialized ones.
+template <int NJ>
+__device__ __forceinline__ void bn_consts_to_lds(const BnSrc& b, int C, int tid, float* o_mean, float* o_sc, float* o_beta) {
+    double s[NJ], q[NJ];
+    float g[NJ], be[NJ], rm[NJ], rv[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int c = tid + 256 * j, cc = c < C ? c : C - 1;
+        if (b.train) { s[j] = b.sum[cc]; q[j] = b.sumsq[cc]; rm[j] = 0.f; rv[j] = 0.f; }
+        else { rm[j] = b.rmean[cc]; rv[j] = b.rvar[cc]; s[j] = 0; q[j] = 0; }
+        g[j] = b.gamma[cc]; be[j] = b.beta[cc];
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int c = tid + 256 * j;
+        float mu, rstd;
+        if (b.train) {
+            const double m = s[j] * (double)b.inv_count;
+            double v = q[j] * (double)b.inv_count - m * m;
+            v = v > 0.0 ? v : 0.0;
+            mu = (float)m; rstd = 1.0f / sqrtf((float)v + b.eps);
+        } else {
+            mu = rm[j]; rstd = 1.0f / sqrtf(rv[j] + b.eps);
+        }
+        if (c < C) { o_mean[c] = mu; o_sc[c] = g[j] * rstd; o_beta[c] = be[j]; }
+    }
+}
+
 // y = (x - mean) * (gamma*rstd) + beta, the centred form torch uses (no large-mean cancellation).
 __device__ __forceinline__ float bn_apply(float x, float mean, float sc, float beta) {
     return fmaf(x - mean, sc, beta);

@@ -46,11 +46,7 @@ struct Conv1FwdOp {
     int m0;
     __device__ void setup(const Params& p, int m0_, int, int, float* extra, int tid) {
         mean = extra; sc = extra + 1024; beta = extra + 2048; srcbase = (const int*)(extra + 3072); m0 = m0_;
-        for (int c = tid; c < p.K; c += 256) {
-            float mu, rstd;
-            bn_mean_rstd(p.bn, c, mu, rstd);
-            extra[c] = mu; extra[1024 + c] = p.bn.gamma[c] * rstd; extra[2048 + c] = p.bn.beta[c];
-        }
+        bn_consts_to_lds<4>(p.bn, p.K, tid, extra, extra + 1024, extra + 2048);
         if (POOL && tid < TM) {
             int m = m0 + tid, base = -1;
             if (m < p.M) {

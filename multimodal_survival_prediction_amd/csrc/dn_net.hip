@@ -260,8 +260,11 @@ extern "C" int mms_dn121_forward(void* ws, int B, int D, int H, int W, const flo
 
 // Backward of the training-mode forward that last ran on this workspace.  grads are ACCUMULATED into
 // (caller zeroes them, e.g. one hipMemsetAsync over a flat gradient buffer).  dout: [B][128].
-extern "C" int mms_dn121_backward(void* ws, int B, int D, int H, int W, const float* x, const void* const* params_,
-                                  const float* dout, int lddout, void* const* grads_, hipStream_t s) {
+static int dn121_backward_impl(void* ws, int B, int D, int H, int W, const float* x, const void* const* params_,
+                               const float* dout, int lddout, void* const* grads_, hipStream_t s, hipStream_t side,
+                               hipEvent_t ev_fork, hipEvent_t ev_join) {
+    hipStream_t sw = side ? side : s;       // stream of the weight-gradient kernels
+    bool side_pending = false;
     Plan P;
     if (!make_plan(P, B, D, H, W) || !ws || !x || !params_ || !dout || !grads_) return MMS_ERR_ARG;
     const float* const* prm = (const float* const*)params_;
@@ -288,12 +291,19 @@ extern "C" int mms_dn121_backward(void* ws, int B, int D, int H, int W, const fl
                              at<float>(ws, P.y1[l]), bn2, at<float>(ws, P.dbn_mid),
                              at<double>(ws, P.bb_y1[l]), at<double>(ws, P.bb_y1[l]) + 128,
                              (b > 0 && M <= 1024) ? at<float>(ws, P.partial) : nullptr};
+            if (side && side_pending) {       // the previous layer's weight kernels read dbn_mid: join before overwriting it
+                if (hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) return MMS_ERR_LAUNCH;
+                side_pending = false;
+            }
             TRY(mms_conv3_bwd_data(&bd, s));
-            int ms3 = (M + 511) / 512; if (ms3 < 1) ms3 = 1;
+            if (side) {
+                if (hipEventRecord(ev_fork, s) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess) return MMS_ERR_LAUNCH;
+            }
+            int ms3 = M > 1024 ? (M + 511) / 512 : (M + 127) / 128; if (ms3 < 1) ms3 = 1;
             Conv3BwdWP bw{at<float>(ws, P.y1[l]), at<int>(ws, P.coords[b]), P.g[b], M, bn2, dslab + C, CTOT[b],
                           at<float>(ws, P.dwp[l]), ms3, 1};
-            TRY(mms_conv3_bwd_weight(&bw, s));
-            int ms1 = M / 256; if (ms1 < 1) ms1 = 1; if (ms1 > 32) ms1 = 32;
+            TRY(mms_conv3_bwd_weight(&bw, sw));
+            int ms1 = M > 1024 ? M / 256 : M / 128; if (ms1 < 1) ms1 = 1; if (ms1 > 32) ms1 = 32;
             Conv1BwdP c1{};
             c1.dyraw = at<float>(ws, P.dbn_mid); c1.lddy = 128;
             c1.y = at<float>(ws, P.y1[l]); c1.ldy = 128;
@@ -305,11 +315,19 @@ extern "C" int mms_dn121_backward(void* ws, int B, int D, int H, int W, const fl
             c1.dbn = at<float>(ws, P.dbn_in); c1.lddbn = CTOT[b];
             c1.s1 = at<double>(ws, P.bb_in[l]); c1.s2 = at<double>(ws, P.bb_in[l]) + 1024;
             c1.msplit = ms1; c1.dgamma_out = grd[ip + 3]; c1.dbeta_out = grd[ip + 4];
-            TRY(mms_conv1_bwd_weight(&c1, s));
+            TRY(mms_conv1_bwd_weight(&c1, sw));
+            if (side) {
+                if (hipEventRecord(ev_join, side) != hipSuccess) return MMS_ERR_LAUNCH;
+                side_pending = true;
+            }
             TRY(mms_conv1_bwd_data(&c1, s));
             BnBwdApplyP ap{at<float>(ws, P.dbn_in), CTOT[b], slab, CTOT[b], dslab, CTOT[b], M, C, bn1,
                            bbsrc(P.bb_in[l], 1024), 1, grd[ip], grd[ip + 1]};
             TRY(mms_bn_bwd_apply(&ap, s));
+        }
+        if (side && side_pending) {
+            if (hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) return MMS_ERR_LAUNCH;
+            side_pending = false;
         }
         if (b > 0) {   // transition b-1 -> b
             const int t = b - 1, ip = IDX.trans[t], Kp = CTOT[t], Mp = P.M[t];
@@ -341,8 +359,22 @@ extern "C" int mms_dn121_backward(void* ws, int B, int D, int H, int W, const fl
             TRY(mms_conv0_bwd_weight(&cw, s));
         }
     }
+    if (side && side_pending) {
+        if (hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) return MMS_ERR_LAUNCH;
+    }
     UnpackEntry up[NLAYER];
     for (int i = 0; i < NLAYER; ++i) { up[i].scratch = at<float>(ws, P.dwp[i]); up[i].dw = grd[IDX.layer[i] + 5]; }
     TRY(mms_unpack_conv3_grads(up, NLAYER, s));
     return MMS_OK;
+}
+
+extern "C" int mms_dn121_backward(void* ws, int B, int D, int H, int W, const float* x, const void* const* params,
+                                  const float* dout, int lddout, void* const* grads, hipStream_t s) {
+    return dn121_backward_impl(ws, B, D, H, W, x, params, dout, lddout, grads, s, nullptr, nullptr, nullptr);
+}
+extern "C" int mms_dn121_backward_mt(void* ws, int B, int D, int H, int W, const float* x, const void* const* params,
+                                     const float* dout, int lddout, void* const* grads, hipStream_t s, hipStream_t side,
+                                     hipEvent_t ev_fork, hipEvent_t ev_join) {
+    if (!side || !ev_fork || !ev_join) return MMS_ERR_ARG;
+    return dn121_backward_impl(ws, B, D, H, W, x, params, dout, lddout, grads, s, side, ev_fork, ev_join);
 }

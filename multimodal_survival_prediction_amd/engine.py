@@ -95,6 +95,9 @@ class SurvivalEngine:
         self.step_count = torch.zeros(1, device=self.device)
         self.rng = torch.tensor([0x5EED, 0], dtype=torch.int32, device=self.device)
         self.ent_weight = gate_entropy_weight
+        self.side_stream = torch.cuda.Stream(device=self.device)
+        self.ev_fork, self.ev_join = torch.cuda.Event(), torch.cuda.Event()
+        self.ev_fork.record(); self.ev_join.record()          # materialise the handles
         self.plans = {}
         self.dropout_masks = {}      # parity mode: {lin index: [B, K] multiplicative mask}
         # device-side epoch accumulators: [sum loss*usable, n usable, sum entropy, n batches]
@@ -250,8 +253,10 @@ class SurvivalEngine:
             _lib.check(lib.mms_linear_bwd(ctypes.byref(P.lin_bwd[i]), st), "mms_linear_bwd")
         dfe = P.dbuf["feats"]
         dct = dfe[:, prog["ct_cols"]:]
-        _lib.check(lib.mms_dn121_backward(P.ws.data_ptr(), B, D, H, W, P.ct.data_ptr(), P.ptab, dct.data_ptr(),
-                                          dfe.stride(0), P.gtab, st), "mms_dn121_backward")
+        _lib.check(lib.mms_dn121_backward_mt(P.ws.data_ptr(), B, D, H, W, P.ct.data_ptr(), P.ptab, dct.data_ptr(),
+                                             dfe.stride(0), P.gtab, st, ctypes.c_void_p(self.side_stream.cuda_stream),
+                                             ctypes.c_void_p(self.ev_fork.cuda_event), ctypes.c_void_p(self.ev_join.cuda_event)),
+                   "mms_dn121_backward_mt")
 
     def _train_body(self, P, skip_if_unusable):
         """zero-grad -> forward -> Cox -> backward -> clip -> Adam, and the epoch accumulators."""
