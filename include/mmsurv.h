@@ -196,6 +196,30 @@ typedef struct Conv0BwdWP {                 // dW0[64][343] += sum_m bn0bwd(dbn0
     float* dgamma; float* dbeta;    // [64]
 } Conv0BwdWP;
 
+/* =========================== fallback CT encoder (R/scripts/training/final_multimodal.py:75-86) ==================
+ * 3 x [Conv3d(k3, s2, p1, bias) + BatchNorm3d + ReLU] (1->32->64->128) + AdaptiveAvgPool3d(1): what the reference
+ * runs when MONAI is absent.  Channels-last activations; each conv stores its raw output (+bias) and batch
+ * statistics, BN+ReLU of layer l is applied while layer l+1 (or the pooling) reads it. */
+typedef struct FbConvP {
+    const float* x; int Cin; Dims3 in; Dims3 out; int B;     // x: [B*in][Cin] raw output of the previous conv (or the volume, Cin=1)
+    int has_bn; BnSrc bn;                                    // BN+ReLU of the previous layer (has_bn=0 for the first conv)
+    const float* w; const float* bias; int Cout;             // torch layout [Cout][Cin][27], [Cout]
+    float* y;                                                // [B*out][Cout]
+    double* osum; double* osumsq;                            // [Cout] (nullptr in eval)
+    /* backward (fb_conv_bwd_w / fb_conv_bwd_x) */
+    const float* dy;                                         // [B*out][Cout] gradient w.r.t. y
+    float* dw; float* dbias;                                 // accumulated (atomics)
+    float* dbn_in; double* s1; double* s2;                   // [B*in][Cin] masked input gradient + BN-backward sums (bwd_x)
+    int msplit;
+} FbConvP;
+
+typedef struct FbPoolP {     /* BN+ReLU+global average pool and its backward */
+    const float* y; int C; int V; int B; BnSrc bn;           // [B*V][C]
+    float* out; int ldo;                                     // [B][ldo] first C columns
+    const float* dout; int lddout;
+    float* dbn; double* s1; double* s2;
+} FbPoolP;
+
 /* =========================== heads: small-batch MLP, gate, Cox, optimizer ============================== */
 /* Input prologue of a Linear layer: x' = dropout(relu(bn1d(x))) -- the BatchNorm1d/ReLU/Dropout that FOLLOW the
  * previous Linear in the reference's nn.Sequential (R/scripts/training/final_multimodal.py:93-117) are applied
@@ -304,6 +328,20 @@ int mms_pack_conv3(const float* w, float* wpf, float* wpb, hipStream_t s);
 int mms_pack_conv3_table(const void* table_dev, int nlayers, hipStream_t s);
 int mms_bn_running_update(const void* table_dev, int n, float momentum, hipStream_t s);
 
+
+/* ---- fallback encoder ops + whole-encoder driver (params: 12 pointers in named_parameters() order of the
+ *      nn.Sequential -- {0,1,3,4,6,7}.{weight,bias}; buffers: 3 x {running_mean, running_var, num_batches_tracked}) ---- */
+int mms_fb_conv_fwd(const FbConvP* p, hipStream_t s);
+int mms_fb_conv_bwd_w(const FbConvP* p, hipStream_t s);
+int mms_fb_conv_bwd_x(const FbConvP* p, hipStream_t s);
+int mms_fb_pool_fwd(const FbPoolP* p, hipStream_t s);
+int mms_fb_pool_bwd(const FbPoolP* p, hipStream_t s);
+int mms_fb_workspace_bytes(int B, int D, int H, int W, size_t* bytes);
+int mms_fb_init(void* ws, int B, int D, int H, int W, const void* const* buffers, hipStream_t s);
+int mms_fb_forward(void* ws, int B, int D, int H, int W, const float* x, const void* const* params,
+                   const void* const* buffers, float* out, int ldo, int train, hipStream_t s);
+int mms_fb_backward(void* ws, int B, int D, int H, int W, const float* x, const void* const* params,
+                    const float* dout, int lddout, void* const* grads, hipStream_t s);
 
 /* ---- heads ---- */
 int mms_linear_fwd(const LinearFwdP* p, hipStream_t s);        /* nn.Linear (+ preceding BN1d/ReLU/Dropout, + following ReLU) */

@@ -159,18 +159,25 @@ class SurvivalEngine:
         P.cox_out = torch.zeros(2, device=dev)
         P.lse = torch.zeros(B, device=dev)
         P.entropy = torch.zeros(1, device=dev)
-        # encoder
+        # encoder: DenseNet121-3D (MONAI topology) or the reference's 3-conv fallback
         enc = prog["encoder"]
-        nbytes = ctypes.c_size_t(0)
-        _lib.check(self.lib.mms_dn121_workspace_bytes(B, D, H, W, ctypes.byref(nbytes)), "mms_dn121_workspace_bytes")
-        P.ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        P.fallback = isinstance(enc, nn.Sequential)
         eparams = list(enc.parameters())
         ebufs = list(enc.buffers())
-        P.ptab = (ctypes.c_void_p * 364)(*[p.data_ptr() for p in eparams])
-        P.btab = (ctypes.c_void_p * 363)(*[b.data_ptr() for b in ebufs])
+        npar, nbuf = (12, 9) if P.fallback else (364, 363)
+        assert len(eparams) == npar and len(ebufs) == nbuf
+        nbytes = ctypes.c_size_t(0)
+        wsfn = self.lib.mms_fb_workspace_bytes if P.fallback else self.lib.mms_dn121_workspace_bytes
+        _lib.check(wsfn(B, D, H, W, ctypes.byref(nbytes)), "workspace_bytes")
+        P.ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        P.ptab = (ctypes.c_void_p * npar)(*[p.data_ptr() for p in eparams])
+        P.btab = (ctypes.c_void_p * nbuf)(*[b.data_ptr() for b in ebufs])
         gmap = {id(p): g for p, g in zip(self.params, self.gviews)}
-        P.gtab = (ctypes.c_void_p * 364)(*[gmap[id(p)].data_ptr() for p in eparams])
-        _lib.check(self.lib.mms_dn121_init(P.ws.data_ptr(), B, D, H, W, P.ptab, P.btab, ops.stream()), "mms_dn121_init")
+        P.gtab = (ctypes.c_void_p * npar)(*[gmap[id(p)].data_ptr() for p in eparams])
+        if P.fallback:
+            _lib.check(self.lib.mms_fb_init(P.ws.data_ptr(), B, D, H, W, P.btab, ops.stream()), "mms_fb_init")
+        else:
+            _lib.check(self.lib.mms_dn121_init(P.ws.data_ptr(), B, D, H, W, P.ptab, P.btab, ops.stream()), "mms_dn121_init")
         # head launches (train / eval variants)
         P.lin_fwd = {True: [], False: []}
         P.lin_bwd = []
@@ -227,8 +234,9 @@ class SurvivalEngine:
         B, (D, H, W) = P.B, P.dims
         feats = P.buf["feats"]
         out = feats[:, prog["ct_cols"]:]
-        _lib.check(lib.mms_dn121_forward(P.ws.data_ptr(), B, D, H, W, P.ct.data_ptr(), P.ptab, P.btab, out.data_ptr(),
-                                         feats.stride(0), 1 if train else 0, st), "mms_dn121_forward")
+        fwd = lib.mms_fb_forward if P.fallback else lib.mms_dn121_forward
+        _lib.check(fwd(P.ws.data_ptr(), B, D, H, W, P.ct.data_ptr(), P.ptab, P.btab, out.data_ptr(),
+                       feats.stride(0), 1 if train else 0, st), "encoder forward")
         lf = P.lin_fwd[train]
         n_pre = prog["n_pre"]
         for i in range(n_pre):
@@ -253,6 +261,10 @@ class SurvivalEngine:
             _lib.check(lib.mms_linear_bwd(ctypes.byref(P.lin_bwd[i]), st), "mms_linear_bwd")
         dfe = P.dbuf["feats"]
         dct = dfe[:, prog["ct_cols"]:]
+        if P.fallback:
+            _lib.check(lib.mms_fb_backward(P.ws.data_ptr(), B, D, H, W, P.ct.data_ptr(), P.ptab, dct.data_ptr(),
+                                           dfe.stride(0), P.gtab, st), "mms_fb_backward")
+            return
         _lib.check(lib.mms_dn121_backward_mt(P.ws.data_ptr(), B, D, H, W, P.ct.data_ptr(), P.ptab, dct.data_ptr(),
                                              dfe.stride(0), P.gtab, st, ctypes.c_void_p(self.side_stream.cuda_stream),
                                              ctypes.c_void_p(self.ev_fork.cuda_event), ctypes.c_void_p(self.ev_join.cuda_event)),

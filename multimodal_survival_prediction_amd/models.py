@@ -12,6 +12,21 @@ import torch.nn as nn
 from .densenet import DenseNet121
 from .engine import engine_of
 
+# The reference picks its CT encoder with a module-level switch set by `try: import monai`
+# (final_multimodal.py:34-42).  True -> DenseNet121-3D (MONAI's topology), False -> the in-file 3-conv fallback
+# (final_multimodal.py:75-86).  Both run as HIP kernels here; flip it before constructing a model.
+USE_MONAI = True
+
+
+def _ct_encoder(out_dim=128):
+    if USE_MONAI:
+        return DenseNet121(spatial_dims=3, in_channels=1, out_channels=out_dim, pretrained=False)
+    return nn.Sequential(        # parameter holder with the reference's keys (0,1,3,4,6,7); never called
+        nn.Conv3d(1, 32, 3, stride=2, padding=1), nn.BatchNorm3d(32), nn.ReLU(),
+        nn.Conv3d(32, 64, 3, stride=2, padding=1), nn.BatchNorm3d(64), nn.ReLU(),
+        nn.Conv3d(64, out_dim, 3, stride=2, padding=1), nn.BatchNorm3d(out_dim), nn.ReLU(),
+        nn.AdaptiveAvgPool3d(1))
+
 
 def _rna_encoder(rna_dim):
     return nn.Sequential(nn.Linear(rna_dim, 512), nn.BatchNorm1d(512), nn.ReLU(), nn.Dropout(0.3),
@@ -76,8 +91,8 @@ def _run(model, ct, rna, clinical, mask):
 class MultiModalSurvivalNet(nn.Module):
     def __init__(self, rna_dim=5005, clinical_dim=1):
         super().__init__()
-        self.ct_encoder = DenseNet121(spatial_dims=3, in_channels=1, out_channels=128, pretrained=False)
-        self.use_monai = True
+        self.ct_encoder = _ct_encoder(128)
+        self.use_monai = USE_MONAI
         self.ct_pool = nn.AdaptiveAvgPool3d(1)
         self.rna_encoder = _rna_encoder(rna_dim)
         self.clinical_encoder = nn.Sequential(nn.Linear(clinical_dim, 32), nn.ReLU())
@@ -91,8 +106,8 @@ class MultiModalSurvivalNet(nn.Module):
 class PartialModalityNet(nn.Module):
     def __init__(self, rna_dim=5005, clinical_dim=1):
         super().__init__()
-        self.ct_encoder = DenseNet121(spatial_dims=3, in_channels=1, out_channels=128, pretrained=False)
-        self.use_monai = True
+        self.ct_encoder = _ct_encoder(128)
+        self.use_monai = USE_MONAI
         self.ct_pool = nn.AdaptiveAvgPool3d(1)
         self.rna_encoder = _rna_encoder(rna_dim)
         self.clinical_encoder = nn.Sequential(nn.Linear(clinical_dim, 32), nn.ReLU())
@@ -114,9 +129,10 @@ class SimpleFusionModel(nn.Module):
             nn.Linear(rna_dim, 1024), nn.BatchNorm1d(1024), nn.ReLU(), nn.Dropout(0.3),
             nn.Linear(1024, 512), nn.BatchNorm1d(512), nn.ReLU(), nn.Dropout(0.3),
             nn.Linear(512, rna_feature_dim), nn.ReLU())
-        self.image_encoder = DenseNet121(spatial_dims=3, in_channels=1, out_channels=img_feature_dim, pretrained=False)
-        self.use_monai = True
-        self.image_pool = nn.AdaptiveAvgPool3d(1)
+        self.image_encoder = _ct_encoder(img_feature_dim)
+        self.use_monai = USE_MONAI
+        if USE_MONAI:
+            self.image_pool = nn.AdaptiveAvgPool3d(1)
         self.fusion = nn.Sequential(
             nn.Linear(rna_feature_dim + img_feature_dim, 256), nn.BatchNorm1d(256), nn.ReLU(), nn.Dropout(0.3),
             nn.Linear(256, 128), nn.ReLU(), nn.Dropout(0.2), nn.Linear(128, 1))
