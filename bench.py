@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--mode", choices=["fold", "ddp"], default="fold",
+                    help="N>1: 'fold' = K-fold units sharded over ranks, no collective (default); 'ddp' = one model, global "
+                         "batch N*B, flat gradient all-reduce (RCCL) per step")
     args = ap.parse_args()
 
     from multimodal_survival_prediction_amd import distributed as D
@@ -121,21 +124,24 @@ def main():
     cohort_cpu = data.make_cohort(n=109, dims=dims, rna_dim=rna_dim, seed=608, complete=True)
     cohort = data.cohort_to(cohort_cpu, dev)                      # resident in HBM before the timed region
     folds = data.kfold_indices(cohort["n"], 5, seed=42)
-    train_idx = torch.as_tensor(folds[rank % 5][0])
-    torch.manual_seed(42 + rank)
+    ddp = args.mode == "ddp" and world > 1
+    train_idx = torch.as_tensor(folds[0 if ddp else rank % 5][0])
+    torch.manual_seed(42 if ddp else 42 + rank)                   # ddp: identical initial weights on every rank
     model = models.MultiModalSurvivalNet(rna_dim=rna_dim).to(dev)
     opt = FusedOptimizer(model, lr=1e-4, weight_decay=1e-4, adamw=False)
     eng = opt.engine
     model.train()
-    nb = len(train_idx) // B                                      # full batches of the fold's train split
+    gb = B * world if ddp else B                                  # patients per step handled by the job's model(s)
+    nb = len(train_idx) // gb                                     # full (global) batches of the fold's train split
     gen = torch.Generator().manual_seed(7)
     order = train_idx[torch.randperm(len(train_idx), generator=gen)].to(dev)
 
     def step(i):
-        j = order[(i % nb) * B:(i % nb) * B + B]
+        o = (i % nb) * gb + (rank * B if ddp else 0)              # ddp: this rank's shard of the global batch
+        j = order[o:o + B]
         lab = cohort["label"][j]
         eng.train_step(cohort["image"][j], cohort["rnaseq"][j], cohort["clinical"][j], time=lab[:, 0], event=lab[:, 1],
-                       skip_if_unusable=True, use_graph=not args.no_graph)
+                       skip_if_unusable=True, use_graph=not args.no_graph, ddp_world=world if ddp else 1)
 
     for i in range(max(args.warmup, 2)):
         step(i)
@@ -159,7 +165,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "MultiModalSurvivalNet (DenseNet121-3D CT 64x64x32 + RNA-seq 5005 + clinical), "
                                    "109 synthetic complete patients, 5-fold split, batch 4, Adam lr 1e-4 wd 1e-4, clip 1.0",
-                       "global_batch": world * B, "parallelism": f"kfold-shard x{world} (fold k -> rank k mod N, no collective)",
+                       "global_batch": world * B, "parallelism": (f"ddp x{world} (flat gradient all-reduce per step, local BN + local Cox risk set)" if ddp else
+                                       f"kfold-shard x{world} (fold k -> rank k mod N, no collective)"),
                        "hip_graph": not args.no_graph, "mean_train_loss": stats["sum_loss"] / max(stats["n_batches"], 1)},
         }
         avg_t, avg_f = measure_dominant_kernel(B, dims, dev)

@@ -19,11 +19,16 @@ def env_world():
 
 
 def init(backend=None):
+    """-> (world, rank, local device index).  Backend: argument, else $MMS_DIST_BACKEND, else nccl (= RCCL) when a GPU is
+    present.  `gloo` lets several ranks share one card (rehearsals on a 1-GPU box); the local index wraps accordingly."""
     world, rank, local = env_world()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank, world_size=world)
+        backend = backend or os.environ.get("MMS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    if torch.cuda.is_available():
+        local = local % max(torch.cuda.device_count(), 1)
     return world, rank, local
 
 
@@ -44,7 +49,12 @@ def gather_fold_results(local_results, world):
 def allreduce_mean_(flat, world):
     """In-place mean of a flat gradient buffer over ranks (one bucket: the buffer is already contiguous)."""
     if world > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if flat.is_cuda and dist.get_backend() == "gloo":      # rehearsal path: gloo reduces through host memory
+            h = flat.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            flat.copy_(h)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat.div_(world)
     return flat
 
@@ -52,7 +62,7 @@ def allreduce_mean_(flat, world):
 def max_over_ranks(x, device):
     if not dist.is_initialized():
         return x
-    t = torch.tensor([x], dtype=torch.float64, device=device)
+    t = torch.tensor([x], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
