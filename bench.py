@@ -170,9 +170,15 @@ def main():
                        "hip_graph": not args.no_graph, "mean_train_loss": stats["sum_loss"] / max(stats["n_batches"], 1)},
         }
         avg_t, avg_f = measure_dominant_kernel(B, dims, dev)
+        traffic = None      # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_conv3bwdw_traffic.json")) as f:
+                traffic = json.load(f)["avg_hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         out["roofline"] = {"bound": "mfma", "kernel": "tile_gemm_kernel<Conv3BwdWOp> (weight gradient of the dense-layer 3x3x3 conv, 58 launches/step)",
                            "achieved": avg_f / avg_t / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": avg_f / avg_t / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                           "frac": avg_f / avg_t / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                            "avg_launch_us": avg_t * 1e6, "avg_flops_per_launch": avg_f}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cohort_cpu, torch.as_tensor(folds[0][0]), args.cpu_steps, B)
