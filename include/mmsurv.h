@@ -187,6 +187,7 @@ typedef struct PoolBwdP {                   // maxpool backward + relu0 mask -> 
     const float* y0; BnSrc bn;
     float* dbn;                     // [B*in][64]
     double* s1; double* s2;         // [64]
+    const int* coords;              // optional [B*in] packed (d,h,w) of the conv0 grid (saves the per-voxel integer divisions)
 } PoolBwdP;
 
 typedef struct Conv0BwdWP {                 // dW0[64][343] += sum_m bn0bwd(dbn0)[m][n] * x[patch(m,k)]

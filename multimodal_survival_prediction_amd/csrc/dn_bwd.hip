@@ -596,8 +596,14 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolBwdP p) {
     for (int it = 0; it < 64; ++it) {
         const int m = blockIdx.x * 256 + it * 4 + vr;
         if (m >= Min) break;
-        const int b = m / vox_in, r = m % vox_in;
-        const int id = r / (p.in.H * p.in.W), ih = (r / p.in.W) % p.in.H, iw = r % p.in.W;
+        int b, id, ih, iw;
+        if (p.coords) {
+            unpack_dhw(p.coords[m], id, ih, iw);
+            b = (m - ((id * p.in.H + ih) * p.in.W + iw)) / vox_in;
+        } else {
+            const int r = m % vox_in;
+            b = m / vox_in; id = r / (p.in.H * p.in.W); ih = (r / p.in.W) % p.in.H; iw = r % p.in.W;
+        }
         float g = 0;
         // windows od with 2*od-1 <= id <= 2*od+1
         for (int od = id >> 1; od <= (id + 1) >> 1; ++od) {

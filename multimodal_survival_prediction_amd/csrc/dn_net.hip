@@ -351,7 +351,7 @@ static int dn121_backward_impl(void* ws, int B, int D, int H, int W, const float
         } else {       // stem
             const BnSrc bn0 = mk_bn(ws, P.st_y0, 64, prm, IDX.n0w, nullptr, 0, P.M0, 1);
             PoolBwdP pb{dslab, CTOT[0], at<uint8_t>(ws, P.argmax), P.g[0], P.g0, B, at<float>(ws, P.y0), bn0,
-                        at<float>(ws, P.dbn0), at<double>(ws, P.bb_y0), at<double>(ws, P.bb_y0) + 64};
+                        at<float>(ws, P.dbn0), at<double>(ws, P.bb_y0), at<double>(ws, P.bb_y0) + 64, at<int>(ws, P.coords0)};
             TRY(mms_pool_bwd(&pb, s));
             int ms0 = P.M0 / 1024; if (ms0 < 1) ms0 = 1; if (ms0 > 64) ms0 = 64;
             Conv0BwdWP cw{at<float>(ws, P.dbn0), at<float>(ws, P.y0), bn0, bbsrc(P.bb_y0, 64), x, P.in, P.g0,

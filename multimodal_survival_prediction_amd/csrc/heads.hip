@@ -68,7 +68,25 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const LinearFwdP p) {
     float acc[MM];
 #pragma unroll
     for (int m = 0; m < MM; ++m) acc[m] = 0.f;
-    for (int k = lane; k < p.K; k += 64) {
+    int kstart = lane;
+    const bool plain = !p.pro.bn && !(p.pro.train && (p.pro.drop_mask || p.pro.drop_p > 0.f));
+    if (plain) {     // raw input (first layers: 5005-wide RNA-seq rows): 4 independent (w, x[0..M)) load groups in flight
+        const float* wr = p.w + (size_t)n * p.K;
+        for (; kstart + 192 < p.K; kstart += 256) {
+            float w4[4], x4[4][MM];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                w4[u] = wr[kstart + 64 * u];
+#pragma unroll
+                for (int m = 0; m < MM; ++m) x4[u][m] = m < p.M ? p.x[(size_t)m * p.ldx + kstart + 64 * u] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int m = 0; m < MM; ++m) acc[m] = fmaf(w4[u], x4[u][m], acc[m]);
+        }
+    }
+    for (int k = kstart; k < p.K; k += 64) {
         float x[MM];
 #pragma unroll
         for (int m = 0; m < MM; ++m) x[m] = m < p.M ? p.x[(size_t)m * p.ldx + k] : 0.f;

@@ -129,9 +129,9 @@ def head_bwd(dout, pooled, slab, C, B, V, bn, w, dw, dbias, dgamma, dbeta, dslab
     call("mms_head_bwd", p)
 
 
-def pool_bwd(dslab, argmax, out_dims, in_dims, B, y0, bn, dbn, s1, s2):
+def pool_bwd(dslab, argmax, out_dims, in_dims, B, y0, bn, dbn, s1, s2, coords=None):
     p = _S()["PoolBwdP"](ptr(dslab), dslab.stride(0), ptr(argmax), dims3(out_dims), dims3(in_dims), B, ptr(y0), bn,
-                         ptr(dbn), ptr(s1), ptr(s2))
+                         ptr(dbn), ptr(s1), ptr(s2), ptr(coords))
     call("mms_pool_bwd", p)
 
 

@@ -137,7 +137,7 @@ def test_stem_backward(ops, B, dims, ms):
     dslab = torch.zeros(M1, 256, device=DEV); dslab[:, :64] = _d(cl(dout))
     dbn0 = torch.empty(M0, 64, device=DEV)
     a1, a2 = stats(DEV, 64)
-    ops.pool_bwd(dslab, am, pd, od, B, y0d, bn, dbn0, a1, a2)
+    ops.pool_bwd(dslab, am, pd, od, B, y0d, bn, dbn0, a1, a2, coords if ms > 1 else None)    # with / without the coordinate table
     dw, dg, db = torch.zeros_like(w0), torch.zeros(64, device=DEV), torch.zeros(64, device=DEV)
     ops.conv0_bwd_weight(dbn0, y0d, bn, ops.bnbwd(a1, a2), xd, dims, od, coords, dw, ms, dg, db)
     torch.cuda.synchronize()
