@@ -167,6 +167,22 @@ def test_cox_valid_mask_equals_subset(ops):
     np.testing.assert_allclose(dh.cpu().numpy(), g, rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("n", [2048, 8192])
+def test_cox_large_risk_set_vs_fp64_oracle(ops, n):
+    """BASELINE config 5 (large risk-set stress): O(n^2) kernel pair vs the fp64 numpy oracle, tolerance 1e-4."""
+    from oracle.losses import cox_npll_grad_np, cox_npll_np
+    rng = np.random.default_rng(n)
+    h = rng.normal(size=n).astype(np.float32)
+    t = (rng.exponential(1000, n) + 1 + np.arange(n) * 1e-3).astype(np.float32)
+    e = (rng.random(n) < 0.57).astype(np.float32)
+    out, dh = ops.cox_fwd_bwd(*(torch.tensor(a).to(DEV) for a in (h, t, e)))
+    torch.cuda.synchronize()
+    ref = cox_npll_np(h, e, t)
+    assert abs(out[0].item() - ref) <= 1e-4 * max(1.0, abs(ref)) and out[1].item() == 1.0
+    g = cox_npll_grad_np(h, e, t)
+    assert float(np.abs(dh.cpu().numpy() - g).max()) <= 1e-4 * float(np.abs(g).max())
+
+
 def test_cindex_golden(ops):
     z = np.load(f"{G}/g2_cindex.npz")
     for n in ("n4", "n23", "n116", "n1639", "n5none"):
