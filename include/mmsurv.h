@@ -76,8 +76,9 @@ typedef struct Conv3FwdP {
     float* out; int ldo;            // slab + coff, row pitch
     BnSrc bn;                       // over 128 channels of y1
     double* osum; double* osumsq;   // [32] (nullptr in eval)
-    float* partial;                 // optional scratch [27][M][32]: split the 27 taps over workgroups (small M), then
-                                    // a reduce kernel sums them, writes the slab columns and the statistics
+    float* partial;                 // optional scratch [nsplit][M][32]: split the 27 taps over nsplit workgroups per tile,
+                                    // then a reduce kernel sums them, writes the slab columns and the statistics
+    int nsplit;                     // 1..27 (used when partial != null); workgroup z handles taps [z*ceil(27/nsplit), ...)
 } Conv3FwdP;
 
 // ---- conv0: Conv3d(1,64,k7,s2,p3,no bias) -------------------------------------------------------------
@@ -126,7 +127,8 @@ typedef struct Conv3BwdDataP {
     BnSrc bn;                       // bn2
     float* dbn;                     // [M][128] out
     double* s1; double* s2;         // [128] out (atomics)
-    float* partial;                 // optional scratch [27][M][128]: tap split as in Conv3FwdP
+    float* partial;                 // optional scratch [nsplit][M][128]: tap split as in Conv3FwdP
+    int nsplit;
 } Conv3BwdDataP;
 
 // conv3 backward-weight: dW[cout][cin][tap] += sum_m relu(bn(y1))[nbr(m,tap)][cin] * dz[m][cout]

@@ -40,11 +40,12 @@ struct Conv3BwdDataOp {
     typedef float4 BRaw;
     float* ex;
     // TK = 32 = the 32 output channels of one tap; per-thread constants as in Conv3FwdOp (taps mirrored)
-    int voff, woff[4], tapoff_b, wsoff;
+    int voff, woff[4], tapoff_b, wsoff, p_nsplit;
     unsigned m9, sel;
     buf_rsrc_t rz, rw;
     __device__ void setup(const Params& p, int m0, int, int, float* extra, int tid) {
         ex = extra;
+        p_nsplit = p.nsplit > 0 ? p.nsplit : 27;
         if (tid < 128) {
             float mu, rstd;
             bn_mean_rstd(p.bn, tid, mu, rstd);
@@ -60,7 +61,10 @@ struct Conv3BwdDataOp {
         for (int i = 0; i < 4; ++i) woff[i] = (((tid >> 3) + 32 * i) * 864 + co) * 4;
     }
     __device__ void krange(const Params&, int z, int& kb, int& ke) {
-        if (SPLIT) { kb = z * 32; ke = kb + 32; } else { kb = 0; ke = 27 * 32; }
+        if (SPLIT) {
+            const int tpw = (27 + p_nsplit - 1) / p_nsplit;
+            kb = z * tpw * 32; ke = kb + tpw * 32; if (ke > 27 * 32) ke = 27 * 32;
+        } else { kb = 0; ke = 27 * 32; }
     }
     __device__ void step(const Params& p, int k0) {
         const int tap = k0 >> 5, kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(256) void conv3_bwd_data_reduce_kernel(const Conv3B
     for (int m = blockIdx.x * 4 + rg; m < mend; m += 2) {
         float v[27];
 #pragma unroll
-        for (int t = 0; t < 27; ++t) v[t] = p.partial[((size_t)t * p.M + m) * 128 + c];    // 27 loads in flight
+        for (int t = 0; t < 27; ++t) v[t] = t < p.nsplit ? p.partial[((size_t)t * p.M + m) * 128 + c] : 0.f;    // loads in flight
         float a = 0.f;
 #pragma unroll
         for (int t = 0; t < 27; ++t) a += v[t];
@@ -139,7 +143,8 @@ extern "C" int mms_conv3_bwd_data(const Conv3BwdDataP* pp, hipStream_t s) {
     const Conv3BwdDataP& p = *pp;
     if (p.M <= 0 || p.lddz % 4 != 0) return MMS_ERR_ARG;
     if (p.partial) {
-        int rc = launch_tile_gemm<Conv3BwdDataOp<true>>(p, dim3((p.M + 31) / 32, 1, 27), s);
+        if (p.nsplit < 1 || p.nsplit > 27 || (p.nsplit - 1) * ((27 + p.nsplit - 1) / p.nsplit) >= 27) return MMS_ERR_ARG;
+        int rc = launch_tile_gemm<Conv3BwdDataOp<true>>(p, dim3((p.M + 31) / 32, 1, p.nsplit), s);
         if (rc != MMS_OK) return rc;
         MMS_LAUNCH(conv3_bwd_data_reduce_kernel, dim3((p.M + 3) / 4), dim3(256), 0, s, p);
         return mms_check_launch();

@@ -147,9 +147,10 @@ struct Conv3FwdOp {
     int voff[4], woff[4];
     unsigned m9[4];
     buf_rsrc_t ry, rw;
-    int tapoff_b, wsoff;
+    int tapoff_b, wsoff, p_nsplit;
     unsigned sel;
     __device__ void setup(const Params& p, int m0, int, int, float*, int tid) {
+        p_nsplit = p.nsplit > 0 ? p.nsplit : 27;
         const int c0 = (tid & 31) * 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -169,7 +170,10 @@ struct Conv3FwdOp {
         }
     }
     __device__ void krange(const Params&, int z, int& kb, int& ke) {
-        if (SPLIT) { kb = z * 128; ke = kb + 128; } else { kb = 0; ke = 27 * 128; }
+        if (SPLIT) {
+            const int tpw = (27 + p_nsplit - 1) / p_nsplit;
+            kb = z * tpw * 128; ke = kb + tpw * 128; if (ke > 27 * 128) ke = 27 * 128;
+        } else { kb = 0; ke = 27 * 128; }
     }
     __device__ void step(const Params& p, int k0) {
         const int tap = k0 >> 7, kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(256) void conv3_fwd_reduce_kernel(const Conv3FwdP p
     for (int m = blockIdx.x * 8 + rg; m < p.M && m < blockIdx.x * 8 + 8; m += 8) {
         float v[27];
 #pragma unroll
-        for (int t = 0; t < 27; ++t) v[t] = p.partial[((size_t)t * p.M + m) * 32 + c];    // 27 loads in flight
+        for (int t = 0; t < 27; ++t) v[t] = t < p.nsplit ? p.partial[((size_t)t * p.M + m) * 32 + c] : 0.f;    // loads in flight
         float a = 0.f;
 #pragma unroll
         for (int t = 0; t < 27; ++t) a += v[t];
@@ -233,7 +237,10 @@ extern "C" int mms_conv3_fwd(const Conv3FwdP* pp, hipStream_t s) {
     const Conv3FwdP& p = *pp;
     if (p.M <= 0 || p.ldo % 4 != 0) return MMS_ERR_ARG;
     if (p.partial) {
-        int rc = launch_tile_gemm<Conv3FwdOp<true>>(p, dim3((p.M + 31) / 32, 1, 27), s);
+        if (p.nsplit < 1 || p.nsplit > 27) return MMS_ERR_ARG;
+        const int tpw = (27 + p.nsplit - 1) / p.nsplit;
+        if ((p.nsplit - 1) * tpw >= 27) return MMS_ERR_ARG;       // every workgroup must own at least one tap
+        int rc = launch_tile_gemm<Conv3FwdOp<true>>(p, dim3((p.M + 31) / 32, 1, p.nsplit), s);
         if (rc != MMS_OK) return rc;
         MMS_LAUNCH(conv3_fwd_reduce_kernel, dim3((p.M + 7) / 8), dim3(256), 0, s, p);
         return mms_check_launch();

@@ -72,7 +72,10 @@ bool make_plan(Plan& P, int B, int D, int H, int W) {
     P.dbn_in = take(mx);
     P.dbn0 = take((size_t)P.M0 * 64 * 4);
     P.pooled = take((size_t)B * 1024 * 4);
-    P.partial = take((size_t)27 * (P.M[1] > 1024 ? 1024 : P.M[1]) * 128 * 4);     // tap-split scratch (blocks with M <= 1024)
+    {   // tap-split scratch: 27 partials for blocks with M <= 1024, NSPLIT_BIG for larger ones
+        size_t a = (size_t)27 * (P.M[1] > 1024 ? 1024 : P.M[1]) * 128 * 4, b2 = (size_t)3 * P.M[0] * 128 * 4;
+        P.partial = take(a > b2 ? a : b2);
+    }
     P.tab_pack = take(sizeof(PackEntry) * NLAYER);
     P.tab_bn = take(sizeof(BnRunEntry) * NBN);
     P.stats_begin = o;
@@ -141,7 +144,7 @@ extern "C" int mms_head_bwd(const HeadBwdP*, hipStream_t);
 extern "C" int mms_pool_bwd(const PoolBwdP*, hipStream_t);
 extern "C" int mms_conv0_bwd_weight(const Conv0BwdWP*, hipStream_t);
 
-#define TRY(x) do { int rc_ = (x); if (rc_ != MMS_OK) return rc_; } while (0)
+#define TRY(x) do { int rc_ = (x); if (rc_ != MMS_OK) { fprintf(stderr, "mmsurv: %s -> %d (dn_net.hip:%d)\n", #x, rc_, __LINE__); return rc_; } } while (0)
 
 extern "C" int mms_dn121_workspace_bytes(int B, int D, int H, int W, size_t* bytes) {
     Plan P;
@@ -239,7 +242,7 @@ extern "C" int mms_dn121_forward(void* ws, int B, int D, int H, int W, const flo
             Conv3FwdP c3{at<float>(ws, P.y1[l]), at<int>(ws, P.coords[b]), P.g[b], P.M[b], at<float>(ws, P.wpf[l]),
                          slab + C, CTOT[b], mk_bn(ws, P.st_y1[l], 128, prm, ip + 3, buffers, IDX.bn_layer2[l], P.M[b], train),
                          st(P.st_slab[b], CTOT[b], C, false), st(P.st_slab[b], CTOT[b], C, true),
-                         (b > 0 && P.M[b] <= 1024) ? at<float>(ws, P.partial) : nullptr};
+                         P.M[b] <= 1024 ? at<float>(ws, P.partial) : nullptr, 27};   // (3-way split at M = 8192 measured slower)
             TRY(mms_conv3_fwd(&c3, s));
         }
         if (b < 3) {
@@ -290,7 +293,7 @@ static int dn121_backward_impl(void* ws, int B, int D, int H, int W, const float
             Conv3BwdDataP bd{dslab + C, CTOT[b], at<int>(ws, P.coords[b]), P.g[b], M, at<float>(ws, P.wpb[l]),
                              at<float>(ws, P.y1[l]), bn2, at<float>(ws, P.dbn_mid),
                              at<double>(ws, P.bb_y1[l]), at<double>(ws, P.bb_y1[l]) + 128,
-                             (b > 0 && M <= 1024) ? at<float>(ws, P.partial) : nullptr};
+                             M <= 1024 ? at<float>(ws, P.partial) : nullptr, 27};
             if (side && side_pending) {       // the previous layer's weight kernels read dbn_mid: join before overwriting it
                 if (hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) return MMS_ERR_LAUNCH;
                 side_pending = false;

@@ -47,10 +47,10 @@ def conv1_fwd(x, K, w, y, bn, M, osum=None, osumsq=None, pool=False, in_dims=(0,
     call("mms_conv1_fwd", p)
 
 
-def conv3_fwd(y1, coords, dims, wp, out, bn, osum=None, osumsq=None, partial=None):
+def conv3_fwd(y1, coords, dims, wp, out, bn, osum=None, osumsq=None, partial=None, nsplit=27):
     M = y1.shape[0]
     p = _S()["Conv3FwdP"](ptr(y1), ptr(coords), dims3(dims), M, ptr(wp), ptr(out), out.stride(0), bn,
-                          ptr(osum), ptr(osumsq), ptr(partial))
+                          ptr(osum), ptr(osumsq), ptr(partial), nsplit)
     call("mms_conv3_fwd", p)
 
 
@@ -83,9 +83,9 @@ def bnbwd(s1, s2):
     return _S()["BnBwd"](ptr(s1), ptr(s2))
 
 
-def conv3_bwd_data(dz, coords, dims, wpb, y1, bn, dbn, s1, s2, partial=None):
+def conv3_bwd_data(dz, coords, dims, wpb, y1, bn, dbn, s1, s2, partial=None, nsplit=27):
     p = _S()["Conv3BwdDataP"](ptr(dz), dz.stride(0), ptr(coords), dims3(dims), y1.shape[0], ptr(wpb), ptr(y1), bn,
-                              ptr(dbn), ptr(s1), ptr(s2), ptr(partial))
+                              ptr(dbn), ptr(s1), ptr(s2), ptr(partial), nsplit)
     call("mms_conv3_bwd_data", p)
 
 

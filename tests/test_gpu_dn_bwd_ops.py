@@ -22,7 +22,7 @@ def _d(t):
 
 @pytest.mark.parametrize("B,dims,C,Ctot,ms", [(2, (4, 4, 2), 64, 256, 1), (4, (8, 8, 4), 96, 256, 4), (3, (2, 2, 1), 512, 1024, 1),
                                               (2, (16, 16, 8), 224, 256, 16)])
-@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("split", [0, 27, 3])
 def test_dense_layer_backward(ops, B, dims, C, Ctot, ms, split):
     """One _DenseLayer: norm1-relu-conv1-norm2-relu-conv2 + cat; gradient w.r.t. every parameter and the input slab."""
     torch.manual_seed(0)
@@ -57,7 +57,7 @@ def test_dense_layer_backward(ops, B, dims, C, Ctot, ms, split):
     dbn_mid = torch.empty(M, 128, device=DEV)
     a1, a2 = stats(DEV, 128)
     part = torch.empty(27 * M * 128, device=DEV) if split else None
-    ops.conv3_bwd_data(dslab[:, C:C + 32], coords, dims, wpb, y1d, bn2, dbn_mid, a1, a2, part)
+    ops.conv3_bwd_data(dslab[:, C:C + 32], coords, dims, wpb, y1d, bn2, dbn_mid, a1, a2, part, split or 27)
     dw2 = torch.zeros_like(w2)
     ops.conv3_bwd_weight(y1d, coords, dims, bn2, dslab[:, C:C + 32], dw2, ms)
     dw1 = torch.zeros_like(w1)

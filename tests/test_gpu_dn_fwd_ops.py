@@ -73,7 +73,7 @@ def test_transition_fwd(ops, B, dims, K):
 
 @pytest.mark.parametrize("B,dims", [(4, (16, 16, 8)), (2, (8, 8, 4)), (4, (4, 4, 2)), (4, (2, 2, 1)), (3, (5, 3, 2))])
 @pytest.mark.parametrize("train", [True, False])
-@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("split", [0, 27, 3, 5])
 def test_conv3_fwd(ops, B, dims, train, split):
     torch.manual_seed(2)
     M = B * dims[0] * dims[1] * dims[2]
@@ -92,7 +92,7 @@ def test_conv3_fwd(ops, B, dims, train, split):
     slab = torch.zeros(M, 256, device=DEV)
     os_, oq = stats(DEV, 32)
     part = torch.empty(27 * M * 32, device=DEV) if split else None      # tap-split path: partial tiles + reduce kernel
-    ops.conv3_fwd(y1d, coords, dims, wpf, slab[:, 64:96], bn, os_ if train else None, oq if train else None, part)
+    ops.conv3_fwd(y1d, coords, dims, wpf, slab[:, 64:96], bn, os_ if train else None, oq if train else None, part, split or 27)
     torch.cuda.synchronize()
     assert_close(slab[:, 64:96], cl(ref), 1e-4, "conv3 out")
     assert float(slab[:, :64].abs().max()) == 0.0 and float(slab[:, 96:].abs().max()) == 0.0
