@@ -2,10 +2,16 @@
 """Headline benchmark: patients/sec of the multimodal survival training hot path on MI355X.
 
 Workload (BASELINE.json configs[1]): full MultiModalSurvivalNet (DenseNet121-3D CT 64x64x32 + RNA-seq 5005 +
-clinical), 109 synthetic complete-modality patients, batch 4, fold 1 of a 5-fold split, Adam(lr 1e-4, wd 1e-4),
-clip_grad_norm_(1.0).  A "step" is one pass of the hot path over one batch of 4 patients: zero-grad, forward,
-Cox partial likelihood, backward, clip, Adam -- all inside one replayed HIP graph.  The cohort is resident in HBM
-before the timed region; per step the batch is gathered device-to-device into the graph's static buffers.
+clinical), 109 synthetic complete-modality patients, batch 4, 5-fold split, Adam(lr 1e-4, wd 1e-4),
+clip_grad_norm_(1.0).  A "step" is one pass of the hot path over one batch of 4 patients of one fold's model:
+zero-grad, forward, Cox partial likelihood, backward, clip, Adam -- all inside one replayed HIP graph.  The cohort is
+resident in HBM before the timed region; per step the batch is gathered device-to-device into the graph's static buffers.
+
+K-fold cross-validation trains 5 independent models, and at batch 4 one model's step is a chain of ~570 small dependent
+kernels that leaves most of the 256 CUs idle.  Each rank therefore trains F folds CONCURRENTLY (default F = 3, measured
+optimum with the default 4 hardware queues): one model + optimiser + step graph + HIP stream per fold, the K timed steps
+dealt round-robin over the F fold models.  Per-model semantics are untouched (each step is the same graph as with F = 1);
+`config.single_chain_patients_per_s` reports the F = 1 rate measured in the same run.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]            (N>1: launched by torch.distributed.run)
 N>1 shards K-fold units over ranks (fold k -> rank k mod N, no data-path collective): weak scaling.
@@ -100,6 +106,8 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--concurrent-folds", type=int, default=3,
+                    help="fold models trained concurrently per GPU, one HIP stream + step graph each (mode fold)")
     ap.add_argument("--mode", choices=["fold", "ddp"], default="fold",
                     help="N>1: 'fold' = K-fold units sharded over ranks, no collective (default); 'ddp' = one model, global "
                          "batch N*B, flat gradient all-reduce (RCCL) per step")
@@ -125,37 +133,50 @@ def main():
     cohort = data.cohort_to(cohort_cpu, dev)                      # resident in HBM before the timed region
     folds = data.kfold_indices(cohort["n"], 5, seed=42)
     ddp = args.mode == "ddp" and world > 1
-    train_idx = torch.as_tensor(folds[0 if ddp else rank % 5][0])
-    torch.manual_seed(42 if ddp else 42 + rank)                   # ddp: identical initial weights on every rank
-    model = models.MultiModalSurvivalNet(rna_dim=rna_dim).to(dev)
-    opt = FusedOptimizer(model, lr=1e-4, weight_decay=1e-4, adamw=False)
-    eng = opt.engine
-    model.train()
-    gb = B * world if ddp else B                                  # patients per step handled by the job's model(s)
-    nb = len(train_idx) // gb                                     # full (global) batches of the fold's train split
-    gen = torch.Generator().manual_seed(7)
-    order = train_idx[torch.randperm(len(train_idx), generator=gen)].to(dev)
+    F = 1 if ddp else max(1, args.concurrent_folds)
+    engines, streams, orders = [], [], []
+    for f in range(F):
+        fold = 0 if ddp else (rank * F + f) % 5
+        train_idx = torch.as_tensor(folds[fold][0])
+        torch.manual_seed(42 if ddp else 42 + rank * F + f)       # ddp: identical initial weights on every rank
+        model = models.MultiModalSurvivalNet(rna_dim=rna_dim).to(dev)
+        model.train()
+        engines.append(FusedOptimizer(model, lr=1e-4, weight_decay=1e-4, adamw=False).engine)
+        streams.append(torch.cuda.Stream(device=dev))
+        gen = torch.Generator().manual_seed(7 + f)
+        orders.append(train_idx[torch.randperm(len(train_idx), generator=gen)].to(dev))
+    gb = B * world if ddp else B                                  # patients per step handled by one model
 
-    def step(i):
-        o = (i % nb) * gb + (rank * B if ddp else 0)              # ddp: this rank's shard of the global batch
+    def step(i, nf=F):
+        f = i % nf
+        order = orders[f]
+        nb = len(order) // gb                                     # full (global) batches of the fold's train split
+        k = (i // nf) % nb
+        o = k * gb + (rank * B if ddp else 0)                     # ddp: this rank's shard of the global batch
         j = order[o:o + B]
         lab = cohort["label"][j]
-        eng.train_step(cohort["image"][j], cohort["rnaseq"][j], cohort["clinical"][j], time=lab[:, 0], event=lab[:, 1],
-                       skip_if_unusable=True, use_graph=not args.no_graph, ddp_world=world if ddp else 1)
+        with torch.cuda.stream(streams[f]):
+            engines[f].train_step(cohort["image"][j], cohort["rnaseq"][j], cohort["clinical"][j], time=lab[:, 0],
+                                  event=lab[:, 1], skip_if_unusable=True, use_graph=not args.no_graph,
+                                  ddp_world=world if ddp else 1)
 
-    for i in range(max(args.warmup, 2)):
+    def timed(nsteps, nf):
+        torch.cuda.synchronize()
+        D.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(nsteps):
+            step(i, nf)
+        torch.cuda.synchronize()
+        D.barrier()
+        torch.cuda.synchronize()
+        return D.max_over_ranks(time.perf_counter() - t0, dev)
+
+    for i in range(max(args.warmup, 3 * F)):                      # includes each fold model's graph capture
         step(i)
-    torch.cuda.synchronize()
-    D.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    D.barrier()
-    torch.cuda.synchronize()
-    dt = D.max_over_ranks(time.perf_counter() - t0, dev)
-    stats = eng.epoch_stats()
+    dt = timed(args.steps, F)
+    dt1 = timed(max(args.steps // 3, 10), 1) / max(args.steps // 3, 10) if F > 1 else dt / args.steps   # single chain
+    stats = engines[0].epoch_stats()
 
     if rank == 0:
         out = {
@@ -166,7 +187,8 @@ def main():
             "config": {"workload": "MultiModalSurvivalNet (DenseNet121-3D CT 64x64x32 + RNA-seq 5005 + clinical), "
                                    "109 synthetic complete patients, 5-fold split, batch 4, Adam lr 1e-4 wd 1e-4, clip 1.0",
                        "global_batch": world * B, "parallelism": (f"ddp x{world} (flat gradient all-reduce per step, local BN + local Cox risk set)" if ddp else
-                                       f"kfold-shard x{world} (fold k -> rank k mod N, no collective)"),
+                                       f"kfold-shard x{world} ranks x {F} concurrent fold models per GPU (one stream + step graph each, no collective)"),
+                       "concurrent_folds": F, "single_chain_patients_per_s": world * B / dt1, "single_chain_ms_per_step": dt1 * 1e3,
                        "hip_graph": not args.no_graph, "mean_train_loss": stats["sum_loss"] / max(stats["n_batches"], 1)},
         }
         avg_t, avg_f = measure_dominant_kernel(B, dims, dev)
