@@ -8,8 +8,8 @@ zero-grad, forward, Cox partial likelihood, backward, clip, Adam -- all inside o
 resident in HBM before the timed region; per step the batch is gathered device-to-device into the graph's static buffers.
 
 K-fold cross-validation trains 5 independent models, and at batch 4 one model's step is a chain of ~570 small dependent
-kernels that leaves most of the 256 CUs idle.  Each rank therefore trains F folds CONCURRENTLY (default F = 3, measured
-optimum with the default 4 hardware queues): one model + optimiser + step graph + HIP stream per fold, the K timed steps
+kernels that leaves most of the 256 CUs idle.  Each rank therefore trains F folds CONCURRENTLY (default F = 4 = one per
+hardware queue, the measured optimum): one model + optimiser + step graph + HIP stream per fold, the K timed steps
 dealt round-robin over the F fold models.  Per-model semantics are untouched (each step is the same graph as with F = 1);
 `config.single_chain_patients_per_s` reports the F = 1 rate measured in the same run.
 
@@ -106,7 +106,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--concurrent-folds", type=int, default=3,
+    ap.add_argument("--concurrent-folds", type=int, default=4,
                     help="fold models trained concurrently per GPU, one HIP stream + step graph each (mode fold)")
     ap.add_argument("--mode", choices=["fold", "ddp"], default="fold",
                     help="N>1: 'fold' = K-fold units sharded over ranks, no collective (default); 'ddp' = one model, global "

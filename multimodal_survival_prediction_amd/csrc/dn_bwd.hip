@@ -591,15 +591,18 @@ extern "C" int mms_head_bwd(const HeadBwdP* pp, hipStream_t s) {
 // one workgroup = 256 conv0-grid voxels x 64 channels
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolBwdP p) {
+    // workgroup = 64 conv0-grid voxels x 64 channels.  Each input voxel is covered by 1 or 2 windows per axis
+    // (od in {id>>1, (id+1)>>1}; they coincide for even id): all 8 candidates are loaded unconditionally from clamped
+    // addresses and selected afterwards (the duplicate candidate of an even coordinate is masked out).
     __shared__ double red[2][4][64];
     const int c = threadIdx.x & 63, vr = threadIdx.x >> 6;
     float mu, rs;
     bn_mean_rstd(p.bn, c, mu, rs);
     const float ga = p.bn.gamma[c], be = p.bn.beta[c];
-    const int vox_in = p.in.D * p.in.H * p.in.W, Min = p.B * vox_in;
+    const int vox_in = p.in.D * p.in.H * p.in.W, Min = p.B * vox_in, vox_out = p.out.D * p.out.H * p.out.W;
     double s1 = 0, s2 = 0;
-    for (int it = 0; it < 64; ++it) {
-        const int m = blockIdx.x * 256 + it * 4 + vr;
+    for (int it = 0; it < 16; ++it) {
+        const int m = blockIdx.x * 64 + it * 4 + vr;
         if (m >= Min) break;
         int b, id, ih, iw;
         if (p.coords) {
@@ -609,21 +612,29 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolBwdP p) {
             const int r = m % vox_in;
             b = m / vox_in; id = r / (p.in.H * p.in.W); ih = (r / p.in.W) % p.in.H; iw = r % p.in.W;
         }
-        float g = 0;
-        // windows od with 2*od-1 <= id <= 2*od+1
-        for (int od = id >> 1; od <= (id + 1) >> 1; ++od) {
-            if (od >= p.out.D) continue;
-            for (int oh = ih >> 1; oh <= (ih + 1) >> 1; ++oh) {
-                if (oh >= p.out.H) continue;
-                for (int ow = iw >> 1; ow <= (iw + 1) >> 1; ++ow) {
-                    if (ow >= p.out.W) continue;
-                    const int tap = ((id - 2 * od + 1) * 3 + (ih - 2 * oh + 1)) * 3 + (iw - 2 * ow + 1);
-                    const size_t mo = ((size_t)(b * p.out.D + od) * p.out.H + oh) * p.out.W + ow;
-                    if (p.argmax[mo * 64 + c] == tap) g += p.dslab[mo * p.ld + c];
-                }
-            }
+        const float y = p.y0[(size_t)m * 64 + c];
+        uint8_t am[8];
+        float gv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int od = min((id + (k >> 2)) >> 1, p.out.D - 1), oh = min((ih + ((k >> 1) & 1)) >> 1, p.out.H - 1),
+                      ow = min((iw + (k & 1)) >> 1, p.out.W - 1);
+            const size_t mo = (size_t)b * vox_out + ((size_t)od * p.out.H + oh) * p.out.W + ow;
+            am[k] = p.argmax[mo * 64 + c];
+            gv[k] = p.dslab[mo * p.ld + c];
         }
-        const float xh = (p.y0[(size_t)m * 64 + c] - mu) * rs;
+        float g = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int kd = k >> 2, kh = (k >> 1) & 1, kw = k & 1;
+            const int od = (id + kd) >> 1, oh = (ih + kh) >> 1, ow = (iw + kw) >> 1;
+            // second candidate of an axis exists only for odd coordinates and inside the pooled grid
+            const bool ok = (kd == 0 || (id & 1)) && (kh == 0 || (ih & 1)) && (kw == 0 || (iw & 1)) &&
+                            od < p.out.D && oh < p.out.H && ow < p.out.W;
+            const int tap = ((id - 2 * od + 1) * 3 + (ih - 2 * oh + 1)) * 3 + (iw - 2 * ow + 1);
+            g += (ok && am[k] == tap) ? gv[k] : 0.f;
+        }
+        const float xh = (y - mu) * rs;
         g = fmaf(ga, xh, be) > 0.f ? g : 0.f;
         p.dbn[(size_t)m * 64 + c] = g;
         s1 += g; s2 += (double)g * xh;
@@ -639,7 +650,7 @@ extern "C" int mms_pool_bwd(const PoolBwdP* pp, hipStream_t s) {
     const PoolBwdP& p = *pp;
     const int Min = p.B * p.in.D * p.in.H * p.in.W;
     if (Min <= 0) return MMS_ERR_ARG;
-    MMS_LAUNCH(pool_bwd_kernel, dim3((Min + 255) / 256), dim3(256), 0, s, p);
+    MMS_LAUNCH(pool_bwd_kernel, dim3((Min + 63) / 64), dim3(256), 0, s, p);
     return mms_check_launch();
 }
 

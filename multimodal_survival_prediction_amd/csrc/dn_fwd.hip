@@ -309,6 +309,8 @@ extern "C" int mms_conv0_fwd(const Conv0FwdP* pp, hipStream_t s) {
 // bn0 + relu + maxpool(3,2,1): one workgroup = 32 pooled voxels x 64 channels
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pool_fwd_kernel(const PoolFwdP p) {
+    // workgroup = 16 pooled voxels x 64 channels (4 voxel rows x 4 iterations).  The 27 window loads of a voxel are
+    // issued together from clamped (always valid) addresses and selected afterwards: branch-free, 27 loads in flight.
     __shared__ double red[2][4][64];
     const int c = threadIdx.x & 63, vr = threadIdx.x >> 6;
     float mu, rstd;
@@ -316,20 +318,27 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const PoolFwdP p) {
     const float sc = p.bn.gamma[c] * rstd, be = p.bn.beta[c];
     const int vox_out = p.out.D * p.out.H * p.out.W, Mout = p.B * vox_out;
     double s = 0, q = 0;
-    for (int it = 0; it < 8; ++it) {
-        int m = blockIdx.x * 32 + it * 4 + vr;
+    for (int it = 0; it < 4; ++it) {
+        const int m = blockIdx.x * 16 + it * 4 + vr;
         if (m >= Mout) break;
-        int b = m / vox_out, r = m % vox_out;
-        int od = r / (p.out.H * p.out.W), oh = (r / p.out.W) % p.out.H, ow = r % p.out.W;
+        const int b = m / vox_out, r = m % vox_out;
+        const int od = r / (p.out.H * p.out.W), oh = (r / p.out.W) % p.out.H, ow = r % p.out.W;
+        const float* base = p.y0 + (size_t)b * p.in.D * p.in.H * p.in.W * 64 + c;
+        float v[27];
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            const int id = 2 * od - 1 + t / 9, ih = 2 * oh - 1 + (t / 3) % 3, iw = 2 * ow - 1 + t % 3;
+            const int cd = min(max(id, 0), p.in.D - 1), ch = min(max(ih, 0), p.in.H - 1), cw = min(max(iw, 0), p.in.W - 1);
+            v[t] = base[((size_t)(cd * p.in.H + ch) * p.in.W + cw) * 64];
+        }
         float best = -INFINITY;
         int bi = 0;
+#pragma unroll
         for (int t = 0; t < 27; ++t) {
-            int id = 2 * od - 1 + t / 9, ih = 2 * oh - 1 + (t / 3) % 3, iw = 2 * ow - 1 + t % 3;
-            if ((unsigned)id >= (unsigned)p.in.D || (unsigned)ih >= (unsigned)p.in.H || (unsigned)iw >= (unsigned)p.in.W)
-                continue;
-            size_t src = ((size_t)(b * p.in.D + id) * p.in.H + ih) * p.in.W + iw;
-            float v = fmaxf(bn_apply(p.y0[src * 64 + c], mu, sc, be), 0.f);
-            if (v > best) { best = v; bi = t; }   // strict >: first maximum in scan order wins (torch)
+            const int id = 2 * od - 1 + t / 9, ih = 2 * oh - 1 + (t / 3) % 3, iw = 2 * ow - 1 + t % 3;
+            const bool ok = (unsigned)id < (unsigned)p.in.D && (unsigned)ih < (unsigned)p.in.H && (unsigned)iw < (unsigned)p.in.W;
+            const float a = ok ? fmaxf(bn_apply(v[t], mu, sc, be), 0.f) : -INFINITY;
+            if (a > best) { best = a; bi = t; }   // strict >: first maximum in scan order wins (torch)
         }
         p.slab[(size_t)m * p.ld + c] = best;
         if (p.argmax) p.argmax[(size_t)m * 64 + c] = (uint8_t)bi;
@@ -349,7 +358,7 @@ extern "C" int mms_pool_fwd(const PoolFwdP* pp, hipStream_t s) {
     const PoolFwdP& p = *pp;
     int Mout = p.B * p.out.D * p.out.H * p.out.W;
     if (Mout <= 0) return MMS_ERR_ARG;
-    MMS_LAUNCH(pool_fwd_kernel, dim3((Mout + 31) / 32), dim3(256), 0, s, p);
+    MMS_LAUNCH(pool_fwd_kernel, dim3((Mout + 15) / 16), dim3(256), 0, s, p);
     return mms_check_launch();
 }
 

@@ -73,7 +73,13 @@ __global__ __launch_bounds__(Op::SPEC ? 512 : 256) void tile_gemm_kernel(const t
     const bool producer = Op::SPEC ? threadIdx.x >= 256 : true;
     const bool consumer = Op::SPEC ? threadIdx.x < 256 : true;
     const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
-    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN, z = blockIdx.z;
+    // XCD-aware tile order (cdna_hip_programming.md T1): workgroups are dealt round-robin over the 8 XCDs, so give the
+    // blocks that share an XCD (equal blockIdx.x % 8) a CONTIGUOUS range of M tiles -- neighbouring tiles share halo rows /
+    // operand panels, and each XCD's L2 then holds one compact slice of the activations instead of a scatter of all of them.
+    // Placement only affects speed, never results.
+    int bx = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bx = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int m0 = bx * TM, n0 = blockIdx.y * TN, z = blockIdx.z;
 
     Op op;
     op.setup(p, m0, n0, z, extra, tid);
@@ -114,14 +120,22 @@ __global__ __launch_bounds__(Op::SPEC ? 512 : 256) void tile_gemm_kernel(const t
         for (int i = 0; i < NA; ++i) {
             int row, k; a_pos(i, row, k);
             bool ok;
+#ifdef MMS_ABLATE_ALOAD
+            ok = false; R.ra[i] = typename Op::ARaw{};
+#else
             R.ra[i] = op.a_ld(p, i, m0 + row, k0 + k, ok);
+#endif
             R.oka |= (ok ? 1u : 0u) << i;
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             int row, k; b_pos(i, row, k);
             bool ok;
+#ifdef MMS_ABLATE_BLOAD
+            ok = false; R.rb[i] = typename Op::BRaw{};
+#else
             R.rb[i] = op.b_ld(p, i, n0 + row, k0 + k, ok);
+#endif
             R.okb |= (ok ? 1u : 0u) << i;
         }
     };
@@ -160,25 +174,29 @@ __global__ __launch_bounds__(Op::SPEC ? 512 : 256) void tile_gemm_kernel(const t
         const float* at = As + buf * ATILE;
         const float* bt = Bs + buf * BTILE;
         const int li = lane & 31, kh = wk * 32 + 4 * (lane >> 5);
+        float4 a[4], b[4];      // all LDS reads of the K-step are issued before its 16 dependent MFMAs
 #pragma unroll
-        for (int kk = 0; kk < 32; kk += 8) {
-            float4 a, b;
+        for (int q = 0; q < 4; ++q) {
+            const int kk = 8 * q;
             if constexpr (Op::AMODE == LD_R4) {
-                const float* q = at + (kh + kk) * APITCH + wm * 32 + li;
-                a = make_float4(q[0], q[APITCH], q[2 * APITCH], q[3 * APITCH]);
+                const float* r = at + (kh + kk) * APITCH + wm * 32 + li;
+                a[q] = make_float4(r[0], r[APITCH], r[2 * APITCH], r[3 * APITCH]);
             } else {
-                a = *(const float4*)(at + (wm * 32 + li) * APITCH + kh + kk);
+                a[q] = *(const float4*)(at + (wm * 32 + li) * APITCH + kh + kk);
             }
             if constexpr (Op::BMODE == LD_R4) {
-                const float* q = bt + (kh + kk) * BPITCH + wn * 32 + li;
-                b = make_float4(q[0], q[BPITCH], q[2 * BPITCH], q[3 * BPITCH]);
+                const float* r = bt + (kh + kk) * BPITCH + wn * 32 + li;
+                b[q] = make_float4(r[0], r[BPITCH], r[2 * BPITCH], r[3 * BPITCH]);
             } else {
-                b = *(const float4*)(bt + (wn * 32 + li) * BPITCH + kh + kk);
+                b[q] = *(const float4*)(bt + (wn * 32 + li) * BPITCH + kh + kk);
             }
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, b[q].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, b[q].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, b[q].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, b[q].w, acc, 0, 0, 0);
         }
     };
 
@@ -209,12 +227,21 @@ __global__ __launch_bounds__(Op::SPEC ? 512 : 256) void tile_gemm_kernel(const t
             if (consumer) mma(buf);
             __syncthreads();
         } else {
+            // two register sets: the global loads of tile t+2 are issued before the MFMAs of tile t and consumed (transform
+            // + LDS store) one step later, so L2/MALL latency has a full step to hide (vmcnt retires in order)
             gload(R0, kb);
+            if (kb + TK < ke) gload(R1, kb + TK);
             sstore(R0, 0);
             __syncthreads();
             int buf = 0;
-            for (int k0 = kb; k0 + TK < ke; k0 += TK) {
-                gload(R0, k0 + TK);
+            for (int k0 = kb; k0 + TK < ke; k0 += 2 * TK) {
+                if (k0 + 2 * TK < ke) gload(R0, k0 + 2 * TK);
+                mma(buf);
+                sstore(R1, buf ^ 1);
+                __syncthreads();
+                buf ^= 1;
+                if (k0 + 2 * TK >= ke) break;
+                if (k0 + 3 * TK < ke) gload(R1, k0 + 3 * TK);
                 mma(buf);
                 sstore(R0, buf ^ 1);
                 __syncthreads();

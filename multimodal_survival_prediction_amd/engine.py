@@ -13,6 +13,7 @@ PyTorch supplies device memory, streams and graph capture only; every numeric op
 include/mmsurv.h.  Nothing here falls back to torch math.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -261,6 +262,12 @@ class SurvivalEngine:
             _lib.check(lib.mms_linear_bwd(ctypes.byref(P.lin_bwd[i]), st), "mms_linear_bwd")
         dfe = P.dbuf["feats"]
         dct = dfe[:, prog["ct_cols"]:]
+        # The weight-gradient fork (mms_dn121_backward_mt) is off by default: measured, it neither helps a single chain
+        # (graph branches run mostly serially) nor concurrent fold models (it takes hardware queues away from them).
+        if os.environ.get("MMS_SIDE_STREAM") != "1" and not P.fallback:
+            _lib.check(lib.mms_dn121_backward(P.ws.data_ptr(), B, D, H, W, P.ct.data_ptr(), P.ptab, dct.data_ptr(),
+                                              dfe.stride(0), P.gtab, st), "mms_dn121_backward")
+            return
         if P.fallback:
             _lib.check(lib.mms_fb_backward(P.ws.data_ptr(), B, D, H, W, P.ct.data_ptr(), P.ptab, dct.data_ptr(),
                                            dfe.stride(0), P.gtab, st), "mms_fb_backward")
