@@ -50,6 +50,8 @@ typedef struct BnSrc {
     float inv_count;       /* 1 / rows the statistics were taken over */
     float eps;
     int train;
+    int nrep;              /* accumulator replicas (0/1 = one): sum[c + r*rep_stride], r < nrep, are added up by the reader */
+    int rep_stride;        /* in doubles */
 } BnSrc;
 
 
@@ -65,6 +67,7 @@ typedef struct Conv1FwdP {
     double* osum; double* osumsq;   // [N] batch-stat accumulators of y (nullptr in eval)
     int pool;                       // 1: AvgPool3d(2,2) of relu(bn(x)) before the GEMM (== conv then pool)
     Dims3 in;                       // input grid (pool=1)
+    int srep; int sstride;          // statistic-accumulator replicas written by this op: workgroup x adds to replica x % srep (stride in doubles)
 } Conv1FwdP;
 
 // ---- 3x3x3 conv, pad 1 (dense-layer conv2): slab[:, coff:coff+32] = conv3(relu(bn(y1)), W) ---------------
@@ -79,6 +82,7 @@ typedef struct Conv3FwdP {
     float* partial;                 // optional scratch [nsplit][M][32]: split the 27 taps over nsplit workgroups per tile,
                                     // then a reduce kernel sums them, writes the slab columns and the statistics
     int nsplit;                     // 1..27 (used when partial != null); workgroup z handles taps [z*ceil(27/nsplit), ...)
+    int srep; int sstride;          // statistic-accumulator replicas written by this op: workgroup x adds to replica x % srep (stride in doubles)
 } Conv3FwdP;
 
 // ---- conv0: Conv3d(1,64,k7,s2,p3,no bias) -------------------------------------------------------------
@@ -90,6 +94,7 @@ typedef struct Conv0FwdP {
     const float* w;                 // [64][343]
     float* y;                       // [M][64]
     double* osum; double* osumsq;   // [64]
+    int srep; int sstride;          // statistic-accumulator replicas written by this op: workgroup x adds to replica x % srep (stride in doubles)
 } Conv0FwdP;
 
 // ---- bn0 + relu + MaxPool3d(3,2,1) -> slab1[:, 0:64] -----------------------------------------------------
@@ -100,6 +105,7 @@ typedef struct PoolFwdP {
     uint8_t* argmax;                // [B*out][64] tap index 0..26 of the first maximum (torch scan order)
     BnSrc bn;
     double* osum; double* osumsq;   // [64] stats of the pooled output (nullptr in eval)
+    int srep; int sstride;          // statistic-accumulator replicas written by this op: workgroup x adds to replica x % srep (stride in doubles)
 } PoolFwdP;
 
 // ---- norm5 + relu + global-avg-pool + Linear(1024,128) ---------------------------------------------------
@@ -116,6 +122,7 @@ typedef struct HeadFwdP {
 typedef struct BnBwd {
     const double* s1;      // [C] sum_m dbn
     const double* s2;      // [C] sum_m dbn * xhat
+    int nrep; int rep_stride;   // replicas as in BnSrc
 } BnBwd;
 
 // conv3 backward-data: dbn2 = (dz (*) W^T) * [a2 > 0], plus BN2-backward sums
@@ -129,6 +136,7 @@ typedef struct Conv3BwdDataP {
     double* s1; double* s2;         // [128] out (atomics)
     float* partial;                 // optional scratch [nsplit][M][128]: tap split as in Conv3FwdP
     int nsplit;
+    int srep; int sstride;          // statistic-accumulator replicas written by this op: workgroup x adds to replica x % srep (stride in doubles)
 } Conv3BwdDataP;
 
 // conv3 backward-weight: dW[cout][cin][tap] += sum_m relu(bn(y1))[nbr(m,tap)][cin] * dz[m][cout]
@@ -162,6 +170,7 @@ typedef struct Conv1BwdP {
     double* s1; double* s2;         // [K] out (data kernel)
     int msplit;
     float* dgamma_out; float* dbeta_out;   // [N] BN2 parameter grads (= s2_out, s1_out), written by the weight kernel
+    int srep; int sstride;          // statistic-accumulator replicas written by this op: workgroup x adds to replica x % srep (stride in doubles)
 } Conv1BwdP;
 
 // dslab[:, 0:C] (+)= g*rstd*(dbn - s1/M - xhat*s2/M)
@@ -190,6 +199,7 @@ typedef struct PoolBwdP {                   // maxpool backward + relu0 mask -> 
     float* dbn;                     // [B*in][64]
     double* s1; double* s2;         // [64]
     const int* coords;              // optional [B*in] packed (d,h,w) of the conv0 grid (saves the per-voxel integer divisions)
+    int srep; int sstride;          // statistic-accumulator replicas written by this op: workgroup x adds to replica x % srep (stride in doubles)
 } PoolBwdP;
 
 typedef struct Conv0BwdWP {                 // dW0[64][343] += sum_m bn0bwd(dbn0)[m][n] * x[patch(m,k)]

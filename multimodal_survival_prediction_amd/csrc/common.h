@@ -10,11 +10,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 
+// Statistic accumulators may be replicated (fp64 atomics on one address serialise: 256 workgroups adding to the same 64
+// words cost ~5 us): a producer workgroup adds to replica blockIdx.x % nrep, readers add the replicas up.
+__device__ __forceinline__ double* stat_rep(double* base, int nrep, int stride) {
+    return (base && nrep > 1) ? base + (size_t)(blockIdx.x % nrep) * stride : base;
+}
+__device__ __forceinline__ double rep_sum(const double* a, int c, int nrep, int stride) {
+    double s = a[c];
+    for (int r = 1; r < nrep; ++r) s += a[c + (size_t)r * stride];
+    return s;
+}
+
 // mean / rstd of channel c.  The batch variance is the biased one (what torch normalises with).
 __device__ __forceinline__ void bn_mean_rstd(const BnSrc& b, int c, float& mean, float& rstd) {
     if (b.train) {
-        double m = b.sum[c] * (double)b.inv_count;
-        double v = b.sumsq[c] * (double)b.inv_count - m * m;
+        double m = rep_sum(b.sum, c, b.nrep, b.rep_stride) * (double)b.inv_count;
+        double v = rep_sum(b.sumsq, c, b.nrep, b.rep_stride) * (double)b.inv_count - m * m;
         v = v > 0.0 ? v : 0.0;
         mean = (float)m;
         rstd = 1.0f / sqrtf((float)v + b.eps);      // the fp64 part is the cancellation-prone E[x^2]-E[x]^2 only
@@ -33,7 +44,7 @@ __device__ __forceinline__ void bn_consts_to_lds(const BnSrc& b, int C, int tid,
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int c = tid + 256 * j, cc = c < C ? c : C - 1;
-        if (b.train) { s[j] = b.sum[cc]; q[j] = b.sumsq[cc]; rm[j] = 0.f; rv[j] = 0.f; }
+        if (b.train) { s[j] = rep_sum(b.sum, cc, b.nrep, b.rep_stride); q[j] = rep_sum(b.sumsq, cc, b.nrep, b.rep_stride); rm[j] = 0.f; rv[j] = 0.f; }
         else { rm[j] = b.rmean[cc]; rv[j] = b.rvar[cc]; s[j] = 0; q[j] = 0; }
         g[j] = b.gamma[cc]; be[j] = b.beta[cc];
     }
@@ -125,3 +136,8 @@ static inline int mms_check_launch() {
     if (e != hipSuccess) fprintf(stderr, "mmsurv: kernel launch failed: %s\n", hipGetErrorString(e));
     return e == hipSuccess ? MMS_OK : MMS_ERR_LAUNCH;
 }
+
+// Device tables shared by the drivers (dn_net.hip, fallback.hip) and the kernels that walk them.
+struct PackEntry { const float* w; float* wpf; float* wpb; };
+struct UnpackEntry { const float* scratch; float* dw; };
+struct BnRunEntry { const double* sum; const double* sumsq; float* rmean; float* rvar; long long* nbt; int C; float count; int nrep; int rep_stride; };

@@ -103,8 +103,8 @@ struct Conv3BwdDataOp {
         if (active) { red[(rg * 2 + 0) * 128 + c] = s1; red[(rg * 2 + 1) * 128 + c] = s2; }
         __syncthreads();
         if (rg == 0 && active) {
-            atomicAdd(&p.s1[c], red[c] + red[2 * 128 + c]);
-            atomicAdd(&p.s2[c], red[128 + c] + red[3 * 128 + c]);
+            atomicAdd(&stat_rep(p.s1, p.srep, p.sstride)[c], red[c] + red[2 * 128 + c]);
+            atomicAdd(&stat_rep(p.s2, p.srep, p.sstride)[c], red[128 + c] + red[3 * 128 + c]);
         }
     }
 };
@@ -134,8 +134,8 @@ __global__ __launch_bounds__(256) void conv3_bwd_data_reduce_kernel(const Conv3B
     red[0][rg][c] = s1; red[1][rg][c] = s2;
     __syncthreads();
     if (rg == 0) {
-        atomicAdd(&p.s1[c], red[0][0][c] + red[0][1][c]);
-        atomicAdd(&p.s2[c], red[1][0][c] + red[1][1][c]);
+        atomicAdd(&stat_rep(p.s1, p.srep, p.sstride)[c], red[0][0][c] + red[0][1][c]);
+        atomicAdd(&stat_rep(p.s2, p.srep, p.sstride)[c], red[1][0][c] + red[1][1][c]);
     }
 }
 
@@ -229,7 +229,6 @@ struct Conv3BwdWOp {
 
 // tap-major gradient scratch -> canonical torch layout, through LDS so both sides are coalesced.
 // one workgroup per (layer, cout): 27 x 128 floats
-struct UnpackEntry { const float* scratch; float* dw; };
 struct UnpackTable { UnpackEntry e[64]; };      // passed BY VALUE as a kernel argument (1 KB): capture-safe, no device table
 __global__ __launch_bounds__(256) void unpack_conv3_grads_kernel(const UnpackTable tab) {
     __shared__ float t[27 * 129];
@@ -276,8 +275,8 @@ struct DyConsts {   // per output channel n (LDS): dy = A*(dbn - B - yhat*C), yh
                 float mu, rs;
                 bn_mean_rstd(p.bn_out, n, mu, rs);
                 A[i] = p.bn_out.gamma[n] * rs;
-                Bc[i] = (float)(p.bb_out.s1[n] * (double)p.bn_out.inv_count);
-                Cc[i] = (float)(p.bb_out.s2[n] * (double)p.bn_out.inv_count);
+                Bc[i] = (float)(rep_sum(p.bb_out.s1, n, p.bb_out.nrep, p.bb_out.rep_stride) * (double)p.bn_out.inv_count);
+                Cc[i] = (float)(rep_sum(p.bb_out.s2, n, p.bb_out.nrep, p.bb_out.rep_stride) * (double)p.bn_out.inv_count);
                 mean[i] = mu; rstd[i] = rs;
             } else {
                 A[i] = Bc[i] = Cc[i] = mean[i] = rstd[i] = 0.f;
@@ -380,8 +379,8 @@ struct Conv1BwdDataOp {
         if (rg == 0 && k < p.K && active) {
             double a = 0, b = 0;
             for (int g = 0; g < RG; ++g) { a += red[(g * 2) * TN + c]; b += red[(g * 2 + 1) * TN + c]; }
-            atomicAdd(&p.s1[k], a);
-            atomicAdd(&p.s2[k], b);
+            atomicAdd(&stat_rep(p.s1, p.srep, p.sstride)[k], a);
+            atomicAdd(&stat_rep(p.s2, p.srep, p.sstride)[k], b);
         }
     }
 };
@@ -429,8 +428,8 @@ struct Conv1BwdWOp {
         me = mb + mc < p.M ? mb + mc : p.M;
         // BN2 parameter grads: dgamma = sum dbn*xhat, dbeta = sum dbn
         if (p.has_bn_out && p.dgamma_out && blockIdx.y == 0 && z == 0 && tid < 64 && n0r + tid < p.N) {
-            p.dgamma_out[n0r + tid] += (float)p.bb_out.s2[n0r + tid];
-            p.dbeta_out[n0r + tid] += (float)p.bb_out.s1[n0r + tid];
+            p.dgamma_out[n0r + tid] += (float)rep_sum(p.bb_out.s2, n0r + tid, p.bb_out.nrep, p.bb_out.rep_stride);
+            p.dbeta_out[n0r + tid] += (float)rep_sum(p.bb_out.s1, n0r + tid, p.bb_out.nrep, p.bb_out.rep_stride);
         }
     }
     __device__ void krange(const Params&, int, int& kb, int& ke) { kb = mb; ke = me; }
@@ -502,11 +501,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyP p) 
     for (int j = 0; j < 4; ++j) {
         bn_mean_rstd(p.bn, c + j, mu[j], rs[j]);
         gr[j] = p.bn.gamma[c + j] * rs[j];
-        m1[j] = (float)(p.bb.s1[c + j] * (double)p.bn.inv_count);
-        m2[j] = (float)(p.bb.s2[c + j] * (double)p.bn.inv_count);
+        const double t1 = rep_sum(p.bb.s1, c + j, p.bb.nrep, p.bb.rep_stride), t2 = rep_sum(p.bb.s2, c + j, p.bb.nrep, p.bb.rep_stride);
+        m1[j] = (float)(t1 * (double)p.bn.inv_count);
+        m2[j] = (float)(t2 * (double)p.bn.inv_count);
         if (blockIdx.x == 0 && rg == 0 && p.dgamma) {
-            p.dgamma[c + j] += (float)p.bb.s2[c + j];
-            p.dbeta[c + j] += (float)p.bb.s1[c + j];
+            p.dgamma[c + j] += (float)t2;
+            p.dbeta[c + j] += (float)t1;
         }
     }
     const int r0 = blockIdx.x * 32, rows = p.M - r0 < 32 ? p.M - r0 : 32;
@@ -642,8 +642,8 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolBwdP p) {
     red[0][vr][c] = s1; red[1][vr][c] = s2;
     __syncthreads();
     if (vr == 0) {
-        atomicAdd(&p.s1[c], red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-        atomicAdd(&p.s2[c], red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+        atomicAdd(&stat_rep(p.s1, p.srep, p.sstride)[c], red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+        atomicAdd(&stat_rep(p.s2, p.srep, p.sstride)[c], red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
     }
 }
 extern "C" int mms_pool_bwd(const PoolBwdP* pp, hipStream_t s) {
@@ -674,12 +674,13 @@ struct Conv0BwdWOp {
             float mu, rs;
             bn_mean_rstd(p.bn, tid, mu, rs);
             A[tid] = p.bn.gamma[tid] * rs;
-            Bc[tid] = (float)(p.bb.s1[tid] * (double)p.bn.inv_count);
-            Cc[tid] = (float)(p.bb.s2[tid] * (double)p.bn.inv_count);
+            const double t1 = rep_sum(p.bb.s1, tid, p.bb.nrep, p.bb.rep_stride), t2 = rep_sum(p.bb.s2, tid, p.bb.nrep, p.bb.rep_stride);
+            Bc[tid] = (float)(t1 * (double)p.bn.inv_count);
+            Cc[tid] = (float)(t2 * (double)p.bn.inv_count);
             mean[tid] = mu; rstd[tid] = rs;
             if (blockIdx.x == 0 && z == 0 && p.dgamma) {
-                p.dgamma[tid] += (float)p.bb.s2[tid];
-                p.dbeta[tid] += (float)p.bb.s1[tid];
+                p.dgamma[tid] += (float)t2;
+                p.dbeta[tid] += (float)t1;
             }
         }
         int mc = (p.M + p.msplit - 1) / p.msplit;

@@ -17,6 +17,9 @@ __device__ __forceinline__ void store_tile(float* y, int ldy, int M, int N, int 
 template <int TM, int TN>
 __device__ __forceinline__ void tile_col_stats(double* osum, double* osumsq, int M, int N, int m0, int n0,
                                                const float* Cs, int tid) {
+#ifdef MMS_ABLATE_STATS
+    return;
+#endif
     if (osum == nullptr || tid >= TN) return;
     int n = n0 + tid;
     if (n >= N) return;
@@ -95,7 +98,7 @@ struct Conv1FwdOp {
     __device__ void epilogue(const Params& p, int m0_, int n0, int, const float* Cs, int tid, bool active) {
         if (!active) return;
         store_tile<TM, TN>(p.y, p.ldy, p.M, p.N, m0_, n0, Cs, tid);
-        tile_col_stats<TM, TN>(p.osum, p.osumsq, p.M, p.N, m0_, n0, Cs, tid);
+        tile_col_stats<TM, TN>(stat_rep(p.osum, p.srep, p.sstride), stat_rep(p.osumsq, p.srep, p.sstride), p.M, p.N, m0_, n0, Cs, tid);
     }
 };
 
@@ -202,7 +205,7 @@ struct Conv3FwdOp {
             return;
         }
         store_tile<TM, TN>(p.out, p.ldo, p.M, 32, m0_, n0, Cs, tid);
-        tile_col_stats<TM, TN>(p.osum, p.osumsq, p.M, 32, m0_, n0, Cs, tid);
+        tile_col_stats<TM, TN>(stat_rep(p.osum, p.srep, p.sstride), stat_rep(p.osumsq, p.srep, p.sstride), p.M, 32, m0_, n0, Cs, tid);
     }
 };
 
@@ -228,8 +231,8 @@ __global__ __launch_bounds__(256) void conv3_fwd_reduce_kernel(const Conv3FwdP p
         double a = 0, b = 0;
 #pragma unroll
         for (int g = 0; g < 8; ++g) { a += red[0][g][c]; b += red[1][g][c]; }
-        atomicAdd(&p.osum[c], a);
-        atomicAdd(&p.osumsq[c], b);
+        atomicAdd(&stat_rep(p.osum, p.srep, p.sstride)[c], a);
+        atomicAdd(&stat_rep(p.osumsq, p.srep, p.sstride)[c], b);
     }
 }
 
@@ -295,7 +298,7 @@ struct Conv0FwdOp {
     __device__ void epilogue(const Params& p, int m0_, int n0, int, const float* Cs, int tid, bool active) {
         if (!active) return;
         store_tile<TM, TN>(p.y, 64, p.M, 64, m0_, n0, Cs, tid);
-        tile_col_stats<TM, TN>(p.osum, p.osumsq, p.M, 64, m0_, n0, Cs, tid);
+        tile_col_stats<TM, TN>(stat_rep(p.osum, p.srep, p.sstride), stat_rep(p.osumsq, p.srep, p.sstride), p.M, 64, m0_, n0, Cs, tid);
     }
 };
 
@@ -348,8 +351,8 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const PoolFwdP p) {
         red[0][vr][c] = s; red[1][vr][c] = q;
         __syncthreads();
         if (vr == 0) {
-            atomicAdd(&p.osum[c], red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-            atomicAdd(&p.osumsq[c], red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+            atomicAdd(&stat_rep(p.osum, p.srep, p.sstride)[c], red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+            atomicAdd(&stat_rep(p.osumsq, p.srep, p.sstride)[c], red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
         }
     }
 }
@@ -430,7 +433,6 @@ extern "C" int mms_pack_conv3(const float* w, float* wpf, float* wpb, hipStream_
 }
 
 // batched variant over a device table of layer pointers (one launch per forward)
-struct PackEntry { const float* w; float* wpf; float* wpb; };
 // one workgroup per (layer, cout): the 128 x 27 canonical slice goes through LDS so reads and writes are coalesced
 __global__ __launch_bounds__(256) void pack_conv3_table_kernel(const PackEntry* tab) {
     __shared__ float t[128 * 28];
@@ -453,11 +455,10 @@ extern "C" int mms_pack_conv3_table(const void* table_dev, int nlayers, hipStrea
 }
 
 // running_mean/var momentum update (torch: running = 0.9*running + 0.1*batch, unbiased var; nbt += 1)
-struct BnRunEntry { const double* sum; const double* sumsq; float* rmean; float* rvar; long long* nbt; int C; float count; };
 __global__ void bn_running_update_kernel(const BnRunEntry* tab, float momentum) {
     const BnRunEntry e = tab[blockIdx.x];
     for (int c = threadIdx.x; c < e.C; c += blockDim.x) {
-        double m = e.sum[c] / e.count, v = e.sumsq[c] / e.count - m * m;
+        double m = rep_sum(e.sum, c, e.nrep, e.rep_stride) / e.count, v = rep_sum(e.sumsq, c, e.nrep, e.rep_stride) / e.count - m * m;
         if (v < 0) v = 0;
         double unb = e.count > 1.f ? v * e.count / (e.count - 1.0) : v;
         e.rmean[c] = (1.f - momentum) * e.rmean[c] + momentum * (float)m;

@@ -23,13 +23,11 @@ constexpr int NLAYER = 58;
 constexpr int NBN = 121;
 constexpr int NPARAM = 364;
 
-struct PackEntry { const float* w; float* wpf; float* wpb; };
-struct UnpackEntry { const float* scratch; float* dw; };
-struct BnRunEntry { const double* sum; const double* sumsq; float* rmean; float* rvar; long long* nbt; int C; float count; };
 
 struct Plan {
     int B; Dims3 in, g0, g[NB];
     int M0, M[NB];
+    int R0, R[NB];     // statistic-accumulator replicas of the stem level / of each block (common.h: stat_rep)
     // byte offsets into the workspace
     size_t coords0, coords[NB], y0, argmax, slab[NB], dslab[NB], y1[NLAYER], wpf[NLAYER], wpb[NLAYER];
     size_t dbn_mid, dbn_in, dbn0, pooled, tab_pack, tab_bn, partial, dwp[NLAYER];
@@ -51,6 +49,9 @@ bool make_plan(Plan& P, int B, int D, int H, int W) {
     for (int b = 1; b < NB; ++b) P.g[b] = Dims3{P.g[b - 1].D / 2, P.g[b - 1].H / 2, P.g[b - 1].W / 2};
     P.M0 = B * P.g0.D * P.g0.H * P.g0.W;
     for (int b = 0; b < NB; ++b) P.M[b] = B * P.g[b].D * P.g[b].H * P.g[b].W;
+    auto reps = [](int M) { int r = 1; while (r < 8 && M / (2 * r) >= 2048) r *= 2; return r; };   // 16384 rows -> 8, <= 2048 rows -> 1
+    P.R0 = reps(P.M0);
+    for (int b = 0; b < NB; ++b) P.R[b] = reps(P.M[b]);
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = al(o + bytes); return r; };
     P.coords0 = take((size_t)P.M0 * 4);
@@ -80,13 +81,15 @@ bool make_plan(Plan& P, int B, int D, int H, int W) {
     P.tab_bn = take(sizeof(BnRunEntry) * NBN);
     P.stats_begin = o;
     for (int i = 0; i < NLAYER; ++i) P.dwp[i] = take((size_t)27 * 32 * 128 * 4);    // tap-major conv2 gradient scratch (zeroed with the stats)
-    P.st_y0 = take(2 * 64 * 8);
-    for (int b = 0; b < NB; ++b) P.st_slab[b] = take((size_t)2 * CTOT[b] * 8);
-    for (int i = 0; i < NLAYER; ++i) P.st_y1[i] = take(2 * 128 * 8);
-    P.bb_y0 = take(2 * 64 * 8);
-    for (int i = 0; i < NLAYER; ++i) P.bb_y1[i] = take(2 * 128 * 8);
-    for (int i = 0; i < NLAYER; ++i) P.bb_in[i] = take(2 * 1024 * 8);
-    for (int i = 0; i < 3; ++i) P.bb_tr[i] = take(2 * 1024 * 8);
+    int blk_of[NLAYER];
+    { int l2 = 0; for (int b = 0; b < NB; ++b) for (int i = 0; i < LAYERS[b]; ++i) blk_of[l2++] = b; }
+    P.st_y0 = take((size_t)P.R0 * 2 * 64 * 8);
+    for (int b = 0; b < NB; ++b) P.st_slab[b] = take((size_t)P.R[b] * 2 * CTOT[b] * 8);
+    for (int i = 0; i < NLAYER; ++i) P.st_y1[i] = take((size_t)P.R[blk_of[i]] * 2 * 128 * 8);
+    P.bb_y0 = take((size_t)P.R0 * 2 * 64 * 8);
+    for (int i = 0; i < NLAYER; ++i) P.bb_y1[i] = take((size_t)P.R[blk_of[i]] * 2 * 128 * 8);
+    for (int i = 0; i < NLAYER; ++i) P.bb_in[i] = take((size_t)P.R[blk_of[i]] * 2 * 1024 * 8);
+    for (int i = 0; i < 3; ++i) P.bb_tr[i] = take((size_t)P.R[i] * 2 * 1024 * 8);
     P.stats_end = o;
     P.total = o;
     return true;
@@ -113,8 +116,9 @@ const Idx IDX;
 template <class T> inline T* at(void* ws, size_t off) { return (T*)((char*)ws + off); }
 
 inline BnSrc mk_bn(void* ws, size_t st_off, int Ctot_, const float* const* prm, int iw, const void* const* buf, int bn_ord,
-                   int count, int train) {
+                   int count, int train, int nrep) {
     BnSrc b;
+    b.nrep = nrep; b.rep_stride = 2 * Ctot_;
     b.sum = at<double>(ws, st_off);
     b.sumsq = at<double>(ws, st_off) + Ctot_;
     b.rmean = buf ? (const float*)buf[3 * bn_ord] : nullptr;
@@ -180,23 +184,24 @@ extern "C" int mms_dn121_init(void* ws, int B, int D, int H, int W, const void* 
     (void)hipGetLastError();
     PackEntry pk[NLAYER];
     BnRunEntry bn[NBN];
-    auto set_bn = [&](int ord, size_t st, int Ctot_, int C, int count) {
+    auto set_bn = [&](int ord, size_t st, int Ctot_, int C, int count, int nrep) {
+        bn[ord].nrep = nrep; bn[ord].rep_stride = 2 * Ctot_;
         bn[ord].sum = at<double>(ws, st); bn[ord].sumsq = at<double>(ws, st) + Ctot_;
         bn[ord].rmean = (float*)buffers[3 * ord]; bn[ord].rvar = (float*)buffers[3 * ord + 1];
         bn[ord].nbt = (long long*)buffers[3 * ord + 2]; bn[ord].C = C; bn[ord].count = (float)count;
     };
-    set_bn(0, P.st_y0, 64, 64, P.M0);
+    set_bn(0, P.st_y0, 64, 64, P.M0, P.R0);
     int l = 0;
     for (int b = 0; b < NB; ++b) {
         int C = C0[b];
         for (int i = 0; i < LAYERS[b]; ++i, ++l, C += 32) {
             pk[l].w = (const float*)params[IDX.layer[l] + 5];
             pk[l].wpf = at<float>(ws, P.wpf[l]); pk[l].wpb = at<float>(ws, P.wpb[l]);
-            set_bn(IDX.bn_layer1[l], P.st_slab[b], CTOT[b], C, P.M[b]);
-            set_bn(IDX.bn_layer2[l], P.st_y1[l], 128, 128, P.M[b]);
+            set_bn(IDX.bn_layer1[l], P.st_slab[b], CTOT[b], C, P.M[b], P.R[b]);
+            set_bn(IDX.bn_layer2[l], P.st_y1[l], 128, 128, P.M[b], P.R[b]);
         }
-        if (b < 3) set_bn(IDX.bn_trans[b], P.st_slab[b], CTOT[b], CTOT[b], P.M[b]);
-        else set_bn(IDX.bn5, P.st_slab[b], CTOT[b], CTOT[b], P.M[b]);
+        if (b < 3) set_bn(IDX.bn_trans[b], P.st_slab[b], CTOT[b], CTOT[b], P.M[b], P.R[b]);
+        else set_bn(IDX.bn5, P.st_slab[b], CTOT[b], CTOT[b], P.M[b], P.R[b]);
     }
     hipError_t e1 = hipMemcpyAsync(at<void>(ws, P.tab_pack), pk, sizeof(pk), hipMemcpyHostToDevice, s);
     hipError_t e2 = hipMemcpyAsync(at<void>(ws, P.tab_bn), bn, sizeof(bn), hipMemcpyHostToDevice, s);
@@ -223,10 +228,12 @@ extern "C" int mms_dn121_forward(void* ws, int B, int D, int H, int W, const flo
     {   // stem
         Conv0FwdP c0{x, P.in, P.g0, at<int>(ws, P.coords0), P.M0, prm[IDX.conv0], at<float>(ws, P.y0),
                      st(P.st_y0, 64, 0, false), st(P.st_y0, 64, 0, true)};
+        c0.srep = P.R0; c0.sstride = 2 * 64;
         TRY(mms_conv0_fwd(&c0, s));
         PoolFwdP pf{at<float>(ws, P.y0), P.g0, P.g[0], B, at<float>(ws, P.slab[0]), CTOT[0], at<uint8_t>(ws, P.argmax),
-                    mk_bn(ws, P.st_y0, 64, prm, IDX.n0w, buffers, IDX.bn0, P.M0, train),
+                    mk_bn(ws, P.st_y0, 64, prm, IDX.n0w, buffers, IDX.bn0, P.M0, train, P.R0),
                     st(P.st_slab[0], CTOT[0], 0, false), st(P.st_slab[0], CTOT[0], 0, true)};
+        pf.srep = P.R[0]; pf.sstride = 2 * CTOT[0];
         TRY(mms_pool_fwd(&pf, s));
     }
     int l = 0;
@@ -236,25 +243,28 @@ extern "C" int mms_dn121_forward(void* ws, int B, int D, int H, int W, const flo
         for (int i = 0; i < LAYERS[b]; ++i, ++l, C += 32) {
             const int ip = IDX.layer[l];
             Conv1FwdP c1{slab, CTOT[b], P.M[b], C, prm[ip + 2], 128, at<float>(ws, P.y1[l]), 128,
-                         mk_bn(ws, P.st_slab[b], CTOT[b], prm, ip, buffers, IDX.bn_layer1[l], P.M[b], train),
+                         mk_bn(ws, P.st_slab[b], CTOT[b], prm, ip, buffers, IDX.bn_layer1[l], P.M[b], train, P.R[b]),
                          st(P.st_y1[l], 128, 0, false), st(P.st_y1[l], 128, 0, true), 0, Dims3{0, 0, 0}};
+            c1.srep = P.R[b]; c1.sstride = 2 * 128;
             TRY(mms_conv1_fwd(&c1, s));
             Conv3FwdP c3{at<float>(ws, P.y1[l]), at<int>(ws, P.coords[b]), P.g[b], P.M[b], at<float>(ws, P.wpf[l]),
-                         slab + C, CTOT[b], mk_bn(ws, P.st_y1[l], 128, prm, ip + 3, buffers, IDX.bn_layer2[l], P.M[b], train),
+                         slab + C, CTOT[b], mk_bn(ws, P.st_y1[l], 128, prm, ip + 3, buffers, IDX.bn_layer2[l], P.M[b], train, P.R[b]),
                          st(P.st_slab[b], CTOT[b], C, false), st(P.st_slab[b], CTOT[b], C, true),
                          P.M[b] <= 1024 ? at<float>(ws, P.partial) : nullptr, 27};   // (3-way split at M = 8192 measured slower)
+            c3.srep = P.R[b]; c3.sstride = 2 * CTOT[b];
             TRY(mms_conv3_fwd(&c3, s));
         }
         if (b < 3) {
             const int ip = IDX.trans[b];
             Conv1FwdP t{slab, CTOT[b], P.M[b + 1], CTOT[b], prm[ip + 2], CTOT[b] / 2, at<float>(ws, P.slab[b + 1]), CTOT[b + 1],
-                        mk_bn(ws, P.st_slab[b], CTOT[b], prm, ip, buffers, IDX.bn_trans[b], P.M[b], train),
+                        mk_bn(ws, P.st_slab[b], CTOT[b], prm, ip, buffers, IDX.bn_trans[b], P.M[b], train, P.R[b]),
                         st(P.st_slab[b + 1], CTOT[b + 1], 0, false), st(P.st_slab[b + 1], CTOT[b + 1], 0, true), 1, P.g[b]};
+            t.srep = P.R[b + 1]; t.sstride = 2 * CTOT[b + 1];
             TRY(mms_conv1_fwd(&t, s));
         }
     }
     HeadFwdP hd{at<float>(ws, P.slab[3]), CTOT[3], 1024, B, P.M[3] / B,
-                mk_bn(ws, P.st_slab[3], CTOT[3], prm, IDX.n5w, buffers, IDX.bn5, P.M[3], train),
+                mk_bn(ws, P.st_slab[3], CTOT[3], prm, IDX.n5w, buffers, IDX.bn5, P.M[3], train, P.R[3]),
                 prm[IDX.outw], prm[IDX.outb], 128, at<float>(ws, P.pooled), out, ldo};
     TRY(mms_head_fwd(&hd, s));
     if (train && buffers) TRY(mms_bn_running_update(at<void>(ws, P.tab_bn), NBN, 0.1f, s));
@@ -272,10 +282,10 @@ static int dn121_backward_impl(void* ws, int B, int D, int H, int W, const float
     if (!make_plan(P, B, D, H, W) || !ws || !x || !params_ || !dout || !grads_) return MMS_ERR_ARG;
     const float* const* prm = (const float* const*)params_;
     float* const* grd = (float* const*)grads_;
-    auto bbsrc = [&](size_t off, int stride) { return BnBwd{at<double>(ws, off), at<double>(ws, off) + stride}; };
+    auto bbsrc = [&](size_t off, int stride, int nrep) { return BnBwd{at<double>(ws, off), at<double>(ws, off) + stride, nrep, 2 * stride}; };
     {
         HeadBwdP hb{dout, lddout, at<float>(ws, P.pooled), at<float>(ws, P.slab[3]), CTOT[3], 1024, B, P.M[3] / B,
-                    mk_bn(ws, P.st_slab[3], CTOT[3], prm, IDX.n5w, nullptr, 0, P.M[3], 1), prm[IDX.outw], 128,
+                    mk_bn(ws, P.st_slab[3], CTOT[3], prm, IDX.n5w, nullptr, 0, P.M[3], 1, P.R[3]), prm[IDX.outw], 128,
                     grd[IDX.outw], grd[IDX.outb], grd[IDX.n5w], grd[IDX.n5b], at<float>(ws, P.dslab[3]), CTOT[3]};
         TRY(mms_head_bwd(&hb, s));
     }
@@ -288,12 +298,13 @@ static int dn121_backward_impl(void* ws, int B, int D, int H, int W, const float
         for (int i = LAYERS[b] - 1; i >= 0; --i) {
             --l; C -= 32;
             const int ip = IDX.layer[l];
-            const BnSrc bn1 = mk_bn(ws, P.st_slab[b], CTOT[b], prm, ip, nullptr, 0, M, 1);
-            const BnSrc bn2 = mk_bn(ws, P.st_y1[l], 128, prm, ip + 3, nullptr, 0, M, 1);
+            const BnSrc bn1 = mk_bn(ws, P.st_slab[b], CTOT[b], prm, ip, nullptr, 0, M, 1, P.R[b]);
+            const BnSrc bn2 = mk_bn(ws, P.st_y1[l], 128, prm, ip + 3, nullptr, 0, M, 1, P.R[b]);
             Conv3BwdDataP bd{dslab + C, CTOT[b], at<int>(ws, P.coords[b]), P.g[b], M, at<float>(ws, P.wpb[l]),
                              at<float>(ws, P.y1[l]), bn2, at<float>(ws, P.dbn_mid),
                              at<double>(ws, P.bb_y1[l]), at<double>(ws, P.bb_y1[l]) + 128,
                              M <= 1024 ? at<float>(ws, P.partial) : nullptr, 27};
+            bd.srep = P.R[b]; bd.sstride = 2 * 128;
             if (side && side_pending) {       // the previous layer's weight kernels read dbn_mid: join before overwriting it
                 if (hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) return MMS_ERR_LAUNCH;
                 side_pending = false;
@@ -310,13 +321,14 @@ static int dn121_backward_impl(void* ws, int B, int D, int H, int W, const float
             Conv1BwdP c1{};
             c1.dyraw = at<float>(ws, P.dbn_mid); c1.lddy = 128;
             c1.y = at<float>(ws, P.y1[l]); c1.ldy = 128;
-            c1.bn_out = bn2; c1.bb_out = bbsrc(P.bb_y1[l], 128); c1.has_bn_out = 1;
+            c1.bn_out = bn2; c1.bb_out = bbsrc(P.bb_y1[l], 128, P.R[b]); c1.has_bn_out = 1;
             c1.M = M; c1.N = 128;
             c1.x = slab; c1.ldx = CTOT[b]; c1.K = C; c1.bn_in = bn1;
             c1.w = prm[ip + 2]; c1.pool = 0; c1.in = Dims3{0, 0, 0};
             c1.dw = grd[ip + 2];
             c1.dbn = at<float>(ws, P.dbn_in); c1.lddbn = CTOT[b];
             c1.s1 = at<double>(ws, P.bb_in[l]); c1.s2 = at<double>(ws, P.bb_in[l]) + 1024;
+            c1.srep = P.R[b]; c1.sstride = 2 * 1024;
             c1.msplit = ms1; c1.dgamma_out = grd[ip + 3]; c1.dbeta_out = grd[ip + 4];
             TRY(mms_conv1_bwd_weight(&c1, sw));
             if (side) {
@@ -325,7 +337,7 @@ static int dn121_backward_impl(void* ws, int B, int D, int H, int W, const float
             }
             TRY(mms_conv1_bwd_data(&c1, s));
             BnBwdApplyP ap{at<float>(ws, P.dbn_in), CTOT[b], slab, CTOT[b], dslab, CTOT[b], M, C, bn1,
-                           bbsrc(P.bb_in[l], 1024), 1, grd[ip], grd[ip + 1]};
+                           bbsrc(P.bb_in[l], 1024, P.R[b]), 1, grd[ip], grd[ip + 1]};
             TRY(mms_bn_bwd_apply(&ap, s));
         }
         if (side && side_pending) {
@@ -334,30 +346,32 @@ static int dn121_backward_impl(void* ws, int B, int D, int H, int W, const float
         }
         if (b > 0) {   // transition b-1 -> b
             const int t = b - 1, ip = IDX.trans[t], Kp = CTOT[t], Mp = P.M[t];
-            const BnSrc bnt = mk_bn(ws, P.st_slab[t], CTOT[t], prm, ip, nullptr, 0, Mp, 1);
+            const BnSrc bnt = mk_bn(ws, P.st_slab[t], CTOT[t], prm, ip, nullptr, 0, Mp, 1, P.R[t]);
             int ms1 = M / 256; if (ms1 < 1) ms1 = 1; if (ms1 > 32) ms1 = 32;
             Conv1BwdP c1{};
             c1.dyraw = dslab; c1.lddy = CTOT[b]; c1.y = nullptr; c1.ldy = 0; c1.has_bn_out = 0;
-            c1.bn_out = bnt; c1.bb_out = BnBwd{nullptr, nullptr};
+            c1.bn_out = bnt; c1.bb_out = BnBwd{nullptr, nullptr, 0, 0};
             c1.M = M; c1.N = Kp / 2;
             c1.x = at<float>(ws, P.slab[t]); c1.ldx = CTOT[t]; c1.K = Kp; c1.bn_in = bnt;
             c1.w = prm[ip + 2]; c1.pool = 1; c1.in = P.g[t];
             c1.dw = grd[ip + 2];
             c1.dbn = at<float>(ws, P.dbn_in); c1.lddbn = CTOT[t];
             c1.s1 = at<double>(ws, P.bb_tr[t]); c1.s2 = at<double>(ws, P.bb_tr[t]) + 1024;
+            c1.srep = P.R[t]; c1.sstride = 2 * 1024;
             c1.msplit = ms1; c1.dgamma_out = nullptr; c1.dbeta_out = nullptr;
             TRY(mms_conv1_bwd_weight(&c1, s));
             TRY(mms_conv1_bwd_data(&c1, s));
             BnBwdApplyP ap{at<float>(ws, P.dbn_in), CTOT[t], at<float>(ws, P.slab[t]), CTOT[t], at<float>(ws, P.dslab[t]), CTOT[t],
-                           Mp, Kp, bnt, bbsrc(P.bb_tr[t], 1024), 0, grd[ip], grd[ip + 1]};
+                           Mp, Kp, bnt, bbsrc(P.bb_tr[t], 1024, P.R[t]), 0, grd[ip], grd[ip + 1]};
             TRY(mms_bn_bwd_apply(&ap, s));
         } else {       // stem
-            const BnSrc bn0 = mk_bn(ws, P.st_y0, 64, prm, IDX.n0w, nullptr, 0, P.M0, 1);
+            const BnSrc bn0 = mk_bn(ws, P.st_y0, 64, prm, IDX.n0w, nullptr, 0, P.M0, 1, P.R0);
             PoolBwdP pb{dslab, CTOT[0], at<uint8_t>(ws, P.argmax), P.g[0], P.g0, B, at<float>(ws, P.y0), bn0,
                         at<float>(ws, P.dbn0), at<double>(ws, P.bb_y0), at<double>(ws, P.bb_y0) + 64, at<int>(ws, P.coords0)};
+            pb.srep = P.R0; pb.sstride = 2 * 64;
             TRY(mms_pool_bwd(&pb, s));
             int ms0 = P.M0 / 1024; if (ms0 < 1) ms0 = 1; if (ms0 > 64) ms0 = 64;
-            Conv0BwdWP cw{at<float>(ws, P.dbn0), at<float>(ws, P.y0), bn0, bbsrc(P.bb_y0, 64), x, P.in, P.g0,
+            Conv0BwdWP cw{at<float>(ws, P.dbn0), at<float>(ws, P.y0), bn0, bbsrc(P.bb_y0, 64, P.R0), x, P.in, P.g0,
                           at<int>(ws, P.coords0), P.M0, grd[IDX.conv0], ms0, grd[IDX.n0w], grd[IDX.n0b]};
             TRY(mms_conv0_bwd_weight(&cw, s));
         }

@@ -183,7 +183,6 @@ extern "C" int mms_fb_pool_bwd(const FbPoolP* pp, hipStream_t s) {
 // ================================= whole-encoder driver =================================
 namespace {
 constexpr int FC[4] = {1, 32, 64, 128};
-struct BnRunEntry { const double* sum; const double* sumsq; float* rmean; float* rvar; long long* nbt; int C; float count; };
 struct FbPlan {
     int B; Dims3 g[4]; int M[4];
     size_t y[4], dy[4], dbn[4], st[4], bb[4], tab_bn, stats_begin, stats_end, total;
@@ -206,6 +205,7 @@ bool fb_plan(FbPlan& P, int B, int D, int H, int W) {
 template <class T> inline T* at(void* ws, size_t off) { return (T*)((char*)ws + off); }
 inline BnSrc fb_bn(void* ws, const FbPlan& P, int l, const float* const* prm, const void* const* buf, int train) {
     BnSrc b;
+    b.nrep = 0; b.rep_stride = 0;
     b.sum = at<double>(ws, P.st[l]); b.sumsq = b.sum + 128;
     b.rmean = buf ? (const float*)buf[3 * (l - 1)] : nullptr; b.rvar = buf ? (const float*)buf[3 * (l - 1) + 1] : nullptr;
     b.gamma = prm[4 * (l - 1) + 2]; b.beta = prm[4 * (l - 1) + 3];
@@ -233,6 +233,7 @@ extern "C" int mms_fb_init(void* ws, int B, int D, int H, int W, const void* con
         bn[l - 1].sum = at<double>(ws, P.st[l]); bn[l - 1].sumsq = bn[l - 1].sum + 128;
         bn[l - 1].rmean = (float*)buffers[3 * (l - 1)]; bn[l - 1].rvar = (float*)buffers[3 * (l - 1) + 1];
         bn[l - 1].nbt = (long long*)buffers[3 * (l - 1) + 2]; bn[l - 1].C = FC[l]; bn[l - 1].count = (float)P.M[l];
+        bn[l - 1].nrep = 0; bn[l - 1].rep_stride = 0;
     }
     if (hipMemcpyAsync(at<void>(ws, P.tab_bn), bn, sizeof(bn), hipMemcpyHostToDevice, s) != hipSuccess) return MMS_ERR_LAUNCH;
     if (hipStreamSynchronize(s) != hipSuccess) return MMS_ERR_LAUNCH;
@@ -274,7 +275,7 @@ extern "C" int mms_fb_backward(void* ws, int B, int D, int H, int W, const float
     for (int l = 3; l >= 1; --l) {
         // BN_l backward: dbn_l -> dy_l (gradient w.r.t. the raw conv output), BN parameter grads
         BnBwdApplyP ap{at<float>(ws, P.dbn[l]), FC[l], at<float>(ws, P.y[l]), FC[l], at<float>(ws, P.dy[l]), FC[l], P.M[l], FC[l],
-                       fb_bn(ws, P, l, prm, nullptr, 1), BnBwd{at<double>(ws, P.bb[l]), at<double>(ws, P.bb[l]) + 128}, 0,
+                       fb_bn(ws, P, l, prm, nullptr, 1), BnBwd{at<double>(ws, P.bb[l]), at<double>(ws, P.bb[l]) + 128, 0, 0}, 0,
                        grd[4 * (l - 1) + 2], grd[4 * (l - 1) + 3]};
         TRY(mms_bn_bwd_apply(&ap, s));
         FbConvP c{};
