@@ -108,6 +108,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--concurrent-folds", type=int, default=4,
                     help="fold models trained concurrently per GPU, one HIP stream + step graph each (mode fold)")
+    ap.add_argument("--fold-group", type=int, default=1,
+                    help="fold models advanced in lock-step by ONE launch sequence (FoldGroupEngine, *_group entry points); "
+                         "--concurrent-folds then counts concurrent groups")
     ap.add_argument("--mode", choices=["fold", "ddp"], default="fold",
                     help="N>1: 'fold' = K-fold units sharded over ranks, no collective (default); 'ddp' = one model, global "
                          "batch N*B, flat gradient all-reduce (RCCL) per step")
@@ -134,48 +137,90 @@ def main():
     folds = data.kfold_indices(cohort["n"], 5, seed=42)
     ddp = args.mode == "ddp" and world > 1
     F = 1 if ddp else max(1, args.concurrent_folds)
-    engines, streams, orders = [], [], []
+    G = 1 if ddp else max(1, min(args.fold_group, 8))
+    engines, groups, streams, orders = [], [], [], []          # engines/orders: one per fold model, index f * G + g
     for f in range(F):
-        fold = 0 if ddp else (rank * F + f) % 5
-        train_idx = torch.as_tensor(folds[fold][0])
-        torch.manual_seed(42 if ddp else 42 + rank * F + f)       # ddp: identical initial weights on every rank
-        model = models.MultiModalSurvivalNet(rna_dim=rna_dim).to(dev)
-        model.train()
-        engines.append(FusedOptimizer(model, lr=1e-4, weight_decay=1e-4, adamw=False).engine)
+        ms = []
+        for g in range(G):
+            unit = rank * F * G + f * G + g
+            fold = 0 if ddp else unit % 5
+            train_idx = torch.as_tensor(folds[fold][0])
+            torch.manual_seed(42 if ddp else 42 + unit)           # ddp: identical initial weights on every rank
+            model = models.MultiModalSurvivalNet(rna_dim=rna_dim).to(dev)
+            model.train()
+            ms.append(model)
+            gen = torch.Generator().manual_seed(7 + f * G + g)
+            orders.append(train_idx[torch.randperm(len(train_idx), generator=gen)].to(dev))
+        if G > 1:
+            from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
+            groups.append(FoldGroupEngine(ms, lr=1e-4, weight_decay=1e-4, adamw=False))
+            engines.extend(groups[-1].engines)
+        else:
+            engines.append(FusedOptimizer(ms[0], lr=1e-4, weight_decay=1e-4, adamw=False).engine)
         streams.append(torch.cuda.Stream(device=dev))
-        gen = torch.Generator().manual_seed(7 + f)
-        orders.append(train_idx[torch.randperm(len(train_idx), generator=gen)].to(dev))
     gb = B * world if ddp else B                                  # patients per step handled by one model
 
-    def step(i, nf=F):
-        f = i % nf
-        order = orders[f]
+    def batch_of(m, k):
+        order = orders[m]
         nb = len(order) // gb                                     # full (global) batches of the fold's train split
-        k = (i // nf) % nb
-        o = k * gb + (rank * B if ddp else 0)                     # ddp: this rank's shard of the global batch
+        o = (k % nb) * gb + (rank * B if ddp else 0)              # ddp: this rank's shard of the global batch
         j = order[o:o + B]
         lab = cohort["label"][j]
+        return dict(ct=cohort["image"][j], rna=cohort["rnaseq"][j], clinical=cohort["clinical"][j], time=lab[:, 0], event=lab[:, 1])
+
+    def launch(u, nf, members):
+        """launch unit u: `members` (<= G) fold models of group u % nf each take one step (one launch sequence)"""
+        f = u % nf
+        k = u // nf
         with torch.cuda.stream(streams[f]):
-            engines[f].train_step(cohort["image"][j], cohort["rnaseq"][j], cohort["clinical"][j], time=lab[:, 0],
-                                  event=lab[:, 1], skip_if_unusable=True, use_graph=not args.no_graph,
-                                  ddp_world=world if ddp else 1)
+            if G > 1:
+                groups[f].train_step([batch_of(f * G + g, k) for g in range(members)], members=tuple(range(members)),
+                                     skip_if_unusable=True, use_graph=not args.no_graph)
+            else:
+                engines[f].train_step(skip_if_unusable=True, use_graph=not args.no_graph, ddp_world=world if ddp else 1,
+                                      **batch_of(f, k))
+
+    def run(nsteps, nf):
+        """exactly nsteps steps (one step = one batch of one fold model), dealt over nf groups of G lock-step models"""
+        u, left = 0, nsteps
+        while left > 0:
+            m = min(G, left)
+            launch(u, nf, m)
+            u += 1; left -= m
 
     def timed(nsteps, nf):
         torch.cuda.synchronize()
         D.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(nsteps):
-            step(i, nf)
+        run(nsteps, nf)
         torch.cuda.synchronize()
         D.barrier()
         torch.cuda.synchronize()
         return D.max_over_ranks(time.perf_counter() - t0, dev)
 
-    for i in range(max(args.warmup, 3 * F)):                      # includes each fold model's graph capture
-        step(i)
+    run(max(args.warmup, 3 * F * G), F)                           # includes each fold model's / group's graph capture
+    if G > 1 and args.steps % G:
+        run(args.steps % G, 1)                                    # the ragged tail's sub-group graph, captured outside the timed region
     dt = timed(args.steps, F)
-    dt1 = timed(max(args.steps // 3, 10), 1) / max(args.steps // 3, 10) if F > 1 else dt / args.steps   # single chain
+    # single chain: ONE fold model alone on the GPU (no grouping, no concurrency), same graph-replayed step
+    if F * G > 1:
+        n1 = max(args.steps // (3 * F * G), 10)
+        if G > 1:
+            def one(i):
+                groups[0].train_step([batch_of(0, i)], members=(0,), skip_if_unusable=True, use_graph=not args.no_graph)
+            for i in range(3):
+                one(i)
+            torch.cuda.synchronize(); D.barrier()
+            t0 = time.perf_counter()
+            for i in range(n1):
+                one(i)
+            torch.cuda.synchronize(); D.barrier()
+            dt1 = D.max_over_ranks(time.perf_counter() - t0, dev) / n1
+        else:
+            dt1 = timed(n1, 1) / n1
+    else:
+        dt1 = dt / args.steps
     stats = engines[0].epoch_stats()
 
     if rank == 0:
@@ -187,8 +232,8 @@ def main():
             "config": {"workload": "MultiModalSurvivalNet (DenseNet121-3D CT 64x64x32 + RNA-seq 5005 + clinical), "
                                    "109 synthetic complete patients, 5-fold split, batch 4, Adam lr 1e-4 wd 1e-4, clip 1.0",
                        "global_batch": world * B, "parallelism": (f"ddp x{world} (flat gradient all-reduce per step, local BN + local Cox risk set)" if ddp else
-                                       f"kfold-shard x{world} ranks x {F} concurrent fold models per GPU (one stream + step graph each, no collective)"),
-                       "concurrent_folds": F, "single_chain_patients_per_s": world * B / dt1, "single_chain_ms_per_step": dt1 * 1e3,
+                                       f"kfold-shard x{world} ranks x {F} concurrent groups x {G} lock-step fold models per GPU (one stream + step graph per group, no collective)"),
+                       "concurrent_folds": F, "fold_group": G, "single_chain_patients_per_s": world * B / dt1, "single_chain_ms_per_step": dt1 * 1e3,
                        "hip_graph": not args.no_graph, "mean_train_loss": stats["sum_loss"] / max(stats["n_batches"], 1)},
         }
         avg_t, avg_f = measure_dominant_kernel(B, dims, dev)

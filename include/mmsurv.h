@@ -31,6 +31,7 @@ typedef struct ihipEvent_t* hipEvent_t;
 #define MMS_OK 0
 #define MMS_ERR_ARG (-1)
 #define MMS_ERR_LAUNCH (-2)
+#define MMS_MAX_GROUP 8      /* models per fold-group launch (the *_group entry points) */
 
 #ifdef __cplusplus
 extern "C" {
@@ -314,6 +315,9 @@ typedef struct AdamP {
     float* step;                    // [1] step counter (incremented by the update kernel when not skipped)
     const float* skip_flag;         // null or device scalar: update only if *skip_flag != 0
     int adamw;                      // 0: Adam with L2-coupled weight decay; 1: AdamW (decoupled)
+    /* optional per-step bookkeeping done by mms_grad_sumsq (all nullable): acc[4] += {loss*usable, usable, entropy, 1} */
+    float* acc; const float* cox_out; const float* entropy;
+    int* rng;                       // [2] dropout (seed, step counter): counter += 1 after the step's kernels have used it
 } AdamP;
 
 /* ---- ABI self-description ---- */
@@ -384,6 +388,44 @@ int mms_dn121_backward(void* ws, int B, int D, int H, int W, const float* x, con
 int mms_dn121_backward_mt(void* ws, int B, int D, int H, int W, const float* x, const void* const* params,
                           const float* dout, int lddout, void* const* grads, hipStream_t s, hipStream_t side,
                           hipEvent_t ev_fork, hipEvent_t ev_join);
+
+/* =========================== fold groups =====================================================================
+ * The reference trains its K fold models one after the other (R/scripts/training/final_multimodal.py:316-402,
+ * partial_modality_training.py:482-560, simple_fusion.py:318-436); they are independent, so this library can advance
+ * ng <= MMS_MAX_GROUP of them in lock-step: every *_group entry point takes an ARRAY of ng parameter blocks (one per
+ * model, identical shapes, any pointers) and issues ONE launch whose grid carries the model index as an extra
+ * dimension.  Per-model arithmetic is exactly that of the single-model entry point (which is the ng = 1 case of the
+ * same kernel); a batch-4 step of one model cannot fill 256 CUs, a group of them can. */
+int mms_conv0_fwd_group(const Conv0FwdP* p, int ng, hipStream_t s);
+int mms_pool_fwd_group(const PoolFwdP* p, int ng, hipStream_t s);
+int mms_conv1_fwd_group(const Conv1FwdP* p, int ng, hipStream_t s);
+int mms_conv3_fwd_group(const Conv3FwdP* p, int ng, hipStream_t s);
+int mms_head_fwd_group(const HeadFwdP* p, int ng, hipStream_t s);
+int mms_conv3_bwd_data_group(const Conv3BwdDataP* p, int ng, hipStream_t s);
+int mms_conv3_bwd_weight_group(const Conv3BwdWP* p, int ng, hipStream_t s);
+int mms_conv1_bwd_data_group(const Conv1BwdP* p, int ng, hipStream_t s);
+int mms_conv1_bwd_weight_group(const Conv1BwdP* p, int ng, hipStream_t s);
+int mms_bn_bwd_apply_group(const BnBwdApplyP* p, int ng, hipStream_t s);
+int mms_head_bwd_group(const HeadBwdP* p, int ng, hipStream_t s);
+int mms_pool_bwd_group(const PoolBwdP* p, int ng, hipStream_t s);
+int mms_conv0_bwd_weight_group(const Conv0BwdWP* p, int ng, hipStream_t s);
+int mms_pack_conv3_table_group(const void* const* tables_dev, int ng, int nlayers, hipStream_t s);
+int mms_bn_running_update_group(const void* const* tables_dev, int ng, int n, float momentum, hipStream_t s);
+int mms_zero_regions_group(void* const* regions_dev, int ng, size_t bytes, hipStream_t s);   /* 16-B aligned regions of equal size, zero-filled by one launch */
+int mms_linear_fwd_group(const LinearFwdP* p, int ng, hipStream_t s);
+int mms_linear_bwd_group(const LinearBwdP* p, int ng, hipStream_t s);
+int mms_gate_fwd_group(const GateP* p, int ng, hipStream_t s);
+int mms_gate_bwd_group(const GateP* p, int ng, hipStream_t s);
+int mms_cox_fwd_bwd_group(const CoxP* p, int ng, hipStream_t s);
+int mms_grad_sumsq_group(const AdamP* p, int ng, hipStream_t s);
+int mms_clip_adam_group(const AdamP* p, int ng, hipStream_t s);
+/* whole-encoder drivers: entry g of every array describes model g (arguments as mms_dn121_forward / _backward) */
+int mms_dn121_forward_group(int ng, void* const* ws, int B, int D, int H, int W, const float* const* x,
+                            const void* const* const* params, const void* const* const* buffers, float* const* out,
+                            int ldo, int train, hipStream_t s);
+int mms_dn121_backward_group(int ng, void* const* ws, int B, int D, int H, int W, const float* const* x,
+                             const void* const* const* params, const float* const* dout, int lddout,
+                             void* const* const* grads, hipStream_t s);
 
 #ifdef __cplusplus
 }

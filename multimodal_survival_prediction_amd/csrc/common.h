@@ -9,6 +9,20 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Fold groups: one launch advances up to MMS_MAX_GROUP independent models of identical shape (the K-fold models of the
+// reference's cross-validation loop, final_multimodal.py:316-402).  The kernel argument is the array of the models'
+// parameter blocks BY VALUE (<= 8 x 328 B, kernarg segment); the model index is an extra grid dimension: blockIdx.z for
+// plain kernels, blockIdx.z / zdim for the tile-GEMM core (whose own z = blockIdx.z % zdim).  Per-model work is exactly
+// the single-model kernel's: grouping changes placement only, never results.
+template <class P> struct Grp { P p[MMS_MAX_GROUP]; int zdim; };
+template <class P> static inline bool grp_fill(Grp<P>& a, const P* pp, int ng, int zdim) {
+    if (!pp || ng < 1 || ng > MMS_MAX_GROUP) return false;
+    for (int g = 0; g < ng; ++g) a.p[g] = pp[g];
+    a.zdim = zdim;
+    return true;
+}
+#define MMS_SINGLE(name, T) extern "C" int name(const T* p, hipStream_t s) { return name##_group(p, 1, s); }
+
 
 // Statistic accumulators may be replicated (fp64 atomics on one address serialise: 256 workgroups adding to the same 64
 // words cost ~5 us): a producer workgroup adds to replica blockIdx.x % nrep, readers add the replicas up.

@@ -110,7 +110,8 @@ struct Conv3BwdDataOp {
 };
 
 // tap-split variant: sum the 27 partials, apply the relu2 mask, write dbn2 and the BN2-backward sums
-__global__ __launch_bounds__(256) void conv3_bwd_data_reduce_kernel(const Conv3BwdDataP p) {
+__global__ __launch_bounds__(256) void conv3_bwd_data_reduce_kernel(const Grp<Conv3BwdDataP> grp) {
+    const Conv3BwdDataP& p = grp.p[blockIdx.z];
     __shared__ double red[2][2][128];
     const int c = threadIdx.x & 127, rg = threadIdx.x >> 7;
     float mu, rstd;
@@ -139,18 +140,27 @@ __global__ __launch_bounds__(256) void conv3_bwd_data_reduce_kernel(const Conv3B
     }
 }
 
-extern "C" int mms_conv3_bwd_data(const Conv3BwdDataP* pp, hipStream_t s) {
+extern "C" int mms_conv3_bwd_data_group(const Conv3BwdDataP* pp, int ng, hipStream_t s) {
+    if (!pp || ng < 1 || ng > MMS_MAX_GROUP) return MMS_ERR_ARG;
     const Conv3BwdDataP& p = *pp;
     if (p.M <= 0 || p.lddz % 4 != 0) return MMS_ERR_ARG;
+    for (int g = 1; g < ng; ++g) {
+        const Conv3BwdDataP& q = pp[g];
+        if (q.M != p.M || q.lddz % 4 != 0 || q.g.D != p.g.D || q.g.H != p.g.H || q.g.W != p.g.W ||
+            (q.partial == nullptr) != (p.partial == nullptr) || q.nsplit != p.nsplit) return MMS_ERR_ARG;
+    }
     if (p.partial) {
         if (p.nsplit < 1 || p.nsplit > 27 || (p.nsplit - 1) * ((27 + p.nsplit - 1) / p.nsplit) >= 27) return MMS_ERR_ARG;
-        int rc = launch_tile_gemm<Conv3BwdDataOp<true>>(p, dim3((p.M + 31) / 32, 1, p.nsplit), s);
+        int rc = launch_tile_gemm<Conv3BwdDataOp<true>>(pp, ng, dim3((p.M + 31) / 32, 1, p.nsplit), s);
         if (rc != MMS_OK) return rc;
-        MMS_LAUNCH(conv3_bwd_data_reduce_kernel, dim3((p.M + 3) / 4), dim3(256), 0, s, p);
+        Grp<Conv3BwdDataP> a;
+        grp_fill(a, pp, ng, 1);
+        MMS_LAUNCH(conv3_bwd_data_reduce_kernel, dim3((p.M + 3) / 4, 1, ng), dim3(256), 0, s, a);
         return mms_check_launch();
     }
-    return launch_tile_gemm<Conv3BwdDataOp<false>>(p, dim3((p.M + 31) / 32, 1, 1), s);
+    return launch_tile_gemm<Conv3BwdDataOp<false>>(pp, ng, dim3((p.M + 31) / 32, 1, 1), s);
 }
+MMS_SINGLE(mms_conv3_bwd_data, Conv3BwdDataP)
 
 // ------------------------------------------------------------------------------------------------------
 // conv3 backward-weight: dW[cout][cin][tap] += sum_m a2[m + off(tap)][cin] * dz[m][cout]
@@ -254,12 +264,19 @@ extern "C" int mms_unpack_conv3_grads(const void* table_host, int nlayers, hipSt
     return mms_check_launch();
 }
 
-extern "C" int mms_conv3_bwd_weight(const Conv3BwdWP* pp, hipStream_t s) {
+extern "C" int mms_conv3_bwd_weight_group(const Conv3BwdWP* pp, int ng, hipStream_t s) {
+    if (!pp || ng < 1 || ng > MMS_MAX_GROUP) return MMS_ERR_ARG;
     const Conv3BwdWP& p = *pp;
     if (p.M <= 0 || p.msplit <= 0 || p.lddz % 4 != 0) return MMS_ERR_ARG;
     if ((((p.M + p.msplit - 1) / p.msplit + 31) & ~31) > 1024) return MMS_ERR_ARG;    // row chunk must fit the LDS mask table
-    return launch_tile_gemm<Conv3BwdWOp>(p, dim3(1, 1, 27 * p.msplit), s);
+    for (int g = 1; g < ng; ++g) {
+        const Conv3BwdWP& q = pp[g];
+        if (q.M != p.M || q.msplit != p.msplit || q.lddz % 4 != 0 || q.g.D != p.g.D || q.g.H != p.g.H || q.g.W != p.g.W ||
+            q.dw_tapmajor != p.dw_tapmajor) return MMS_ERR_ARG;
+    }
+    return launch_tile_gemm<Conv3BwdWOp>(pp, ng, dim3(1, 1, 27 * p.msplit), s);
 }
+MMS_SINGLE(mms_conv3_bwd_weight, Conv3BwdWP)
 
 // ------------------------------------------------------------------------------------------------------
 // 1x1 conv backward.  Shared pieces: dy(m, n) with the output-side BN backward folded in, a(m, k) recompute.
@@ -385,20 +402,32 @@ struct Conv1BwdDataOp {
     }
 };
 
-extern "C" int mms_conv1_bwd_data(const Conv1BwdP* pp, hipStream_t s) {
+static bool conv1_bwd_same(const Conv1BwdP* pp, int ng) {
+    const Conv1BwdP& p = *pp;
+    for (int g = 1; g < ng; ++g) {
+        const Conv1BwdP& q = pp[g];
+        if (q.M != p.M || q.N != p.N || q.K != p.K || q.ldx % 4 != 0 || q.lddy % 4 != 0 || q.pool != p.pool || q.has_bn_out != p.has_bn_out ||
+            q.msplit != p.msplit || q.in.D != p.in.D || q.in.H != p.in.H || q.in.W != p.in.W) return false;
+    }
+    return true;
+}
+extern "C" int mms_conv1_bwd_data_group(const Conv1BwdP* pp, int ng, hipStream_t s) {
+    if (!pp || ng < 1 || ng > MMS_MAX_GROUP) return MMS_ERR_ARG;
     const Conv1BwdP& p = *pp;
     if (p.M <= 0 || p.K % 32 != 0 || p.N % 32 != 0 || p.ldx % 4 != 0 || p.lddy % 4 != 0) return MMS_ERR_ARG;
     if (p.has_bn_out && p.N != 128) return MMS_ERR_ARG;
+    if (!conv1_bwd_same(pp, ng)) return MMS_ERR_ARG;
     const bool big = (long)p.M * p.K >= 256L * 64 * 64;
     if (big) {
         dim3 g((p.M + 63) / 64, (p.K + 63) / 64, 1);
-        return p.pool ? launch_tile_gemm<Conv1BwdDataOp<2, 2, 1, true>>(p, g, s)
-                      : launch_tile_gemm<Conv1BwdDataOp<2, 2, 1, false>>(p, g, s);
+        return p.pool ? launch_tile_gemm<Conv1BwdDataOp<2, 2, 1, true>>(pp, ng, g, s)
+                      : launch_tile_gemm<Conv1BwdDataOp<2, 2, 1, false>>(pp, ng, g, s);
     }
     dim3 g((p.M + 31) / 32, (p.K + 31) / 32, 1);
-    return p.pool ? launch_tile_gemm<Conv1BwdDataOp<1, 1, 4, true>>(p, g, s)
-                  : launch_tile_gemm<Conv1BwdDataOp<1, 1, 4, false>>(p, g, s);
+    return p.pool ? launch_tile_gemm<Conv1BwdDataOp<1, 1, 4, true>>(pp, ng, g, s)
+                  : launch_tile_gemm<Conv1BwdDataOp<1, 1, 4, false>>(pp, ng, g, s);
 }
+MMS_SINGLE(mms_conv1_bwd_data, Conv1BwdP)
 
 // ---- weight: dW[n][k] += sum_m dy[m][n] * a[m][k] ; rows n, cols k, reduce over m (split over grid.z)
 template <bool POOL>
@@ -482,17 +511,21 @@ struct Conv1BwdWOp {
     }
 };
 
-extern "C" int mms_conv1_bwd_weight(const Conv1BwdP* pp, hipStream_t s) {
+extern "C" int mms_conv1_bwd_weight_group(const Conv1BwdP* pp, int ng, hipStream_t s) {
+    if (!pp || ng < 1 || ng > MMS_MAX_GROUP) return MMS_ERR_ARG;
     const Conv1BwdP& p = *pp;
     if (p.M <= 0 || p.msplit <= 0 || p.K % 32 != 0 || p.N % 32 != 0) return MMS_ERR_ARG;
+    if (!conv1_bwd_same(pp, ng)) return MMS_ERR_ARG;
     dim3 g((p.N + 63) / 64, (p.K + 63) / 64, p.msplit);
-    return p.pool ? launch_tile_gemm<Conv1BwdWOp<true>>(p, g, s) : launch_tile_gemm<Conv1BwdWOp<false>>(p, g, s);
+    return p.pool ? launch_tile_gemm<Conv1BwdWOp<true>>(pp, ng, g, s) : launch_tile_gemm<Conv1BwdWOp<false>>(pp, ng, g, s);
 }
+MMS_SINGLE(mms_conv1_bwd_weight, Conv1BwdP)
 
 // ------------------------------------------------------------------------------------------------------
 // BN backward apply into the gradient slab: dx[:, 0:C] (+)= g*rstd*(dbn - s1/M - xhat*s2/M)
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyP p) {
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const Grp<BnBwdApplyP> grp) {
+    const BnBwdApplyP& p = grp.p[blockIdx.z];
     // workgroup = 32 rows x one 256-channel chunk; each thread owns 4 channels and keeps their constants in registers
     const int tid = threadIdx.x, c = blockIdx.y * 256 + (tid & 63) * 4, rg = tid >> 6;
     if (c >= p.C) return;
@@ -524,18 +557,26 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyP p) 
     }
 }
 
-extern "C" int mms_bn_bwd_apply(const BnBwdApplyP* pp, hipStream_t s) {
+extern "C" int mms_bn_bwd_apply_group(const BnBwdApplyP* pp, int ng, hipStream_t s) {
+    Grp<BnBwdApplyP> a;
+    if (!grp_fill(a, pp, ng, 1)) return MMS_ERR_ARG;
     const BnBwdApplyP& p = *pp;
     if (p.M <= 0 || p.C % 4 != 0 || p.lddbn % 4 || p.ldx % 4 || p.lddx % 4) return MMS_ERR_ARG;
-    MMS_LAUNCH(bn_bwd_apply_kernel, dim3((p.M + 31) / 32, (p.C + 255) / 256), dim3(256), 0, s, p);
+    for (int g = 1; g < ng; ++g) {
+        const BnBwdApplyP& q = pp[g];
+        if (q.M != p.M || q.C != p.C || q.lddbn % 4 || q.ldx % 4 || q.lddx % 4 || q.accumulate != p.accumulate) return MMS_ERR_ARG;
+    }
+    MMS_LAUNCH(bn_bwd_apply_kernel, dim3((p.M + 31) / 32, (p.C + 255) / 256, ng), dim3(256), 0, s, a);
     return mms_check_launch();
 }
+MMS_SINGLE(mms_bn_bwd_apply, BnBwdApplyP)
 
 // ------------------------------------------------------------------------------------------------------
 // head backward: Linear(C,N) + global-avg-pool + relu + norm5.  M = B*V rows is small: one thread per channel
 // walks all rows, so the BN sums need no atomics.
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void head_bwd_feat_kernel(const HeadBwdP p) {
+__global__ __launch_bounds__(256) void head_bwd_feat_kernel(const Grp<HeadBwdP> grp) {
+    const HeadBwdP& p = grp.p[blockIdx.z];
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= p.C) return;
     float mu, rs;
@@ -565,7 +606,8 @@ __global__ __launch_bounds__(256) void head_bwd_feat_kernel(const HeadBwdP p) {
     p.dgamma[c] += (float)s2;
     p.dbeta[c] += (float)s1;
 }
-__global__ __launch_bounds__(256) void head_bwd_w_kernel(const HeadBwdP p) {
+__global__ __launch_bounds__(256) void head_bwd_w_kernel(const Grp<HeadBwdP> grp) {
+    const HeadBwdP& p = grp.p[blockIdx.z];
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= p.N * p.C) return;
     const int n = idx / p.C, c = idx % p.C;
@@ -578,19 +620,27 @@ __global__ __launch_bounds__(256) void head_bwd_w_kernel(const HeadBwdP p) {
         p.dbias[n] += d;
     }
 }
-extern "C" int mms_head_bwd(const HeadBwdP* pp, hipStream_t s) {
+extern "C" int mms_head_bwd_group(const HeadBwdP* pp, int ng, hipStream_t s) {
+    Grp<HeadBwdP> a;
+    if (!grp_fill(a, pp, ng, 1)) return MMS_ERR_ARG;
     const HeadBwdP& p = *pp;
     if (p.B <= 0) return MMS_ERR_ARG;
-    MMS_LAUNCH(head_bwd_feat_kernel, dim3((p.C + 255) / 256), dim3(256), 0, s, p);
-    MMS_LAUNCH(head_bwd_w_kernel, dim3((p.N * p.C + 255) / 256), dim3(256), 0, s, p);
+    for (int g = 1; g < ng; ++g) {
+        const HeadBwdP& q = pp[g];
+        if (q.B != p.B || q.C != p.C || q.N != p.N || q.V != p.V) return MMS_ERR_ARG;
+    }
+    MMS_LAUNCH(head_bwd_feat_kernel, dim3((p.C + 255) / 256, 1, ng), dim3(256), 0, s, a);
+    MMS_LAUNCH(head_bwd_w_kernel, dim3((p.N * p.C + 255) / 256, 1, ng), dim3(256), 0, s, a);
     return mms_check_launch();
 }
+MMS_SINGLE(mms_head_bwd, HeadBwdP)
 
 // ------------------------------------------------------------------------------------------------------
 // maxpool(3,2,1) backward (gather form, no atomics on the gradient) + relu0 mask -> dbn0, BN0 sums
 // one workgroup = 256 conv0-grid voxels x 64 channels
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolBwdP p) {
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const Grp<PoolBwdP> grp) {
+    const PoolBwdP& p = grp.p[blockIdx.z];
     // workgroup = 64 conv0-grid voxels x 64 channels.  Each input voxel is covered by 1 or 2 windows per axis
     // (od in {id>>1, (id+1)>>1}; they coincide for even id): all 8 candidates are loaded unconditionally from clamped
     // addresses and selected afterwards (the duplicate candidate of an even coordinate is masked out).
@@ -646,13 +696,21 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolBwdP p) {
         atomicAdd(&stat_rep(p.s2, p.srep, p.sstride)[c], red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
     }
 }
-extern "C" int mms_pool_bwd(const PoolBwdP* pp, hipStream_t s) {
+extern "C" int mms_pool_bwd_group(const PoolBwdP* pp, int ng, hipStream_t s) {
+    Grp<PoolBwdP> a;
+    if (!grp_fill(a, pp, ng, 1)) return MMS_ERR_ARG;
     const PoolBwdP& p = *pp;
     const int Min = p.B * p.in.D * p.in.H * p.in.W;
     if (Min <= 0) return MMS_ERR_ARG;
-    MMS_LAUNCH(pool_bwd_kernel, dim3((Min + 63) / 64), dim3(256), 0, s, p);
+    for (int g = 1; g < ng; ++g) {
+        const PoolBwdP& q = pp[g];
+        if (q.B != p.B || q.in.D != p.in.D || q.in.H != p.in.H || q.in.W != p.in.W || q.out.D != p.out.D || q.out.H != p.out.H ||
+            q.out.W != p.out.W) return MMS_ERR_ARG;
+    }
+    MMS_LAUNCH(pool_bwd_kernel, dim3((Min + 63) / 64, 1, ng), dim3(256), 0, s, a);
     return mms_check_launch();
 }
+MMS_SINGLE(mms_pool_bwd, PoolBwdP)
 
 // ------------------------------------------------------------------------------------------------------
 // conv0 backward-weight: dW0[n][k] += sum_m dy0[m][n] * x[patch(m,k)], dy0 = BN0-backward(dbn0)
@@ -726,8 +784,15 @@ struct Conv0BwdWOp {
         }
     }
 };
-extern "C" int mms_conv0_bwd_weight(const Conv0BwdWP* pp, hipStream_t s) {
+extern "C" int mms_conv0_bwd_weight_group(const Conv0BwdWP* pp, int ng, hipStream_t s) {
+    if (!pp || ng < 1 || ng > MMS_MAX_GROUP) return MMS_ERR_ARG;
     const Conv0BwdWP& p = *pp;
     if (p.M <= 0 || p.msplit <= 0) return MMS_ERR_ARG;
-    return launch_tile_gemm<Conv0BwdWOp>(p, dim3(6, 1, p.msplit), s);
+    for (int g = 1; g < ng; ++g) {
+        const Conv0BwdWP& q = pp[g];
+        if (q.M != p.M || q.msplit != p.msplit || q.in.D != p.in.D || q.in.H != p.in.H || q.in.W != p.in.W || q.out.D != p.out.D ||
+            q.out.H != p.out.H || q.out.W != p.out.W) return MMS_ERR_ARG;
+    }
+    return launch_tile_gemm<Conv0BwdWOp>(pp, ng, dim3(6, 1, p.msplit), s);
 }
+MMS_SINGLE(mms_conv0_bwd_weight, Conv0BwdWP)

@@ -102,21 +102,28 @@ struct Conv1FwdOp {
     }
 };
 
-extern "C" int mms_conv1_fwd(const Conv1FwdP* pp, hipStream_t s) {
+extern "C" int mms_conv1_fwd_group(const Conv1FwdP* pp, int ng, hipStream_t s) {
+    if (!pp || ng < 1 || ng > MMS_MAX_GROUP) return MMS_ERR_ARG;
     const Conv1FwdP& p = *pp;
     if (p.K % 32 != 0 || p.K > 1024 || p.ldx % 4 != 0 || p.M <= 0) return MMS_ERR_ARG;
     if (p.pool && ((p.in.D | p.in.H | p.in.W) & 1)) return MMS_ERR_ARG;
+    for (int g = 1; g < ng; ++g) {
+        const Conv1FwdP& q = pp[g];
+        if (q.M != p.M || q.N != p.N || q.K != p.K || q.ldx % 4 != 0 || q.pool != p.pool || q.in.D != p.in.D || q.in.H != p.in.H ||
+            q.in.W != p.in.W) return MMS_ERR_ARG;
+    }
     // big M: 64x64 tiles, no in-workgroup K split; small M: 32x32 tiles with the 4 waves splitting K
     const bool big = (long)p.M * p.N >= 256L * 64 * 64;
     if (big) {
         dim3 g((p.M + 63) / 64, (p.N + 63) / 64, 1);
-        return p.pool ? launch_tile_gemm<Conv1FwdOp<2, 2, 1, true>>(p, g, s)
-                      : launch_tile_gemm<Conv1FwdOp<2, 2, 1, false>>(p, g, s);
+        return p.pool ? launch_tile_gemm<Conv1FwdOp<2, 2, 1, true>>(pp, ng, g, s)
+                      : launch_tile_gemm<Conv1FwdOp<2, 2, 1, false>>(pp, ng, g, s);
     }
     dim3 g((p.M + 31) / 32, (p.N + 31) / 32, 1);
-    return p.pool ? launch_tile_gemm<Conv1FwdOp<1, 1, 4, true>>(p, g, s)
-                  : launch_tile_gemm<Conv1FwdOp<1, 1, 4, false>>(p, g, s);
+    return p.pool ? launch_tile_gemm<Conv1FwdOp<1, 1, 4, true>>(pp, ng, g, s)
+                  : launch_tile_gemm<Conv1FwdOp<1, 1, 4, false>>(pp, ng, g, s);
 }
+MMS_SINGLE(mms_conv1_fwd, Conv1FwdP)
 
 // ------------------------------------------------------------------------------------------------------
 // 3x3x3 conv (pad 1): implicit GEMM, K = (tap, cin) = 27*128, one K-step per tap
@@ -210,7 +217,8 @@ struct Conv3FwdOp {
 };
 
 // sums the 27 tap partials (fixed order: deterministic), writes the slab columns, accumulates the batch statistics
-__global__ __launch_bounds__(256) void conv3_fwd_reduce_kernel(const Conv3FwdP p) {
+__global__ __launch_bounds__(256) void conv3_fwd_reduce_kernel(const Grp<Conv3FwdP> grp) {
+    const Conv3FwdP& p = grp.p[blockIdx.z];
     __shared__ double red[2][8][32];
     const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
     double s = 0, q = 0;
@@ -236,20 +244,29 @@ __global__ __launch_bounds__(256) void conv3_fwd_reduce_kernel(const Conv3FwdP p
     }
 }
 
-extern "C" int mms_conv3_fwd(const Conv3FwdP* pp, hipStream_t s) {
+extern "C" int mms_conv3_fwd_group(const Conv3FwdP* pp, int ng, hipStream_t s) {
+    if (!pp || ng < 1 || ng > MMS_MAX_GROUP) return MMS_ERR_ARG;
     const Conv3FwdP& p = *pp;
     if (p.M <= 0 || p.ldo % 4 != 0) return MMS_ERR_ARG;
+    for (int g = 1; g < ng; ++g) {
+        const Conv3FwdP& q = pp[g];
+        if (q.M != p.M || q.ldo % 4 != 0 || q.g.D != p.g.D || q.g.H != p.g.H || q.g.W != p.g.W || (q.partial == nullptr) != (p.partial == nullptr) ||
+            q.nsplit != p.nsplit) return MMS_ERR_ARG;
+    }
     if (p.partial) {
         if (p.nsplit < 1 || p.nsplit > 27) return MMS_ERR_ARG;
         const int tpw = (27 + p.nsplit - 1) / p.nsplit;
         if ((p.nsplit - 1) * tpw >= 27) return MMS_ERR_ARG;       // every workgroup must own at least one tap
-        int rc = launch_tile_gemm<Conv3FwdOp<true>>(p, dim3((p.M + 31) / 32, 1, p.nsplit), s);
+        int rc = launch_tile_gemm<Conv3FwdOp<true>>(pp, ng, dim3((p.M + 31) / 32, 1, p.nsplit), s);
         if (rc != MMS_OK) return rc;
-        MMS_LAUNCH(conv3_fwd_reduce_kernel, dim3((p.M + 7) / 8), dim3(256), 0, s, p);
+        Grp<Conv3FwdP> a;
+        grp_fill(a, pp, ng, 1);
+        MMS_LAUNCH(conv3_fwd_reduce_kernel, dim3((p.M + 7) / 8, 1, ng), dim3(256), 0, s, a);
         return mms_check_launch();
     }
-    return launch_tile_gemm<Conv3FwdOp<false>>(p, dim3((p.M + 31) / 32, 1, 1), s);
+    return launch_tile_gemm<Conv3FwdOp<false>>(pp, ng, dim3((p.M + 31) / 32, 1, 1), s);
 }
+MMS_SINGLE(mms_conv3_fwd, Conv3FwdP)
 
 // ------------------------------------------------------------------------------------------------------
 // conv0: Conv3d(1, 64, k7, s2, p3) as implicit GEMM, K = 343 taps
@@ -302,16 +319,24 @@ struct Conv0FwdOp {
     }
 };
 
-extern "C" int mms_conv0_fwd(const Conv0FwdP* pp, hipStream_t s) {
+extern "C" int mms_conv0_fwd_group(const Conv0FwdP* pp, int ng, hipStream_t s) {
+    if (!pp || ng < 1 || ng > MMS_MAX_GROUP) return MMS_ERR_ARG;
     const Conv0FwdP& p = *pp;
     if (p.M <= 0) return MMS_ERR_ARG;
-    return launch_tile_gemm<Conv0FwdOp>(p, dim3((p.M + 63) / 64, 1, 1), s);
+    for (int g = 1; g < ng; ++g) {
+        const Conv0FwdP& q = pp[g];
+        if (q.M != p.M || q.in.D != p.in.D || q.in.H != p.in.H || q.in.W != p.in.W || q.out.D != p.out.D || q.out.H != p.out.H ||
+            q.out.W != p.out.W) return MMS_ERR_ARG;
+    }
+    return launch_tile_gemm<Conv0FwdOp>(pp, ng, dim3((p.M + 63) / 64, 1, 1), s);
 }
+MMS_SINGLE(mms_conv0_fwd, Conv0FwdP)
 
 // ------------------------------------------------------------------------------------------------------
 // bn0 + relu + maxpool(3,2,1): one workgroup = 32 pooled voxels x 64 channels
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pool_fwd_kernel(const PoolFwdP p) {
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const Grp<PoolFwdP> grp) {
+    const PoolFwdP& p = grp.p[blockIdx.z];
     // workgroup = 16 pooled voxels x 64 channels (4 voxel rows x 4 iterations).  The 27 window loads of a voxel are
     // issued together from clamped (always valid) addresses and selected afterwards: branch-free, 27 loads in flight.
     __shared__ double red[2][4][64];
@@ -357,18 +382,27 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const PoolFwdP p) {
     }
 }
 
-extern "C" int mms_pool_fwd(const PoolFwdP* pp, hipStream_t s) {
+extern "C" int mms_pool_fwd_group(const PoolFwdP* pp, int ng, hipStream_t s) {
+    Grp<PoolFwdP> a;
+    if (!grp_fill(a, pp, ng, 1)) return MMS_ERR_ARG;
     const PoolFwdP& p = *pp;
     int Mout = p.B * p.out.D * p.out.H * p.out.W;
     if (Mout <= 0) return MMS_ERR_ARG;
-    MMS_LAUNCH(pool_fwd_kernel, dim3((Mout + 15) / 16), dim3(256), 0, s, p);
+    for (int g = 1; g < ng; ++g) {
+        const PoolFwdP& q = pp[g];
+        if (q.B != p.B || q.in.D != p.in.D || q.in.H != p.in.H || q.in.W != p.in.W || q.out.D != p.out.D || q.out.H != p.out.H ||
+            q.out.W != p.out.W) return MMS_ERR_ARG;
+    }
+    MMS_LAUNCH(pool_fwd_kernel, dim3((Mout + 15) / 16, 1, ng), dim3(256), 0, s, a);
     return mms_check_launch();
 }
+MMS_SINGLE(mms_pool_fwd, PoolFwdP)
 
 // ------------------------------------------------------------------------------------------------------
 // head: norm5 + relu + global average pool + Linear(C, N)
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void head_fwd_kernel(const HeadFwdP p) {
+__global__ __launch_bounds__(256) void head_fwd_kernel(const Grp<HeadFwdP> grp) {
+    const HeadFwdP& p = grp.p[blockIdx.z];
     extern __shared__ float pooled[];   // [B][C]
     const int tid = threadIdx.x;
     for (int idx = tid; idx < p.B * p.C; idx += 256) {
@@ -393,13 +427,20 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadFwdP p) {
     }
 }
 
-extern "C" int mms_head_fwd(const HeadFwdP* pp, hipStream_t s) {
+extern "C" int mms_head_fwd_group(const HeadFwdP* pp, int ng, hipStream_t s) {
+    Grp<HeadFwdP> a;
+    if (!grp_fill(a, pp, ng, 1)) return MMS_ERR_ARG;
     const HeadFwdP& p = *pp;
     size_t smem = (size_t)p.B * p.C * sizeof(float);
     if (smem > 64 * 1024 || p.B <= 0) return MMS_ERR_ARG;
-    MMS_LAUNCH(head_fwd_kernel, dim3((p.N + 3) / 4), dim3(256), smem, s, p);
+    for (int g = 1; g < ng; ++g) {
+        const HeadFwdP& q = pp[g];
+        if (q.B != p.B || q.C != p.C || q.N != p.N || q.V != p.V) return MMS_ERR_ARG;
+    }
+    MMS_LAUNCH(head_fwd_kernel, dim3((p.N + 3) / 4, 1, ng), dim3(256), smem, s, a);
     return mms_check_launch();
 }
+MMS_SINGLE(mms_head_fwd, HeadFwdP)
 
 // ------------------------------------------------------------------------------------------------------
 // helpers: voxel coordinate tables, conv2 weight packing, BN running-stat update
@@ -434,9 +475,10 @@ extern "C" int mms_pack_conv3(const float* w, float* wpf, float* wpb, hipStream_
 
 // batched variant over a device table of layer pointers (one launch per forward)
 // one workgroup per (layer, cout): the 128 x 27 canonical slice goes through LDS so reads and writes are coalesced
-__global__ __launch_bounds__(256) void pack_conv3_table_kernel(const PackEntry* tab) {
+struct TabPtrs { const void* t[MMS_MAX_GROUP]; };
+__global__ __launch_bounds__(256) void pack_conv3_table_kernel(const TabPtrs tabs) {
     __shared__ float t[128 * 28];
-    const PackEntry e = tab[blockIdx.y];
+    const PackEntry e = ((const PackEntry*)tabs.t[blockIdx.z])[blockIdx.y];
     const int co = blockIdx.x;
     const float* src = e.w + (size_t)co * 128 * 27;
     for (int idx = threadIdx.x; idx < 128 * 27; idx += 256) t[(idx / 27) * 28 + idx % 27] = src[idx];
@@ -448,15 +490,20 @@ __global__ __launch_bounds__(256) void pack_conv3_table_kernel(const PackEntry* 
         e.wpb[((size_t)cin * 27 + tap) * 32 + co] = v;       // 4-byte scatter at stride 128 B: 442 KB per layer, L2-absorbed
     }
 }
-extern "C" int mms_pack_conv3_table(const void* table_dev, int nlayers, hipStream_t s) {
-    MMS_LAUNCH(pack_conv3_table_kernel, dim3(32, nlayers), dim3(256), 0, s,
-                       (const PackEntry*)table_dev);
+extern "C" int mms_pack_conv3_table_group(const void* const* tables_dev, int ng, int nlayers, hipStream_t s) {
+    if (!tables_dev || ng < 1 || ng > MMS_MAX_GROUP || nlayers <= 0) return MMS_ERR_ARG;
+    TabPtrs tp;
+    for (int g = 0; g < ng; ++g) tp.t[g] = tables_dev[g];
+    MMS_LAUNCH(pack_conv3_table_kernel, dim3(32, nlayers, ng), dim3(256), 0, s, tp);
     return mms_check_launch();
+}
+extern "C" int mms_pack_conv3_table(const void* table_dev, int nlayers, hipStream_t s) {
+    return mms_pack_conv3_table_group(&table_dev, 1, nlayers, s);
 }
 
 // running_mean/var momentum update (torch: running = 0.9*running + 0.1*batch, unbiased var; nbt += 1)
-__global__ void bn_running_update_kernel(const BnRunEntry* tab, float momentum) {
-    const BnRunEntry e = tab[blockIdx.x];
+__global__ void bn_running_update_kernel(const TabPtrs tabs, float momentum) {
+    const BnRunEntry e = ((const BnRunEntry*)tabs.t[blockIdx.z])[blockIdx.x];
     for (int c = threadIdx.x; c < e.C; c += blockDim.x) {
         double m = rep_sum(e.sum, c, e.nrep, e.rep_stride) / e.count, v = rep_sum(e.sumsq, c, e.nrep, e.rep_stride) / e.count - m * m;
         if (v < 0) v = 0;
@@ -466,8 +513,30 @@ __global__ void bn_running_update_kernel(const BnRunEntry* tab, float momentum) 
     }
     if (threadIdx.x == 0 && e.nbt) *e.nbt += 1;
 }
-extern "C" int mms_bn_running_update(const void* table_dev, int n, float momentum, hipStream_t s) {
-    if (n <= 0) return MMS_OK;
-    MMS_LAUNCH(bn_running_update_kernel, dim3(n), dim3(256), 0, s, (const BnRunEntry*)table_dev, momentum);
+// zero-fill of one region per model (the per-step statistic accumulators + gradient scratch): one launch for the group
+__global__ __launch_bounds__(256) void zero_regions_kernel(const TabPtrs regions, size_t n16) {
+    float4* dst = (float4*)regions.t[blockIdx.z];
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+extern "C" int mms_zero_regions_group(void* const* regions_dev, int ng, size_t bytes, hipStream_t s) {
+    if (!regions_dev || ng < 1 || ng > MMS_MAX_GROUP || (bytes & 15)) return MMS_ERR_ARG;
+    if (bytes == 0) return MMS_OK;
+    TabPtrs tp;
+    for (int g = 0; g < ng; ++g) { if (((uintptr_t)regions_dev[g]) & 15) return MMS_ERR_ARG; tp.t[g] = regions_dev[g]; }
+    size_t n16 = bytes >> 4, blocks = (n16 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    MMS_LAUNCH(zero_regions_kernel, dim3((unsigned)blocks, 1, ng), dim3(256), 0, s, tp, n16);
     return mms_check_launch();
+}
+extern "C" int mms_bn_running_update_group(const void* const* tables_dev, int ng, int n, float momentum, hipStream_t s) {
+    if (n <= 0) return MMS_OK;
+    if (!tables_dev || ng < 1 || ng > MMS_MAX_GROUP) return MMS_ERR_ARG;
+    TabPtrs tp;
+    for (int g = 0; g < ng; ++g) tp.t[g] = tables_dev[g];
+    MMS_LAUNCH(bn_running_update_kernel, dim3(n, 1, ng), dim3(256), 0, s, tp, momentum);
+    return mms_check_launch();
+}
+extern "C" int mms_bn_running_update(const void* table_dev, int n, float momentum, hipStream_t s) {
+    return mms_bn_running_update_group(&table_dev, 1, n, momentum, s);
 }

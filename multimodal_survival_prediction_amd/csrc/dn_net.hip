@@ -131,22 +131,23 @@ inline BnSrc mk_bn(void* ws, size_t st_off, int Ctot_, const float* const* prm, 
 }  // namespace
 
 extern "C" int mms_init_coords(int*, int, int, int, int, hipStream_t);
-extern "C" int mms_pack_conv3_table(const void*, int, hipStream_t);
+extern "C" int mms_pack_conv3_table_group(const void* const*, int, int, hipStream_t);
 extern "C" int mms_unpack_conv3_grads(const void*, int, hipStream_t);
-extern "C" int mms_bn_running_update(const void*, int, float, hipStream_t);
-extern "C" int mms_conv0_fwd(const Conv0FwdP*, hipStream_t);
-extern "C" int mms_pool_fwd(const PoolFwdP*, hipStream_t);
-extern "C" int mms_conv1_fwd(const Conv1FwdP*, hipStream_t);
-extern "C" int mms_conv3_fwd(const Conv3FwdP*, hipStream_t);
-extern "C" int mms_head_fwd(const HeadFwdP*, hipStream_t);
-extern "C" int mms_conv3_bwd_data(const Conv3BwdDataP*, hipStream_t);
-extern "C" int mms_conv3_bwd_weight(const Conv3BwdWP*, hipStream_t);
-extern "C" int mms_conv1_bwd_data(const Conv1BwdP*, hipStream_t);
-extern "C" int mms_conv1_bwd_weight(const Conv1BwdP*, hipStream_t);
-extern "C" int mms_bn_bwd_apply(const BnBwdApplyP*, hipStream_t);
-extern "C" int mms_head_bwd(const HeadBwdP*, hipStream_t);
-extern "C" int mms_pool_bwd(const PoolBwdP*, hipStream_t);
-extern "C" int mms_conv0_bwd_weight(const Conv0BwdWP*, hipStream_t);
+extern "C" int mms_bn_running_update_group(const void* const*, int, int, float, hipStream_t);
+extern "C" int mms_zero_regions_group(void* const*, int, size_t, hipStream_t);
+extern "C" int mms_conv0_fwd_group(const Conv0FwdP*, int, hipStream_t);
+extern "C" int mms_pool_fwd_group(const PoolFwdP*, int, hipStream_t);
+extern "C" int mms_conv1_fwd_group(const Conv1FwdP*, int, hipStream_t);
+extern "C" int mms_conv3_fwd_group(const Conv3FwdP*, int, hipStream_t);
+extern "C" int mms_head_fwd_group(const HeadFwdP*, int, hipStream_t);
+extern "C" int mms_conv3_bwd_data_group(const Conv3BwdDataP*, int, hipStream_t);
+extern "C" int mms_conv3_bwd_weight_group(const Conv3BwdWP*, int, hipStream_t);
+extern "C" int mms_conv1_bwd_data_group(const Conv1BwdP*, int, hipStream_t);
+extern "C" int mms_conv1_bwd_weight_group(const Conv1BwdP*, int, hipStream_t);
+extern "C" int mms_bn_bwd_apply_group(const BnBwdApplyP*, int, hipStream_t);
+extern "C" int mms_head_bwd_group(const HeadBwdP*, int, hipStream_t);
+extern "C" int mms_pool_bwd_group(const PoolBwdP*, int, hipStream_t);
+extern "C" int mms_conv0_bwd_weight_group(const Conv0BwdWP*, int, hipStream_t);
 
 #define TRY(x) do { int rc_ = (x); if (rc_ != MMS_OK) { fprintf(stderr, "mmsurv: %s -> %d (dn_net.hip:%d)\n", #x, rc_, __LINE__); return rc_; } } while (0)
 
@@ -213,132 +214,176 @@ extern "C" int mms_dn121_init(void* ws, int B, int D, int H, int W, const void* 
     return MMS_OK;
 }
 
-extern "C" int mms_dn121_forward(void* ws, int B, int D, int H, int W, const float* x, const void* const* params_,
-                                 const void* const* buffers, float* out, int ldo, int train, hipStream_t s) {
+// One model of a fold group as the drivers see it.
+struct Ctx {
+    void* ws; const float* x; const float* const* prm; const void* const* buf; float* out;      // forward
+    const float* dout; float* const* grd;                                                        // backward
+};
+#define FOR_G for (int g = 0; g < ng; ++g)
+
+// Forward of ng models of identical shape in lock-step: every launch below carries all ng parameter blocks.
+static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W, int ldo, int train, hipStream_t s) {
     Plan P;
-    if (!make_plan(P, B, D, H, W) || !ws || !x || !params_ || !out) return MMS_ERR_ARG;
-    const float* const* prm = (const float* const*)params_;
+    if (!make_plan(P, B, D, H, W) || ng < 1 || ng > MMS_MAX_GROUP) return MMS_ERR_ARG;
+    FOR_G if (!cx[g].ws || !cx[g].x || !cx[g].prm || !cx[g].out) return MMS_ERR_ARG;
+    const void* tabs[MMS_MAX_GROUP];
     if (train) {
-        if (hipMemsetAsync(at<void>(ws, P.stats_begin), 0, P.stats_end - P.stats_begin, s) != hipSuccess) return MMS_ERR_LAUNCH;
+        void* regs[MMS_MAX_GROUP];
+        FOR_G regs[g] = at<void>(cx[g].ws, P.stats_begin);
+        TRY(mms_zero_regions_group(regs, ng, P.stats_end - P.stats_begin, s));
     }
-    TRY(mms_pack_conv3_table(at<void>(ws, P.tab_pack), NLAYER, s));
-    auto st = [&](size_t off, int Ctot_, int coff, bool sq) -> double* {
+    FOR_G tabs[g] = at<void>(cx[g].ws, P.tab_pack);
+    TRY(mms_pack_conv3_table_group(tabs, ng, NLAYER, s));
+    auto st = [&](void* ws, size_t off, int Ctot_, int coff, bool sq) -> double* {
         return train ? at<double>(ws, off) + (sq ? Ctot_ : 0) + coff : nullptr;
     };
     {   // stem
-        Conv0FwdP c0{x, P.in, P.g0, at<int>(ws, P.coords0), P.M0, prm[IDX.conv0], at<float>(ws, P.y0),
-                     st(P.st_y0, 64, 0, false), st(P.st_y0, 64, 0, true)};
-        c0.srep = P.R0; c0.sstride = 2 * 64;
-        TRY(mms_conv0_fwd(&c0, s));
-        PoolFwdP pf{at<float>(ws, P.y0), P.g0, P.g[0], B, at<float>(ws, P.slab[0]), CTOT[0], at<uint8_t>(ws, P.argmax),
-                    mk_bn(ws, P.st_y0, 64, prm, IDX.n0w, buffers, IDX.bn0, P.M0, train, P.R0),
-                    st(P.st_slab[0], CTOT[0], 0, false), st(P.st_slab[0], CTOT[0], 0, true)};
-        pf.srep = P.R[0]; pf.sstride = 2 * CTOT[0];
-        TRY(mms_pool_fwd(&pf, s));
+        Conv0FwdP c0[MMS_MAX_GROUP];
+        PoolFwdP pf[MMS_MAX_GROUP];
+        FOR_G {
+            const Ctx& c = cx[g];
+            c0[g] = Conv0FwdP{c.x, P.in, P.g0, at<int>(c.ws, P.coords0), P.M0, c.prm[IDX.conv0], at<float>(c.ws, P.y0),
+                              st(c.ws, P.st_y0, 64, 0, false), st(c.ws, P.st_y0, 64, 0, true)};
+            c0[g].srep = P.R0; c0[g].sstride = 2 * 64;
+            pf[g] = PoolFwdP{at<float>(c.ws, P.y0), P.g0, P.g[0], B, at<float>(c.ws, P.slab[0]), CTOT[0], at<uint8_t>(c.ws, P.argmax),
+                             mk_bn(c.ws, P.st_y0, 64, c.prm, IDX.n0w, c.buf, IDX.bn0, P.M0, train, P.R0),
+                             st(c.ws, P.st_slab[0], CTOT[0], 0, false), st(c.ws, P.st_slab[0], CTOT[0], 0, true)};
+            pf[g].srep = P.R[0]; pf[g].sstride = 2 * CTOT[0];
+        }
+        TRY(mms_conv0_fwd_group(c0, ng, s));
+        TRY(mms_pool_fwd_group(pf, ng, s));
     }
     int l = 0;
     for (int b = 0; b < NB; ++b) {
         int C = C0[b];
-        float* slab = at<float>(ws, P.slab[b]);
         for (int i = 0; i < LAYERS[b]; ++i, ++l, C += 32) {
             const int ip = IDX.layer[l];
-            Conv1FwdP c1{slab, CTOT[b], P.M[b], C, prm[ip + 2], 128, at<float>(ws, P.y1[l]), 128,
-                         mk_bn(ws, P.st_slab[b], CTOT[b], prm, ip, buffers, IDX.bn_layer1[l], P.M[b], train, P.R[b]),
-                         st(P.st_y1[l], 128, 0, false), st(P.st_y1[l], 128, 0, true), 0, Dims3{0, 0, 0}};
-            c1.srep = P.R[b]; c1.sstride = 2 * 128;
-            TRY(mms_conv1_fwd(&c1, s));
-            Conv3FwdP c3{at<float>(ws, P.y1[l]), at<int>(ws, P.coords[b]), P.g[b], P.M[b], at<float>(ws, P.wpf[l]),
-                         slab + C, CTOT[b], mk_bn(ws, P.st_y1[l], 128, prm, ip + 3, buffers, IDX.bn_layer2[l], P.M[b], train, P.R[b]),
-                         st(P.st_slab[b], CTOT[b], C, false), st(P.st_slab[b], CTOT[b], C, true),
-                         P.M[b] <= 1024 ? at<float>(ws, P.partial) : nullptr, 27};   // (3-way split at M = 8192 measured slower)
-            c3.srep = P.R[b]; c3.sstride = 2 * CTOT[b];
-            TRY(mms_conv3_fwd(&c3, s));
+            Conv1FwdP c1[MMS_MAX_GROUP];
+            Conv3FwdP c3[MMS_MAX_GROUP];
+            FOR_G {
+                const Ctx& c = cx[g];
+                float* slab = at<float>(c.ws, P.slab[b]);
+                c1[g] = Conv1FwdP{slab, CTOT[b], P.M[b], C, c.prm[ip + 2], 128, at<float>(c.ws, P.y1[l]), 128,
+                                  mk_bn(c.ws, P.st_slab[b], CTOT[b], c.prm, ip, c.buf, IDX.bn_layer1[l], P.M[b], train, P.R[b]),
+                                  st(c.ws, P.st_y1[l], 128, 0, false), st(c.ws, P.st_y1[l], 128, 0, true), 0, Dims3{0, 0, 0}};
+                c1[g].srep = P.R[b]; c1[g].sstride = 2 * 128;
+                c3[g] = Conv3FwdP{at<float>(c.ws, P.y1[l]), at<int>(c.ws, P.coords[b]), P.g[b], P.M[b], at<float>(c.ws, P.wpf[l]),
+                                  slab + C, CTOT[b], mk_bn(c.ws, P.st_y1[l], 128, c.prm, ip + 3, c.buf, IDX.bn_layer2[l], P.M[b], train, P.R[b]),
+                                  st(c.ws, P.st_slab[b], CTOT[b], C, false), st(c.ws, P.st_slab[b], CTOT[b], C, true),
+                                  P.M[b] <= 1024 ? at<float>(c.ws, P.partial) : nullptr, 27};   // (3-way split at M = 8192 measured slower)
+                c3[g].srep = P.R[b]; c3[g].sstride = 2 * CTOT[b];
+            }
+            TRY(mms_conv1_fwd_group(c1, ng, s));
+            TRY(mms_conv3_fwd_group(c3, ng, s));
         }
         if (b < 3) {
             const int ip = IDX.trans[b];
-            Conv1FwdP t{slab, CTOT[b], P.M[b + 1], CTOT[b], prm[ip + 2], CTOT[b] / 2, at<float>(ws, P.slab[b + 1]), CTOT[b + 1],
-                        mk_bn(ws, P.st_slab[b], CTOT[b], prm, ip, buffers, IDX.bn_trans[b], P.M[b], train, P.R[b]),
-                        st(P.st_slab[b + 1], CTOT[b + 1], 0, false), st(P.st_slab[b + 1], CTOT[b + 1], 0, true), 1, P.g[b]};
-            t.srep = P.R[b + 1]; t.sstride = 2 * CTOT[b + 1];
-            TRY(mms_conv1_fwd(&t, s));
+            Conv1FwdP t[MMS_MAX_GROUP];
+            FOR_G {
+                const Ctx& c = cx[g];
+                t[g] = Conv1FwdP{at<float>(c.ws, P.slab[b]), CTOT[b], P.M[b + 1], CTOT[b], c.prm[ip + 2], CTOT[b] / 2,
+                                 at<float>(c.ws, P.slab[b + 1]), CTOT[b + 1],
+                                 mk_bn(c.ws, P.st_slab[b], CTOT[b], c.prm, ip, c.buf, IDX.bn_trans[b], P.M[b], train, P.R[b]),
+                                 st(c.ws, P.st_slab[b + 1], CTOT[b + 1], 0, false), st(c.ws, P.st_slab[b + 1], CTOT[b + 1], 0, true), 1, P.g[b]};
+                t[g].srep = P.R[b + 1]; t[g].sstride = 2 * CTOT[b + 1];
+            }
+            TRY(mms_conv1_fwd_group(t, ng, s));
         }
     }
-    HeadFwdP hd{at<float>(ws, P.slab[3]), CTOT[3], 1024, B, P.M[3] / B,
-                mk_bn(ws, P.st_slab[3], CTOT[3], prm, IDX.n5w, buffers, IDX.bn5, P.M[3], train, P.R[3]),
-                prm[IDX.outw], prm[IDX.outb], 128, at<float>(ws, P.pooled), out, ldo};
-    TRY(mms_head_fwd(&hd, s));
-    if (train && buffers) TRY(mms_bn_running_update(at<void>(ws, P.tab_bn), NBN, 0.1f, s));
+    HeadFwdP hd[MMS_MAX_GROUP];
+    FOR_G {
+        const Ctx& c = cx[g];
+        hd[g] = HeadFwdP{at<float>(c.ws, P.slab[3]), CTOT[3], 1024, B, P.M[3] / B,
+                         mk_bn(c.ws, P.st_slab[3], CTOT[3], c.prm, IDX.n5w, c.buf, IDX.bn5, P.M[3], train, P.R[3]),
+                         c.prm[IDX.outw], c.prm[IDX.outb], 128, at<float>(c.ws, P.pooled), c.out, ldo};
+    }
+    TRY(mms_head_fwd_group(hd, ng, s));
+    if (train) {
+        bool all = true;
+        FOR_G { all = all && cx[g].buf; tabs[g] = at<void>(cx[g].ws, P.tab_bn); }
+        if (all) TRY(mms_bn_running_update_group(tabs, ng, NBN, 0.1f, s));
+    }
     return MMS_OK;
 }
 
-// Backward of the training-mode forward that last ran on this workspace.  grads are ACCUMULATED into
-// (caller zeroes them, e.g. one hipMemsetAsync over a flat gradient buffer).  dout: [B][128].
-static int dn121_backward_impl(void* ws, int B, int D, int H, int W, const float* x, const void* const* params_,
-                               const float* dout, int lddout, void* const* grads_, hipStream_t s, hipStream_t side,
+// Backward of the training-mode forward that last ran on these workspaces.  grads are ACCUMULATED into
+// (caller zeroes them, e.g. one hipMemsetAsync over a flat gradient buffer).  dout: [B][128] per model.
+static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W, int lddout, hipStream_t s, hipStream_t side,
                                hipEvent_t ev_fork, hipEvent_t ev_join) {
     hipStream_t sw = side ? side : s;       // stream of the weight-gradient kernels
     bool side_pending = false;
     Plan P;
-    if (!make_plan(P, B, D, H, W) || !ws || !x || !params_ || !dout || !grads_) return MMS_ERR_ARG;
-    const float* const* prm = (const float* const*)params_;
-    float* const* grd = (float* const*)grads_;
-    auto bbsrc = [&](size_t off, int stride, int nrep) { return BnBwd{at<double>(ws, off), at<double>(ws, off) + stride, nrep, 2 * stride}; };
+    if (!make_plan(P, B, D, H, W) || ng < 1 || ng > MMS_MAX_GROUP) return MMS_ERR_ARG;
+    FOR_G if (!cx[g].ws || !cx[g].x || !cx[g].prm || !cx[g].dout || !cx[g].grd) return MMS_ERR_ARG;
+    auto bbsrc = [&](void* ws, size_t off, int stride, int nrep) { return BnBwd{at<double>(ws, off), at<double>(ws, off) + stride, nrep, 2 * stride}; };
     {
-        HeadBwdP hb{dout, lddout, at<float>(ws, P.pooled), at<float>(ws, P.slab[3]), CTOT[3], 1024, B, P.M[3] / B,
-                    mk_bn(ws, P.st_slab[3], CTOT[3], prm, IDX.n5w, nullptr, 0, P.M[3], 1, P.R[3]), prm[IDX.outw], 128,
-                    grd[IDX.outw], grd[IDX.outb], grd[IDX.n5w], grd[IDX.n5b], at<float>(ws, P.dslab[3]), CTOT[3]};
-        TRY(mms_head_bwd(&hb, s));
+        HeadBwdP hb[MMS_MAX_GROUP];
+        FOR_G {
+            const Ctx& c = cx[g];
+            hb[g] = HeadBwdP{c.dout, lddout, at<float>(c.ws, P.pooled), at<float>(c.ws, P.slab[3]), CTOT[3], 1024, B, P.M[3] / B,
+                             mk_bn(c.ws, P.st_slab[3], CTOT[3], c.prm, IDX.n5w, nullptr, 0, P.M[3], 1, P.R[3]), c.prm[IDX.outw], 128,
+                             c.grd[IDX.outw], c.grd[IDX.outb], c.grd[IDX.n5w], c.grd[IDX.n5b], at<float>(c.ws, P.dslab[3]), CTOT[3]};
+        }
+        TRY(mms_head_bwd_group(hb, ng, s));
     }
     int l = NLAYER;
     for (int b = NB - 1; b >= 0; --b) {
         int C = CTOT[b];
-        float* slab = at<float>(ws, P.slab[b]);
-        float* dslab = at<float>(ws, P.dslab[b]);
         const int M = P.M[b];
         for (int i = LAYERS[b] - 1; i >= 0; --i) {
             --l; C -= 32;
             const int ip = IDX.layer[l];
-            const BnSrc bn1 = mk_bn(ws, P.st_slab[b], CTOT[b], prm, ip, nullptr, 0, M, 1, P.R[b]);
-            const BnSrc bn2 = mk_bn(ws, P.st_y1[l], 128, prm, ip + 3, nullptr, 0, M, 1, P.R[b]);
-            Conv3BwdDataP bd{dslab + C, CTOT[b], at<int>(ws, P.coords[b]), P.g[b], M, at<float>(ws, P.wpb[l]),
-                             at<float>(ws, P.y1[l]), bn2, at<float>(ws, P.dbn_mid),
-                             at<double>(ws, P.bb_y1[l]), at<double>(ws, P.bb_y1[l]) + 128,
-                             M <= 1024 ? at<float>(ws, P.partial) : nullptr, 27};
-            bd.srep = P.R[b]; bd.sstride = 2 * 128;
+            Conv3BwdDataP bd[MMS_MAX_GROUP];
+            Conv3BwdWP bw[MMS_MAX_GROUP];
+            Conv1BwdP c1[MMS_MAX_GROUP];
+            BnBwdApplyP ap[MMS_MAX_GROUP];
+            int ms3 = M > 1024 ? (M + 511) / 512 : (M + 127) / 128; if (ms3 < 1) ms3 = 1;
+            int ms1 = M > 1024 ? M / 256 : M / 128; if (ms1 < 1) ms1 = 1; if (ms1 > 32) ms1 = 32;
+            FOR_G {
+                const Ctx& c = cx[g];
+                float* slab = at<float>(c.ws, P.slab[b]);
+                float* dslab = at<float>(c.ws, P.dslab[b]);
+                const BnSrc bn1 = mk_bn(c.ws, P.st_slab[b], CTOT[b], c.prm, ip, nullptr, 0, M, 1, P.R[b]);
+                const BnSrc bn2 = mk_bn(c.ws, P.st_y1[l], 128, c.prm, ip + 3, nullptr, 0, M, 1, P.R[b]);
+                bd[g] = Conv3BwdDataP{dslab + C, CTOT[b], at<int>(c.ws, P.coords[b]), P.g[b], M, at<float>(c.ws, P.wpb[l]),
+                                      at<float>(c.ws, P.y1[l]), bn2, at<float>(c.ws, P.dbn_mid),
+                                      at<double>(c.ws, P.bb_y1[l]), at<double>(c.ws, P.bb_y1[l]) + 128,
+                                      M <= 1024 ? at<float>(c.ws, P.partial) : nullptr, 27};
+                bd[g].srep = P.R[b]; bd[g].sstride = 2 * 128;
+                bw[g] = Conv3BwdWP{at<float>(c.ws, P.y1[l]), at<int>(c.ws, P.coords[b]), P.g[b], M, bn2, dslab + C, CTOT[b],
+                                   at<float>(c.ws, P.dwp[l]), ms3, 1};
+                Conv1BwdP& q = c1[g];
+                q = Conv1BwdP{};
+                q.dyraw = at<float>(c.ws, P.dbn_mid); q.lddy = 128;
+                q.y = at<float>(c.ws, P.y1[l]); q.ldy = 128;
+                q.bn_out = bn2; q.bb_out = bbsrc(c.ws, P.bb_y1[l], 128, P.R[b]); q.has_bn_out = 1;
+                q.M = M; q.N = 128;
+                q.x = slab; q.ldx = CTOT[b]; q.K = C; q.bn_in = bn1;
+                q.w = c.prm[ip + 2]; q.pool = 0; q.in = Dims3{0, 0, 0};
+                q.dw = c.grd[ip + 2];
+                q.dbn = at<float>(c.ws, P.dbn_in); q.lddbn = CTOT[b];
+                q.s1 = at<double>(c.ws, P.bb_in[l]); q.s2 = at<double>(c.ws, P.bb_in[l]) + 1024;
+                q.srep = P.R[b]; q.sstride = 2 * 1024;
+                q.msplit = ms1; q.dgamma_out = c.grd[ip + 3]; q.dbeta_out = c.grd[ip + 4];
+                ap[g] = BnBwdApplyP{at<float>(c.ws, P.dbn_in), CTOT[b], slab, CTOT[b], dslab, CTOT[b], M, C, bn1,
+                                    bbsrc(c.ws, P.bb_in[l], 1024, P.R[b]), 1, c.grd[ip], c.grd[ip + 1]};
+            }
             if (side && side_pending) {       // the previous layer's weight kernels read dbn_mid: join before overwriting it
                 if (hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) return MMS_ERR_LAUNCH;
                 side_pending = false;
             }
-            TRY(mms_conv3_bwd_data(&bd, s));
+            TRY(mms_conv3_bwd_data_group(bd, ng, s));
             if (side) {
                 if (hipEventRecord(ev_fork, s) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess) return MMS_ERR_LAUNCH;
             }
-            int ms3 = M > 1024 ? (M + 511) / 512 : (M + 127) / 128; if (ms3 < 1) ms3 = 1;
-            Conv3BwdWP bw{at<float>(ws, P.y1[l]), at<int>(ws, P.coords[b]), P.g[b], M, bn2, dslab + C, CTOT[b],
-                          at<float>(ws, P.dwp[l]), ms3, 1};
-            TRY(mms_conv3_bwd_weight(&bw, sw));
-            int ms1 = M > 1024 ? M / 256 : M / 128; if (ms1 < 1) ms1 = 1; if (ms1 > 32) ms1 = 32;
-            Conv1BwdP c1{};
-            c1.dyraw = at<float>(ws, P.dbn_mid); c1.lddy = 128;
-            c1.y = at<float>(ws, P.y1[l]); c1.ldy = 128;
-            c1.bn_out = bn2; c1.bb_out = bbsrc(P.bb_y1[l], 128, P.R[b]); c1.has_bn_out = 1;
-            c1.M = M; c1.N = 128;
-            c1.x = slab; c1.ldx = CTOT[b]; c1.K = C; c1.bn_in = bn1;
-            c1.w = prm[ip + 2]; c1.pool = 0; c1.in = Dims3{0, 0, 0};
-            c1.dw = grd[ip + 2];
-            c1.dbn = at<float>(ws, P.dbn_in); c1.lddbn = CTOT[b];
-            c1.s1 = at<double>(ws, P.bb_in[l]); c1.s2 = at<double>(ws, P.bb_in[l]) + 1024;
-            c1.srep = P.R[b]; c1.sstride = 2 * 1024;
-            c1.msplit = ms1; c1.dgamma_out = grd[ip + 3]; c1.dbeta_out = grd[ip + 4];
-            TRY(mms_conv1_bwd_weight(&c1, sw));
+            TRY(mms_conv3_bwd_weight_group(bw, ng, sw));
+            TRY(mms_conv1_bwd_weight_group(c1, ng, sw));
             if (side) {
                 if (hipEventRecord(ev_join, side) != hipSuccess) return MMS_ERR_LAUNCH;
                 side_pending = true;
             }
-            TRY(mms_conv1_bwd_data(&c1, s));
-            BnBwdApplyP ap{at<float>(ws, P.dbn_in), CTOT[b], slab, CTOT[b], dslab, CTOT[b], M, C, bn1,
-                           bbsrc(P.bb_in[l], 1024, P.R[b]), 1, grd[ip], grd[ip + 1]};
-            TRY(mms_bn_bwd_apply(&ap, s));
+            TRY(mms_conv1_bwd_data_group(c1, ng, s));
+            TRY(mms_bn_bwd_apply_group(ap, ng, s));
         }
         if (side && side_pending) {
             if (hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) return MMS_ERR_LAUNCH;
@@ -346,52 +391,90 @@ static int dn121_backward_impl(void* ws, int B, int D, int H, int W, const float
         }
         if (b > 0) {   // transition b-1 -> b
             const int t = b - 1, ip = IDX.trans[t], Kp = CTOT[t], Mp = P.M[t];
-            const BnSrc bnt = mk_bn(ws, P.st_slab[t], CTOT[t], prm, ip, nullptr, 0, Mp, 1, P.R[t]);
             int ms1 = M / 256; if (ms1 < 1) ms1 = 1; if (ms1 > 32) ms1 = 32;
-            Conv1BwdP c1{};
-            c1.dyraw = dslab; c1.lddy = CTOT[b]; c1.y = nullptr; c1.ldy = 0; c1.has_bn_out = 0;
-            c1.bn_out = bnt; c1.bb_out = BnBwd{nullptr, nullptr, 0, 0};
-            c1.M = M; c1.N = Kp / 2;
-            c1.x = at<float>(ws, P.slab[t]); c1.ldx = CTOT[t]; c1.K = Kp; c1.bn_in = bnt;
-            c1.w = prm[ip + 2]; c1.pool = 1; c1.in = P.g[t];
-            c1.dw = grd[ip + 2];
-            c1.dbn = at<float>(ws, P.dbn_in); c1.lddbn = CTOT[t];
-            c1.s1 = at<double>(ws, P.bb_tr[t]); c1.s2 = at<double>(ws, P.bb_tr[t]) + 1024;
-            c1.srep = P.R[t]; c1.sstride = 2 * 1024;
-            c1.msplit = ms1; c1.dgamma_out = nullptr; c1.dbeta_out = nullptr;
-            TRY(mms_conv1_bwd_weight(&c1, s));
-            TRY(mms_conv1_bwd_data(&c1, s));
-            BnBwdApplyP ap{at<float>(ws, P.dbn_in), CTOT[t], at<float>(ws, P.slab[t]), CTOT[t], at<float>(ws, P.dslab[t]), CTOT[t],
-                           Mp, Kp, bnt, bbsrc(P.bb_tr[t], 1024, P.R[t]), 0, grd[ip], grd[ip + 1]};
-            TRY(mms_bn_bwd_apply(&ap, s));
+            Conv1BwdP c1[MMS_MAX_GROUP];
+            BnBwdApplyP ap[MMS_MAX_GROUP];
+            FOR_G {
+                const Ctx& c = cx[g];
+                const BnSrc bnt = mk_bn(c.ws, P.st_slab[t], CTOT[t], c.prm, ip, nullptr, 0, Mp, 1, P.R[t]);
+                Conv1BwdP& q = c1[g];
+                q = Conv1BwdP{};
+                q.dyraw = at<float>(c.ws, P.dslab[b]); q.lddy = CTOT[b]; q.y = nullptr; q.ldy = 0; q.has_bn_out = 0;
+                q.bn_out = bnt; q.bb_out = BnBwd{nullptr, nullptr, 0, 0};
+                q.M = M; q.N = Kp / 2;
+                q.x = at<float>(c.ws, P.slab[t]); q.ldx = CTOT[t]; q.K = Kp; q.bn_in = bnt;
+                q.w = c.prm[ip + 2]; q.pool = 1; q.in = P.g[t];
+                q.dw = c.grd[ip + 2];
+                q.dbn = at<float>(c.ws, P.dbn_in); q.lddbn = CTOT[t];
+                q.s1 = at<double>(c.ws, P.bb_tr[t]); q.s2 = at<double>(c.ws, P.bb_tr[t]) + 1024;
+                q.srep = P.R[t]; q.sstride = 2 * 1024;
+                q.msplit = ms1; q.dgamma_out = nullptr; q.dbeta_out = nullptr;
+                ap[g] = BnBwdApplyP{at<float>(c.ws, P.dbn_in), CTOT[t], at<float>(c.ws, P.slab[t]), CTOT[t], at<float>(c.ws, P.dslab[t]), CTOT[t],
+                                    Mp, Kp, bnt, bbsrc(c.ws, P.bb_tr[t], 1024, P.R[t]), 0, c.grd[ip], c.grd[ip + 1]};
+            }
+            TRY(mms_conv1_bwd_weight_group(c1, ng, s));
+            TRY(mms_conv1_bwd_data_group(c1, ng, s));
+            TRY(mms_bn_bwd_apply_group(ap, ng, s));
         } else {       // stem
-            const BnSrc bn0 = mk_bn(ws, P.st_y0, 64, prm, IDX.n0w, nullptr, 0, P.M0, 1, P.R0);
-            PoolBwdP pb{dslab, CTOT[0], at<uint8_t>(ws, P.argmax), P.g[0], P.g0, B, at<float>(ws, P.y0), bn0,
-                        at<float>(ws, P.dbn0), at<double>(ws, P.bb_y0), at<double>(ws, P.bb_y0) + 64, at<int>(ws, P.coords0)};
-            pb.srep = P.R0; pb.sstride = 2 * 64;
-            TRY(mms_pool_bwd(&pb, s));
             int ms0 = P.M0 / 1024; if (ms0 < 1) ms0 = 1; if (ms0 > 64) ms0 = 64;
-            Conv0BwdWP cw{at<float>(ws, P.dbn0), at<float>(ws, P.y0), bn0, bbsrc(P.bb_y0, 64, P.R0), x, P.in, P.g0,
-                          at<int>(ws, P.coords0), P.M0, grd[IDX.conv0], ms0, grd[IDX.n0w], grd[IDX.n0b]};
-            TRY(mms_conv0_bwd_weight(&cw, s));
+            PoolBwdP pb[MMS_MAX_GROUP];
+            Conv0BwdWP cw[MMS_MAX_GROUP];
+            FOR_G {
+                const Ctx& c = cx[g];
+                const BnSrc bn0 = mk_bn(c.ws, P.st_y0, 64, c.prm, IDX.n0w, nullptr, 0, P.M0, 1, P.R0);
+                pb[g] = PoolBwdP{at<float>(c.ws, P.dslab[0]), CTOT[0], at<uint8_t>(c.ws, P.argmax), P.g[0], P.g0, B, at<float>(c.ws, P.y0), bn0,
+                                 at<float>(c.ws, P.dbn0), at<double>(c.ws, P.bb_y0), at<double>(c.ws, P.bb_y0) + 64, at<int>(c.ws, P.coords0)};
+                pb[g].srep = P.R0; pb[g].sstride = 2 * 64;
+                cw[g] = Conv0BwdWP{at<float>(c.ws, P.dbn0), at<float>(c.ws, P.y0), bn0, bbsrc(c.ws, P.bb_y0, 64, P.R0), c.x, P.in, P.g0,
+                                   at<int>(c.ws, P.coords0), P.M0, c.grd[IDX.conv0], ms0, c.grd[IDX.n0w], c.grd[IDX.n0b]};
+            }
+            TRY(mms_pool_bwd_group(pb, ng, s));
+            TRY(mms_conv0_bwd_weight_group(cw, ng, s));
         }
     }
     if (side && side_pending) {
         if (hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) return MMS_ERR_LAUNCH;
     }
-    UnpackEntry up[NLAYER];
-    for (int i = 0; i < NLAYER; ++i) { up[i].scratch = at<float>(ws, P.dwp[i]); up[i].dw = grd[IDX.layer[i] + 5]; }
-    TRY(mms_unpack_conv3_grads(up, NLAYER, s));
+    FOR_G {
+        UnpackEntry up[NLAYER];
+        for (int i = 0; i < NLAYER; ++i) { up[i].scratch = at<float>(cx[g].ws, P.dwp[i]); up[i].dw = cx[g].grd[IDX.layer[i] + 5]; }
+        TRY(mms_unpack_conv3_grads(up, NLAYER, s));
+    }
     return MMS_OK;
 }
 
+extern "C" int mms_dn121_forward(void* ws, int B, int D, int H, int W, const float* x, const void* const* params_,
+                                 const void* const* buffers, float* out, int ldo, int train, hipStream_t s) {
+    Ctx c{ws, x, (const float* const*)params_, buffers, out, nullptr, nullptr};
+    return dn121_forward_impl(&c, 1, B, D, H, W, ldo, train, s);
+}
 extern "C" int mms_dn121_backward(void* ws, int B, int D, int H, int W, const float* x, const void* const* params,
                                   const float* dout, int lddout, void* const* grads, hipStream_t s) {
-    return dn121_backward_impl(ws, B, D, H, W, x, params, dout, lddout, grads, s, nullptr, nullptr, nullptr);
+    Ctx c{ws, x, (const float* const*)params, nullptr, nullptr, dout, (float* const*)grads};
+    return dn121_backward_impl(&c, 1, B, D, H, W, lddout, s, nullptr, nullptr, nullptr);
 }
 extern "C" int mms_dn121_backward_mt(void* ws, int B, int D, int H, int W, const float* x, const void* const* params,
                                      const float* dout, int lddout, void* const* grads, hipStream_t s, hipStream_t side,
                                      hipEvent_t ev_fork, hipEvent_t ev_join) {
     if (!side || !ev_fork || !ev_join) return MMS_ERR_ARG;
-    return dn121_backward_impl(ws, B, D, H, W, x, params, dout, lddout, grads, s, side, ev_fork, ev_join);
+    Ctx c{ws, x, (const float* const*)params, nullptr, nullptr, dout, (float* const*)grads};
+    return dn121_backward_impl(&c, 1, B, D, H, W, lddout, s, side, ev_fork, ev_join);
+}
+
+// Fold-group drivers: model g of the group is described by the g-th entry of each array (all models share B, D, H, W).
+extern "C" int mms_dn121_forward_group(int ng, void* const* ws, int B, int D, int H, int W, const float* const* x,
+                                       const void* const* const* params, const void* const* const* buffers, float* const* out,
+                                       int ldo, int train, hipStream_t s) {
+    if (ng < 1 || ng > MMS_MAX_GROUP || !ws || !x || !params || !out) return MMS_ERR_ARG;
+    Ctx c[MMS_MAX_GROUP];
+    FOR_G c[g] = Ctx{ws[g], x[g], (const float* const*)params[g], buffers ? buffers[g] : nullptr, out[g], nullptr, nullptr};
+    return dn121_forward_impl(c, ng, B, D, H, W, ldo, train, s);
+}
+extern "C" int mms_dn121_backward_group(int ng, void* const* ws, int B, int D, int H, int W, const float* const* x,
+                                        const void* const* const* params, const float* const* dout, int lddout,
+                                        void* const* const* grads, hipStream_t s) {
+    if (ng < 1 || ng > MMS_MAX_GROUP || !ws || !x || !params || !dout || !grads) return MMS_ERR_ARG;
+    Ctx c[MMS_MAX_GROUP];
+    FOR_G c[g] = Ctx{ws[g], x[g], (const float* const*)params[g], nullptr, nullptr, dout[g], (float* const*)grads[g]};
+    return dn121_backward_impl(c, ng, B, D, H, W, lddout, s, nullptr, nullptr, nullptr);
 }

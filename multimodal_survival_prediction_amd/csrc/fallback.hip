@@ -215,6 +215,7 @@ inline BnSrc fb_bn(void* ws, const FbPlan& P, int l, const float* const* prm, co
 }  // namespace
 
 extern "C" int mms_bn_running_update(const void*, int, float, hipStream_t);
+extern "C" int mms_zero_regions_group(void* const*, int, size_t, hipStream_t);
 extern "C" int mms_bn_bwd_apply(const BnBwdApplyP*, hipStream_t);
 #define TRY(x) do { int rc_ = (x); if (rc_ != MMS_OK) return rc_; } while (0)
 
@@ -244,7 +245,10 @@ extern "C" int mms_fb_forward(void* ws, int B, int D, int H, int W, const float*
     FbPlan P;
     if (!fb_plan(P, B, D, H, W) || !ws || !x || !params_ || !out) return MMS_ERR_ARG;
     const float* const* prm = (const float* const*)params_;
-    if (train && hipMemsetAsync(at<void>(ws, P.stats_begin), 0, P.stats_end - P.stats_begin, s) != hipSuccess) return MMS_ERR_LAUNCH;
+    if (train) {    // (a zero-fill kernel, not hipMemsetAsync: consecutive memset nodes of a captured graph were observed to misorder)
+        void* reg = at<void>(ws, P.stats_begin);
+        TRY(mms_zero_regions_group(&reg, 1, P.stats_end - P.stats_begin, s));
+    }
     for (int l = 1; l < 4; ++l) {
         FbConvP c{};
         c.x = l == 1 ? x : at<float>(ws, P.y[l - 1]); c.Cin = FC[l - 1]; c.in = P.g[l - 1]; c.out = P.g[l]; c.B = B;

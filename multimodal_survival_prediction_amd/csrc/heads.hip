@@ -61,7 +61,8 @@ struct ColProlog {
 };
 
 template <int MM>
-__global__ __launch_bounds__(256) void linear_fwd_kernel(const LinearFwdP p) {
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const Grp<LinearFwdP> grp) {
+    const LinearFwdP& p = grp.p[blockIdx.z];
     const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= p.N) return;
     const bool upd = (n == 0) && p.pro.bn && p.pro.train;
@@ -109,23 +110,31 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const LinearFwdP p) {
 }
 
 template <int MM>
-static int launch_linear_fwd(const LinearFwdP& p, hipStream_t s) {
-    MMS_LAUNCH(linear_fwd_kernel<MM>, dim3((p.N + 3) / 4), dim3(256), 0, s, p);
+static int launch_linear_fwd(const Grp<LinearFwdP>& a, int ng, hipStream_t s) {
+    MMS_LAUNCH(linear_fwd_kernel<MM>, dim3((a.p[0].N + 3) / 4, 1, ng), dim3(256), 0, s, a);
     return mms_check_launch();
 }
-extern "C" int mms_linear_fwd(const LinearFwdP* pp, hipStream_t s) {
+extern "C" int mms_linear_fwd_group(const LinearFwdP* pp, int ng, hipStream_t s) {
+    Grp<LinearFwdP> a;
+    if (!grp_fill(a, pp, ng, 1)) return MMS_ERR_ARG;
     const LinearFwdP& p = *pp;
     if (p.M <= 0 || p.M > 32 || p.N <= 0 || p.K <= 0) return MMS_ERR_ARG;
     if (p.pro.bn && p.pro.train && p.M < 2) return MMS_ERR_ARG;   // torch: "Expected more than 1 value per channel"
-    if (p.M <= 4) return launch_linear_fwd<4>(p, s);
-    if (p.M <= 8) return launch_linear_fwd<8>(p, s);
-    if (p.M <= 16) return launch_linear_fwd<16>(p, s);
-    return launch_linear_fwd<32>(p, s);
+    for (int g = 1; g < ng; ++g) {
+        const LinearFwdP& q = pp[g];
+        if (q.M != p.M || q.N != p.N || q.K != p.K || q.pro.bn != p.pro.bn || q.pro.train != p.pro.train) return MMS_ERR_ARG;
+    }
+    if (p.M <= 4) return launch_linear_fwd<4>(a, ng, s);
+    if (p.M <= 8) return launch_linear_fwd<8>(a, ng, s);
+    if (p.M <= 16) return launch_linear_fwd<16>(a, ng, s);
+    return launch_linear_fwd<32>(a, ng, s);
 }
+MMS_SINGLE(mms_linear_fwd, LinearFwdP)
 
 // ---- backward: weight/bias (one wave per output feature n) ---------------------------------------------------
 template <int MM>
-__global__ __launch_bounds__(256) void linear_bwd_w_kernel(const LinearBwdP p) {
+__global__ __launch_bounds__(256) void linear_bwd_w_kernel(const Grp<LinearBwdP> grp) {
+    const LinearBwdP& p = grp.p[blockIdx.z];
     const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= p.N) return;
     float dz[MM], db = 0.f;
@@ -154,7 +163,8 @@ __global__ __launch_bounds__(256) void linear_bwd_w_kernel(const LinearBwdP p) {
 
 // ---- backward: input (one thread per input column k), prologue backward lane-local --------------------------
 template <int MM>
-__global__ __launch_bounds__(256) void linear_bwd_x_kernel(const LinearBwdP p) {
+__global__ __launch_bounds__(256) void linear_bwd_x_kernel(const Grp<LinearBwdP> grp) {
+    const LinearBwdP& p = grp.p[blockIdx.z];
     __shared__ float dzs[MM][128];
     const int k = blockIdx.x * 256 + threadIdx.x;
     float acc[MM];
@@ -209,19 +219,27 @@ __global__ __launch_bounds__(256) void linear_bwd_x_kernel(const LinearBwdP p) {
 }
 
 template <int MM>
-static int launch_linear_bwd(const LinearBwdP& p, hipStream_t s) {
-    if (p.dw) MMS_LAUNCH(linear_bwd_w_kernel<MM>, dim3((p.N + 3) / 4), dim3(256), 0, s, p);
-    if (p.dx) MMS_LAUNCH(linear_bwd_x_kernel<MM>, dim3((p.K + 255) / 256), dim3(256), 0, s, p);
+static int launch_linear_bwd(const Grp<LinearBwdP>& a, int ng, hipStream_t s) {
+    const LinearBwdP& p = a.p[0];
+    if (p.dw) MMS_LAUNCH(linear_bwd_w_kernel<MM>, dim3((p.N + 3) / 4, 1, ng), dim3(256), 0, s, a);
+    if (p.dx) MMS_LAUNCH(linear_bwd_x_kernel<MM>, dim3((p.K + 255) / 256, 1, ng), dim3(256), 0, s, a);
     return mms_check_launch();
 }
-extern "C" int mms_linear_bwd(const LinearBwdP* pp, hipStream_t s) {
+extern "C" int mms_linear_bwd_group(const LinearBwdP* pp, int ng, hipStream_t s) {
+    Grp<LinearBwdP> a;
+    if (!grp_fill(a, pp, ng, 1)) return MMS_ERR_ARG;
     const LinearBwdP& p = *pp;
     if (p.M <= 0 || p.M > 32 || p.N <= 0 || p.K <= 0) return MMS_ERR_ARG;
-    if (p.M <= 4) return launch_linear_bwd<4>(p, s);
-    if (p.M <= 8) return launch_linear_bwd<8>(p, s);
-    if (p.M <= 16) return launch_linear_bwd<16>(p, s);
-    return launch_linear_bwd<32>(p, s);
+    for (int g = 1; g < ng; ++g) {
+        const LinearBwdP& q = pp[g];
+        if (q.M != p.M || q.N != p.N || q.K != p.K || (q.dw == nullptr) != (p.dw == nullptr) || (q.dx == nullptr) != (p.dx == nullptr)) return MMS_ERR_ARG;
+    }
+    if (p.M <= 4) return launch_linear_bwd<4>(a, ng, s);
+    if (p.M <= 8) return launch_linear_bwd<8>(a, ng, s);
+    if (p.M <= 16) return launch_linear_bwd<16>(a, ng, s);
+    return launch_linear_bwd<32>(a, ng, s);
 }
+MMS_SINGLE(mms_linear_bwd, LinearBwdP)
 
 // ------------------------------------------------------------------------------------------------------
 // gated fusion: one workgroup per patient row
@@ -230,7 +248,8 @@ extern "C" int mms_linear_bwd(const LinearBwdP* pp, hipStream_t s) {
 #define GATE_IN 291
 __device__ __forceinline__ int gate_seg(int t) { return t < 128 ? 0 : (t < 256 ? 1 : 2); }
 
-__global__ __launch_bounds__(256) void gate_fwd_kernel(const GateP p) {
+__global__ __launch_bounds__(256) void gate_fwd_kernel(const Grp<GateP> grp) {
+    const GateP& p = grp.p[blockIdx.z];
     __shared__ float G[GATE_IN + 1], h[64], g[3];
     const int m = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     for (int i = t; i < GATE_IN; i += 256)
@@ -261,7 +280,8 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(const GateP p) {
     for (int i = t; i < GATE_F; i += 256) p.fused[(size_t)m * GATE_F + i] = G[i] * g[gate_seg(i)];
 }
 
-__global__ __launch_bounds__(256) void gate_bwd_kernel(const GateP p) {
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const Grp<GateP> grp) {
+    const GateP& p = grp.p[blockIdx.z];
     __shared__ float G[GATE_IN + 1], h[64], g[3], dgs[3], dl[3], dhp[64], red[4][3];
     const int m = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     for (int i = t; i < GATE_IN; i += 256)
@@ -328,16 +348,25 @@ extern "C" int mms_gate_entropy(const float* gate, int M, float scale, float* lo
     return mms_check_launch();
 }
 
-extern "C" int mms_gate_fwd(const GateP* pp, hipStream_t s) {
-    if (pp->M <= 0) return MMS_ERR_ARG;
-    MMS_LAUNCH(gate_fwd_kernel, dim3(pp->M), dim3(256), 0, s, *pp);
+static bool gate_group(Grp<GateP>& a, const GateP* pp, int ng) {
+    if (!grp_fill(a, pp, ng, 1) || pp->M <= 0) return false;
+    for (int g = 1; g < ng; ++g) if (pp[g].M != pp->M) return false;
+    return true;
+}
+extern "C" int mms_gate_fwd_group(const GateP* pp, int ng, hipStream_t s) {
+    Grp<GateP> a;
+    if (!gate_group(a, pp, ng)) return MMS_ERR_ARG;
+    MMS_LAUNCH(gate_fwd_kernel, dim3(pp->M, 1, ng), dim3(256), 0, s, a);
     return mms_check_launch();
 }
-extern "C" int mms_gate_bwd(const GateP* pp, hipStream_t s) {
-    if (pp->M <= 0) return MMS_ERR_ARG;
-    MMS_LAUNCH(gate_bwd_kernel, dim3(pp->M), dim3(256), 0, s, *pp);
+extern "C" int mms_gate_bwd_group(const GateP* pp, int ng, hipStream_t s) {
+    Grp<GateP> a;
+    if (!gate_group(a, pp, ng)) return MMS_ERR_ARG;
+    MMS_LAUNCH(gate_bwd_kernel, dim3(pp->M, 1, ng), dim3(256), 0, s, a);
     return mms_check_launch();
 }
+MMS_SINGLE(mms_gate_fwd, GateP)
+MMS_SINGLE(mms_gate_bwd, GateP)
 
 // ------------------------------------------------------------------------------------------------------
 // Cox partial likelihood, O(n^2) risk-set form.  One wave per row i, lanes over j (wavefront-shuffle reductions).
@@ -345,7 +374,8 @@ extern "C" int mms_gate_bwd(const GateP* pp, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool cox_valid(const CoxP& p, int i) { return p.valid == nullptr || p.valid[i] != 0.f; }
 
-__global__ __launch_bounds__(256) void cox_lse_kernel(const CoxP p) {
+__global__ __launch_bounds__(256) void cox_lse_kernel(const Grp<CoxP> grp) {
+    const CoxP& p = grp.p[blockIdx.z];
     const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= p.n) return;
     if (!cox_valid(p, i)) { if (lane == 0) p.lse[i] = 0.f; return; }
@@ -361,7 +391,8 @@ __global__ __launch_bounds__(256) void cox_lse_kernel(const CoxP p) {
     if (lane == 0) p.lse[i] = mx + logf(s);
 }
 
-__global__ __launch_bounds__(256) void cox_grad_kernel(const CoxP p) {
+__global__ __launch_bounds__(256) void cox_grad_kernel(const Grp<CoxP> grp) {
+    const CoxP& p = grp.p[blockIdx.z];
     __shared__ float red[8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k = blockIdx.x * 4 + wave;
     // batch counts (every block recomputes them: n is small)
@@ -396,13 +427,16 @@ __global__ __launch_bounds__(256) void cox_grad_kernel(const CoxP p) {
         p.dh[(size_t)k * p.lddh] = 0.f;
     }
 }
-extern "C" int mms_cox_fwd_bwd(const CoxP* pp, hipStream_t s) {
+extern "C" int mms_cox_fwd_bwd_group(const CoxP* pp, int ng, hipStream_t s) {
+    Grp<CoxP> a;
+    if (!grp_fill(a, pp, ng, 1)) return MMS_ERR_ARG;
     const CoxP& p = *pp;
-    if (p.n <= 0 || !p.lse || !p.out) return MMS_ERR_ARG;
-    MMS_LAUNCH(cox_lse_kernel, dim3((p.n + 3) / 4), dim3(256), 0, s, p);
-    MMS_LAUNCH(cox_grad_kernel, dim3((p.n + 3) / 4), dim3(256), 0, s, p);
+    for (int g = 0; g < ng; ++g) if (pp[g].n != p.n || pp[g].n <= 0 || !pp[g].lse || !pp[g].out) return MMS_ERR_ARG;
+    MMS_LAUNCH(cox_lse_kernel, dim3((p.n + 3) / 4, 1, ng), dim3(256), 0, s, a);
+    MMS_LAUNCH(cox_grad_kernel, dim3((p.n + 3) / 4, 1, ng), dim3(256), 0, s, a);
     return mms_check_launch();
 }
+MMS_SINGLE(mms_cox_fwd_bwd, CoxP)
 
 // ------------------------------------------------------------------------------------------------------
 // Harrell's C pair counts: one wave per event row i
@@ -435,7 +469,8 @@ extern "C" int mms_cindex_counts(const CindexP* pp, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------------
 // clip_grad_norm_ + Adam / AdamW over a flat buffer
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void grad_sumsq_kernel(const AdamP p) {
+__global__ __launch_bounds__(256) void grad_sumsq_kernel(const Grp<AdamP> grp) {
+    const AdamP& p = grp.p[blockIdx.z];
     __shared__ double red[4];
     const long long n4 = p.n >> 2, stride = (long long)gridDim.x * 256;
     float a = 0.f;
@@ -447,10 +482,21 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(const AdamP p) {
     const double t = block_sum_d((double)a, red);
     if (threadIdx.x == 0) {
         atomicAdd(p.sumsq, t);
-        if (blockIdx.x == 0 && (p.skip_flag == nullptr || *p.skip_flag != 0.f)) p.step[0] += 1.f;
+        if (blockIdx.x == 0) {
+            if (p.skip_flag == nullptr || *p.skip_flag != 0.f) p.step[0] += 1.f;
+            // per-step bookkeeping of the training loop (R/final_multimodal.py:262-264: total_loss += loss.item(), n_batches += 1),
+            // kept on the device: [sum loss*usable, n usable, sum gate entropy, n batches]; dropout stream counter
+            if (p.acc) {
+                if (p.cox_out) { p.acc[0] += p.cox_out[0] * p.cox_out[1]; p.acc[1] += p.cox_out[1]; }
+                if (p.entropy) p.acc[2] += p.entropy[0];
+                p.acc[3] += 1.f;
+            }
+            if (p.rng) p.rng[1] += 1;
+        }
     }
 }
-__global__ __launch_bounds__(256) void clip_adam_kernel(const AdamP p) {
+__global__ __launch_bounds__(256) void clip_adam_kernel(const Grp<AdamP> grp) {
+    const AdamP& p = grp.p[blockIdx.z];
     __shared__ float c[6];
     if (p.skip_flag != nullptr && *p.skip_flag == 0.f) return;
     if (threadIdx.x == 0) {
@@ -477,18 +523,27 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const AdamP p) {
         p.p[i] = w - step_size * m / (sqrtf(v) * inv_sqrt_bc2 + eps);
     }
 }
-extern "C" int mms_grad_sumsq(const AdamP* pp, hipStream_t s) {
-    if (pp->n <= 0) return MMS_ERR_ARG;
+static bool adam_group(Grp<AdamP>& a, const AdamP* pp, int ng) {
+    if (!grp_fill(a, pp, ng, 1) || pp->n <= 0) return false;
+    for (int g = 1; g < ng; ++g) if (pp[g].n != pp->n) return false;
+    return true;
+}
+extern "C" int mms_grad_sumsq_group(const AdamP* pp, int ng, hipStream_t s) {
+    Grp<AdamP> a;
+    if (!adam_group(a, pp, ng)) return MMS_ERR_ARG;
     long long blocks = (pp->n / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    MMS_LAUNCH(grad_sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, *pp);
+    MMS_LAUNCH(grad_sumsq_kernel, dim3((unsigned)blocks, 1, ng), dim3(256), 0, s, a);
     return mms_check_launch();
 }
-extern "C" int mms_clip_adam(const AdamP* pp, hipStream_t s) {
-    if (pp->n <= 0) return MMS_ERR_ARG;
+extern "C" int mms_clip_adam_group(const AdamP* pp, int ng, hipStream_t s) {
+    Grp<AdamP> a;
+    if (!adam_group(a, pp, ng)) return MMS_ERR_ARG;
     long long blocks = (pp->n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    MMS_LAUNCH(clip_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, *pp);
+    MMS_LAUNCH(clip_adam_kernel, dim3((unsigned)blocks, 1, ng), dim3(256), 0, s, a);
     return mms_check_launch();
 }
+MMS_SINGLE(mms_grad_sumsq, AdamP)
+MMS_SINGLE(mms_clip_adam, AdamP)

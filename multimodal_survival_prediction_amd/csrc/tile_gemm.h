@@ -58,7 +58,9 @@ struct TileGemmCfg {
 // instead of idling -- measured on the conv3 forward: MFMA-chain stalls, loader issue and memory waits each took
 // about a third of a one-wave-per-SIMD kernel's time, serialised.
 template <class Op>
-__global__ __launch_bounds__(Op::SPEC ? 512 : 256) void tile_gemm_kernel(const typename Op::Params p) {
+__global__ __launch_bounds__(Op::SPEC ? 512 : 256) void tile_gemm_kernel(const Grp<typename Op::Params> grp) {
+    const int gi = blockIdx.z / grp.zdim;                  // model of the fold group
+    const typename Op::Params& p = grp.p[gi];
     constexpr int WM = Op::WM, WN = Op::WN, WK = Op::WK;
     static_assert(WM * WN * WK == 4, "4 waves per workgroup");
     typedef TileGemmCfg<Op> Cfg;
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(Op::SPEC ? 512 : 256) void tile_gemm_kernel(const t
     // Placement only affects speed, never results.
     int bx = blockIdx.x;
     if ((gridDim.x & 7) == 0) bx = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const int m0 = bx * TM, n0 = blockIdx.y * TN, z = blockIdx.z;
+    const int m0 = bx * TM, n0 = blockIdx.y * TN, z = blockIdx.z - gi * grp.zdim;
 
     Op op;
     op.setup(p, m0, n0, z, extra, tid);
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(Op::SPEC ? 512 : 256) void tile_gemm_kernel(const t
 }
 
 template <class Op>
-static inline int launch_tile_gemm(const typename Op::Params& p, dim3 grid, hipStream_t s) {
+static inline int launch_tile_gemm(const typename Op::Params* pp, int ng, dim3 grid, hipStream_t s) {
     constexpr size_t smem = TileGemmCfg<Op>::smem_bytes();
     static bool attr_set = false;
     if (smem > 64 * 1024 && !attr_set) {
@@ -279,6 +281,9 @@ static inline int launch_tile_gemm(const typename Op::Params& p, dim3 grid, hipS
         attr_set = true;
     }
     if (grid.x == 0 || grid.y == 0 || grid.z == 0) return MMS_OK;
-    MMS_LAUNCH(tile_gemm_kernel<Op>, grid, dim3(Op::SPEC ? 512 : 256), smem, s, p);
+    Grp<typename Op::Params> a;
+    if (!grp_fill(a, pp, ng, (int)grid.z)) return MMS_ERR_ARG;
+    grid.z *= ng;
+    MMS_LAUNCH(tile_gemm_kernel<Op>, grid, dim3(Op::SPEC ? 512 : 256), smem, s, a);
     return mms_check_launch();
 }

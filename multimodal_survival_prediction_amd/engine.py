@@ -77,7 +77,9 @@ class _Plan:
 
 class SurvivalEngine:
     def __init__(self, model, adamw=None, lr=1e-4, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0,
-                 gate_entropy_weight=0.01):
+                 gate_entropy_weight=0.01, _slots=None):
+        """_slots (used by FoldGroupEngine): dict(gflat=[n] fp32, sumsq=[1] fp64, entropy=[1] fp32) views of group-wide
+        buffers, so the per-step zeroing of a whole fold group is three memsets."""
         self.lib = _lib.load_library()
         self.model = model
         self.prog = head_program(model)
@@ -86,13 +88,15 @@ class SurvivalEngine:
             raise RuntimeError("SurvivalEngine: move the model to the GPU first (model.to('cuda')); no CPU fallback")
         self.device = p0.device
         self.params = list(model.parameters())
+        self._slots = _slots or {}
         self._flatten()
         n = self.flat.numel()
         self.m = torch.zeros(n, device=self.device)
         self.v = torch.zeros(n, device=self.device)
         self.adamw = bool(adamw) if adamw is not None else self.prog["kind"] == "SimpleFusionModel"
         self.hyper = torch.tensor([lr, betas[0], betas[1], eps, weight_decay, max_norm], device=self.device)
-        self.sumsq = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self.sumsq = self._slots["sumsq"] if "sumsq" in self._slots else torch.zeros(1, dtype=torch.float64, device=self.device)
+        self.entropy = self._slots["entropy"] if "entropy" in self._slots else torch.zeros(1, device=self.device)
         self.step_count = torch.zeros(1, device=self.device)
         self.rng = torch.tensor([0x5EED, 0], dtype=torch.int32, device=self.device)
         self.ent_weight = gate_entropy_weight
@@ -110,7 +114,8 @@ class SurvivalEngine:
         n = sum(p.numel() for p in self.params)
         pad = (-n) % 4
         self.flat = torch.zeros(n + pad, device=self.device)
-        self.gflat = torch.zeros(n + pad, device=self.device)
+        self.gflat = self._slots["gflat"] if "gflat" in self._slots else torch.zeros(n + pad, device=self.device)
+        assert self.gflat.numel() == n + pad and self.gflat.is_contiguous()
         o = 0
         self.gviews = []
         with torch.no_grad():
@@ -159,7 +164,6 @@ class SurvivalEngine:
         P.valid = torch.ones(B, device=dev)
         P.cox_out = torch.zeros(2, device=dev)
         P.lse = torch.zeros(B, device=dev)
-        P.entropy = torch.zeros(1, device=dev)
         # encoder: DenseNet121-3D (MONAI topology) or the reference's 3-conv fallback
         enc = prog["encoder"]
         P.fallback = isinstance(enc, nn.Sequential)
@@ -211,14 +215,15 @@ class SurvivalEngine:
             P.gate = ops.gate_params(P.buf["feats"], P.mask, g1.weight, g1.bias, g2.weight, g2.bias, P.hidden, P.gatew,
                                      P.buf["fused"], P.dbuf["fused"], self.ent_weight, P.dbuf["feats"],
                                      gmap[id(g1.weight)], gmap[id(g1.bias)], gmap[id(g2.weight)], gmap[id(g2.bias)],
-                                     P.entropy)
+                                     self.entropy)
         hz = P.buf["hz"]
         P.cox = _S()["CoxP"](hz.data_ptr(), 1, P.time.data_ptr(), P.event.data_ptr(), P.valid.data_ptr(), B, 1.0,
                              P.lse.data_ptr(), P.dbuf["hz"].data_ptr(), 1, P.cox_out.data_ptr())
+        book = dict(acc=self.acc, cox_out=P.cox_out, entropy=self.entropy, rng=self.rng)   # per-step bookkeeping, in-kernel
         P.adam = ops.adam_params(self.flat, self.gflat, self.m, self.v, self.hyper, self.sumsq, self.step_count,
-                                 None, self.adamw)
+                                 None, self.adamw, **book)
         P.adam_skip = ops.adam_params(self.flat, self.gflat, self.m, self.v, self.hyper, self.sumsq, self.step_count,
-                                      P.cox_out[1:], self.adamw)
+                                      P.cox_out[1:], self.adamw, **book)
         P.graphs = {}
         self.plans[key] = P
         return P
@@ -243,7 +248,7 @@ class SurvivalEngine:
         for i in range(n_pre):
             _lib.check(lib.mms_linear_fwd(ctypes.byref(lf[i]), st), "mms_linear_fwd")
         if P.gate is not None:
-            P.entropy.zero_()
+            self.entropy.zero_()
             _lib.check(lib.mms_gate_fwd(ctypes.byref(P.gate), st), "mms_gate_fwd")
         for i in range(n_pre, len(lf)):
             _lib.check(lib.mms_linear_fwd(ctypes.byref(lf[i]), st), "mms_linear_fwd")
@@ -293,11 +298,7 @@ class SurvivalEngine:
         ad = P.adam_skip if skip_if_unusable else P.adam
         _lib.check(lib.mms_grad_sumsq(ctypes.byref(ad), st), "mms_grad_sumsq")
         _lib.check(lib.mms_clip_adam(ctypes.byref(ad), st), "mms_clip_adam")
-        self.rng[1] += 1
-        self.acc[0] += P.cox_out[0] * P.cox_out[1]
-        self.acc[1] += P.cox_out[1]
-        self.acc[2] += P.entropy[0]
-        self.acc[3] += 1.0
+        # (dropout counter and the epoch accumulators self.acc are advanced inside mms_grad_sumsq: AdamP.acc / .rng)
 
     # ---- public: fused training step ------------------------------------------------------------------
     def load_batch(self, P, ct, rna, clinical=None, mask=None, time=None, event=None, valid=None):

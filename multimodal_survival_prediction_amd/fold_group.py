@@ -1,0 +1,221 @@
+"""Fold groups: the K fold models of the reference's cross-validation loop advanced in lock-step on one GPU.
+
+The reference trains fold after fold (final_multimodal.py:316-402, partial_modality_training.py:482-560,
+simple_fusion.py:318-436).  The folds are independent models of identical architecture, and one batch-4 step of one
+of them is far too small for 256 CUs (most of its 570 kernels are launch/latency bound).  A `FoldGroupEngine` owns G
+`SurvivalEngine`s and issues every launch of the training step ONCE for the whole group through the `*_group` entry
+points of include/mmsurv.h: same kernels, same per-model arithmetic, G times the workgroups per launch.
+
+Per-model state stays per model (parameters, Adam moments, BatchNorm buffers, learning rate, dropout counters,
+epoch accumulators): a fold trained in a group follows exactly the trajectory it follows alone.
+"""
+import ctypes
+
+import torch
+
+from . import _lib, ops
+from .engine import SurvivalEngine
+
+_S = _lib.structs
+
+
+def _arr(blocks):
+    T = type(blocks[0])
+    return (T * len(blocks))(*blocks)
+
+
+def _ptrs(vals):
+    return (ctypes.c_void_p * len(vals))(*vals)
+
+
+class _GroupPlan:
+    pass
+
+
+class FoldGroupEngine:
+    MAX = 8      # MMS_MAX_GROUP
+
+    def __init__(self, models, **engine_kw):
+        """models: 2..8 modules of the same class/shape, already on the GPU and not yet bound to an engine."""
+        if not 1 <= len(models) <= self.MAX:
+            raise ValueError("a fold group holds 1..%d models" % self.MAX)
+        self.lib = _lib.load_library()
+        dev = next(models[0].parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("FoldGroupEngine: models must be on the GPU (no CPU fallback)")
+        n = sum(p.numel() for p in models[0].parameters())
+        n += (-n) % 4
+        G = len(models)
+        self.device = dev
+        # group-wide buffers so that zeroing the step's accumulators is three memsets for the whole group
+        self.gflat_all = torch.zeros(G, n, device=dev)
+        self.sumsq_all = torch.zeros(G, dtype=torch.float64, device=dev)
+        self.entropy_all = torch.zeros(G, device=dev)
+        self.engines = []
+        for g, m in enumerate(models):
+            if getattr(m, "_mms_engine", None) is not None:
+                raise RuntimeError("model %d already has an engine; build the group from fresh models" % g)
+            if sum(p.numel() for p in m.parameters()) + (-sum(p.numel() for p in m.parameters())) % 4 != n:
+                raise ValueError("fold-group models must have identical shapes")
+            slots = dict(gflat=self.gflat_all[g], sumsq=self.sumsq_all[g:g + 1], entropy=self.entropy_all[g:g + 1])
+            self.engines.append(SurvivalEngine(m, _slots=slots, **engine_kw))
+        kinds = {e.prog["kind"] for e in self.engines}
+        if len(kinds) != 1:
+            raise ValueError("fold-group models must be of one class, got %s" % sorted(kinds))
+        self.plans = {}
+
+    def __len__(self):
+        return len(self.engines)
+
+    # ---- plans -----------------------------------------------------------------------------------
+    def plan(self, B, dims, members=None):
+        members = tuple(range(len(self.engines))) if members is None else tuple(members)
+        key = (B,) + tuple(dims) + (members,)
+        if key in self.plans:
+            return self.plans[key]
+        eng = [self.engines[i] for i in members]
+        Ps = [e.plan(B, dims) for e in eng]
+        if any(P.fallback for P in Ps):
+            raise NotImplementedError("fold groups drive the DenseNet121-3D encoder; the 3-conv fallback encoder has no "
+                                      "group entry points (train those folds one at a time)")
+        GP = _GroupPlan()
+        GP.members, GP.eng, GP.Ps, GP.B, GP.dims = members, eng, Ps, B, tuple(dims)
+        prog = eng[0].prog
+        GP.ng = len(eng)
+        GP.ws = _ptrs([P.ws.data_ptr() for P in Ps])
+        GP.x = _ptrs([P.ct.data_ptr() for P in Ps])
+        GP.params = _ptrs([ctypes.addressof(P.ptab) for P in Ps])
+        GP.buffers = _ptrs([ctypes.addressof(P.btab) for P in Ps])
+        GP.grads = _ptrs([ctypes.addressof(P.gtab) for P in Ps])
+        cc = prog["ct_cols"]
+        GP.out = _ptrs([P.buf["feats"][:, cc:].data_ptr() for P in Ps])
+        GP.dout = _ptrs([P.dbuf["feats"][:, cc:].data_ptr() for P in Ps])
+        GP.ld = Ps[0].buf["feats"].stride(0)
+        nl = len(prog["lins"])
+        GP.lin_fwd = {t: [_arr([P.lin_fwd[t][i] for P in Ps]) for i in range(nl)] for t in (True, False)}
+        GP.lin_bwd = [_arr([P.lin_bwd[i] for P in Ps]) for i in range(nl)]
+        GP.gate = _arr([P.gate for P in Ps]) if Ps[0].gate is not None else None
+        GP.cox = _arr([P.cox for P in Ps])
+        GP.adam = {True: _arr([P.adam_skip for P in Ps]), False: _arr([P.adam for P in Ps])}
+        GP.graphs = {}
+        # zeroing: the whole group's buffers when the group is complete and contiguous, else per member
+        GP.full = members == tuple(range(len(self.engines)))
+        self.plans[key] = GP
+        return GP
+
+    # ---- launches ----------------------------------------------------------------------------------
+    def _forward(self, GP, train):
+        st = ops.stream()
+        lib, ng = self.lib, GP.ng
+        prog = GP.eng[0].prog
+        B, (D, H, W) = GP.B, GP.dims
+        _lib.check(lib.mms_dn121_forward_group(ng, GP.ws, B, D, H, W, GP.x, GP.params, GP.buffers, GP.out, GP.ld,
+                                               1 if train else 0, st), "mms_dn121_forward_group")
+        lf = GP.lin_fwd[train]
+        n_pre = prog["n_pre"]
+        for i in range(n_pre):
+            _lib.check(lib.mms_linear_fwd_group(lf[i], ng, st), "mms_linear_fwd_group")
+        if GP.gate is not None:
+            _lib.check(lib.mms_gate_fwd_group(GP.gate, ng, st), "mms_gate_fwd_group")
+        for i in range(n_pre, len(lf)):
+            _lib.check(lib.mms_linear_fwd_group(lf[i], ng, st), "mms_linear_fwd_group")
+
+    def _zero(self, GP):
+        if GP.full:
+            self.gflat_all.zero_(); self.sumsq_all.zero_(); self.entropy_all.zero_()
+        else:
+            for e in GP.eng:
+                e.gflat.zero_(); e.sumsq.zero_(); e.entropy.zero_()
+
+    def _train_body(self, GP, skip_if_unusable):
+        """zero-grad -> forward -> Cox -> backward -> clip -> Adam for every member, one launch sequence."""
+        st = ops.stream()
+        lib, ng = self.lib, GP.ng
+        prog = GP.eng[0].prog
+        B, (D, H, W) = GP.B, GP.dims
+        self._zero(GP)
+        self._forward(GP, True)
+        _lib.check(lib.mms_cox_fwd_bwd_group(GP.cox, ng, st), "mms_cox_fwd_bwd_group")
+        n_pre = prog["n_pre"]
+        for i in range(len(GP.lin_bwd) - 1, n_pre - 1, -1):
+            _lib.check(lib.mms_linear_bwd_group(GP.lin_bwd[i], ng, st), "mms_linear_bwd_group")
+        if GP.gate is not None:
+            _lib.check(lib.mms_gate_bwd_group(GP.gate, ng, st), "mms_gate_bwd_group")
+        for i in range(n_pre - 1, -1, -1):
+            _lib.check(lib.mms_linear_bwd_group(GP.lin_bwd[i], ng, st), "mms_linear_bwd_group")
+        _lib.check(lib.mms_dn121_backward_group(ng, GP.ws, B, D, H, W, GP.x, GP.params, GP.dout, GP.ld, GP.grads, st),
+                   "mms_dn121_backward_group")
+        ad = GP.adam[bool(skip_if_unusable)]
+        _lib.check(lib.mms_grad_sumsq_group(ad, ng, st), "mms_grad_sumsq_group")
+        _lib.check(lib.mms_clip_adam_group(ad, ng, st), "mms_clip_adam_group")
+
+    # ---- state snapshot around graph warm-up ---------------------------------------------------------
+    def _snapshot(self, eng):
+        return [[e.flat.clone(), e.m.clone(), e.v.clone(), e.step_count.clone(), e.rng.clone(), e.acc.clone(),
+                 [b.clone() for b in e.model.buffers()]] for e in eng]
+
+    def _restore(self, eng, snap):
+        with torch.no_grad():
+            for e, s in zip(eng, snap):
+                e.flat.copy_(s[0]); e.m.copy_(s[1]); e.v.copy_(s[2]); e.step_count.copy_(s[3]); e.rng.copy_(s[4])
+                e.acc.copy_(s[5])
+                for b, b0 in zip(e.model.buffers(), s[6]):
+                    b.copy_(b0)
+
+    def _graph(self, GP, key, body):
+        if key not in GP.graphs:
+            snap = self._snapshot(GP.eng)
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                body()
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            self._restore(GP.eng, snap)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                body()
+            GP.graphs[key] = g
+            self._restore(GP.eng, snap)
+        return GP.graphs[key]
+
+    # ---- public ------------------------------------------------------------------------------------------
+    def train_step(self, batches, members=None, skip_if_unusable=True, use_graph=True):
+        """One optimisation step of every member on its own batch.  batches: one dict per member with the keyword
+        arguments of SurvivalEngine.load_batch (ct, rna, clinical, mask, time, event, valid); all of one batch size."""
+        members = tuple(range(len(self.engines))) if members is None else tuple(members)
+        if len(batches) != len(members):
+            raise ValueError("one batch per member")
+        ct0 = batches[0]["ct"]
+        B, dims = ct0.shape[0], tuple(ct0.shape[-3:])
+        for b in batches:
+            if b["ct"].shape[0] != B or tuple(b["ct"].shape[-3:]) != dims:
+                raise ValueError("fold-group batches must share one shape; split ragged tails into their own step")
+        GP = self.plan(B, dims, members)
+        for e, P, b in zip(GP.eng, GP.Ps, batches):
+            e.load_batch(P, **b)
+        if not use_graph:
+            self._train_body(GP, skip_if_unusable)
+            return
+        self._graph(GP, ("train", bool(skip_if_unusable)), lambda: self._train_body(GP, skip_if_unusable)).replay()
+
+    def forward_eval(self, batches, members=None, use_graph=True):
+        """Eval-mode forward of every member -> list of (hazard [B] view, gate [B,3] or None) per member."""
+        members = tuple(range(len(self.engines))) if members is None else tuple(members)
+        ct0 = batches[0]["ct"]
+        B, dims = ct0.shape[0], tuple(ct0.shape[-3:])
+        GP = self.plan(B, dims, members)
+        for e, P, b in zip(GP.eng, GP.Ps, batches):
+            e.load_batch(P, **b)
+        if use_graph:
+            self._graph(GP, "eval", lambda: self._forward(GP, False)).replay()
+        else:
+            self._forward(GP, False)
+        return [(P.buf["hz"][:, 0], (P.gatew if P.gate is not None else None)) for P in GP.Ps]
+
+    def reset_epoch_stats(self):
+        for e in self.engines:
+            e.reset_epoch_stats()
+
+    def epoch_stats(self):
+        return [e.epoch_stats() for e in self.engines]

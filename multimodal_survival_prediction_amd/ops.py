@@ -189,6 +189,7 @@ def cindex_counts(h, time, event):
     return counts
 
 
-def adam_params(p_, g, m, v, hyper, sumsq, step, skip_flag=None, adamw=False):
+def adam_params(p_, g, m, v, hyper, sumsq, step, skip_flag=None, adamw=False, acc=None, cox_out=None, entropy=None,
+                rng=None):
     return _S()["AdamP"](ptr(p_), ptr(g), ptr(m), ptr(v), p_.numel(), ptr(hyper), ptr(sumsq), ptr(step), ptr(skip_flag),
-                         1 if adamw else 0)
+                         1 if adamw else 0, ptr(acc), ptr(cox_out), ptr(entropy), ptr(rng))

@@ -1,0 +1,129 @@
+"""Fold groups (G models advanced by ONE launch sequence) must follow the trajectories of the same models trained
+one at a time: same kernels, same per-model arithmetic -- only fp32/fp64 atomic ordering may differ."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import DEV, rel_err
+from test_gpu_models import _batch
+
+
+def _models(cls, G, rna_dim, p_drop=0.0):
+    from multimodal_survival_prediction_amd import models as HM
+    out = []
+    for g in range(G):
+        torch.manual_seed(100 + g)
+        m = getattr(HM, cls)(rna_dim=rna_dim)
+        with torch.no_grad():
+            for mod in m.modules():
+                if isinstance(mod, (torch.nn.BatchNorm3d, torch.nn.BatchNorm1d)):
+                    mod.weight.uniform_(0.5, 1.5); mod.bias.normal_(0, 0.1)
+                if isinstance(mod, torch.nn.Dropout):
+                    mod.p = p_drop
+        out.append(m)
+    return out
+
+
+def _kw(cls, ct, rna, clin, t, e, mask, valid):
+    if cls == "MultiModalSurvivalNet":
+        return dict(ct=ct, rna=rna, clinical=clin, time=t, event=e)
+    if cls == "PartialModalityNet":
+        return dict(ct=ct, rna=rna, clinical=clin, mask=mask, time=t, event=e, valid=valid)
+    return dict(ct=ct, rna=rna, time=t, event=e, valid=valid)
+
+
+@pytest.mark.parametrize("cls,G", [("MultiModalSurvivalNet", 3), ("PartialModalityNet", 2), ("SimpleFusionModel", 5)])
+def test_group_step_equals_single_steps(cls, G):
+    from multimodal_survival_prediction_amd.engine import SurvivalEngine
+    from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
+    B, dims, rna_dim = 4, (64, 64, 32), 1024
+    # dropout stays ON (p = 0.3 everywhere): the hash-RNG streams are per model and must advance identically
+    base = _models(cls, G, rna_dim, p_drop=0.3)
+    solo = [copy.deepcopy(m).to(DEV).train() for m in base]
+    grp = [copy.deepcopy(m).to(DEV).train() for m in base]
+    skip = cls != "PartialModalityNet"
+    kw = dict(lr=1e-4, weight_decay=1e-3 if cls == "SimpleFusionModel" else 1e-4)
+    se = [SurvivalEngine(m, **kw) for m in solo]
+    ge = FoldGroupEngine(grp, **kw)
+    valid = torch.tensor([1, 1, 0, 1], dtype=torch.float32)
+    for it in range(3):
+        batches = []
+        for g in range(G):
+            ct, rna, clin, t, e, mask = _batch(B, dims, rna_dim, 50 + 10 * it + g)
+            if it == 1 and g == 1:
+                e = torch.zeros_like(e)       # a batch without events: unusable -> skipped (or entropy-only) step for that member
+            batches.append(_kw(cls, ct, rna, clin, t, e, mask, valid))
+        for g in range(G):
+            se[g].train_step(skip_if_unusable=skip, use_graph=it > 0, **batches[g])
+        ge.train_step(batches, skip_if_unusable=skip, use_graph=it > 0)
+        torch.cuda.synchronize()
+        if it == 0:     # gradients of the very first step: identical inputs and weights on both sides
+            for g in range(G):
+                a, b = se[g].gflat, ge.engines[g].gflat
+                assert rel_err(b, a) <= 2e-5, (g, rel_err(b, a))
+    stats_s = [e.epoch_stats() for e in se]
+    stats_g = ge.epoch_stats()
+    for g in range(G):
+        assert stats_g[g]["n_batches"] == 3 and stats_g[g]["n_usable"] == stats_s[g]["n_usable"]
+        assert abs(stats_g[g]["sum_loss"] - stats_s[g]["sum_loss"]) <= 1e-2 * max(1.0, abs(stats_s[g]["sum_loss"])), (g, stats_g[g], stats_s[g])
+        assert abs(stats_g[g]["sum_entropy"] - stats_s[g]["sum_entropy"]) <= 1e-3 * max(1.0, abs(stats_s[g]["sum_entropy"]))
+        assert int(ge.engines[g].rng[1]) == int(se[g].rng[1]) == 3
+        assert float(ge.engines[g].step_count) == float(se[g].step_count)
+        # Adam turns rounding-noise gradients (exact-zero-gradient parameters) into +-lr moves, so compare in bulk
+        tot = close = 0
+        worst = 0.0
+        for p, q in zip(solo[g].parameters(), grp[g].parameters()):
+            d = (p.detach() - q.detach()).abs()
+            tot += d.numel(); close += int((d <= 2e-5).sum()); worst = max(worst, float(d.max()))
+        assert worst <= 6.5e-4, worst
+        assert close / tot >= 0.9, close / tot
+        for (k, b), (_, c) in zip(solo[g].named_buffers(), grp[g].named_buffers()):
+            if "num_batches" in k:
+                assert int(b) == int(c)
+            else:
+                assert rel_err(c, b) <= 2e-3, k
+    print(f"{cls} x{G}: group == single steps")
+
+
+def test_group_subset_and_eval():
+    """A sub-group (ragged tail: only some folds still have a batch) and the grouped eval forward."""
+    from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
+    cls, G, B, dims, rna_dim = "MultiModalSurvivalNet", 3, 3, (32, 32, 32), 256
+    base = _models(cls, G, rna_dim)
+    grp = [copy.deepcopy(m).to(DEV).train() for m in base]
+    ge = FoldGroupEngine(grp)
+    batches = []
+    for g in range(G):
+        ct, rna, clin, t, e, mask = _batch(B, dims, rna_dim, 7 + g)
+        batches.append(dict(ct=ct, rna=rna, clinical=clin, time=t, event=e))
+    ge.train_step([batches[0], batches[2]], members=(0, 2))
+    torch.cuda.synchronize()
+    st = ge.epoch_stats()
+    assert [s["n_batches"] for s in st] == [1, 0, 1]
+    for m in grp:
+        m.eval()
+    ev = [dict(ct=b["ct"], rna=b["rna"], clinical=b["clinical"]) for b in batches]
+    outs = ge.forward_eval(ev)
+    torch.cuda.synchronize()
+    for g in range(G):
+        hz_single = grp[g](ev[g]["ct"].to(DEV), ev[g]["rna"].to(DEV), ev[g]["clinical"].to(DEV))
+        assert rel_err(outs[g][0], hz_single.reshape(-1)) <= 1e-5
+
+
+def test_group_rejects_mismatched_shapes():
+    from multimodal_survival_prediction_amd import _lib, ops
+    lib = _lib.load_library()
+    S = _lib.structs()
+    x = torch.zeros(64, 64, device=DEV)
+    a = ops.adam_params(x.view(-1), x.view(-1), x.view(-1), x.view(-1), torch.zeros(6, device=DEV),
+                        torch.zeros(1, dtype=torch.float64, device=DEV), torch.zeros(1, device=DEV))
+    y = torch.zeros(32, device=DEV)
+    b = ops.adam_params(y, y, y, y, torch.zeros(6, device=DEV), torch.zeros(1, dtype=torch.float64, device=DEV),
+                        torch.zeros(1, device=DEV))
+    arr = (S["AdamP"] * 2)(a, b)
+    assert lib.mms_grad_sumsq_group(arr, 2, ops.stream()) == -1       # MMS_ERR_ARG: sizes differ
+    assert lib.mms_grad_sumsq_group(arr, 9, ops.stream()) == -1       # > MMS_MAX_GROUP
