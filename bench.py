@@ -35,12 +35,15 @@ PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 BLOCKS = ((6, 64), (12, 128), (24, 256), (16, 512))     # (layers, first-layer input channels) of DenseNet121
 
 
-def measure_dominant_kernel(B, dims, device, reps=20):
+def measure_dominant_kernel(B, dims, device, G=1, reps=20):
     """Average launch duration of the dominant kernel -- tile_gemm_kernel<Conv3BwdWOp>, the weight gradient of the
-    dense-layer 3x3x3 conv (58 launches per step, the largest share of GPU time in profiles/r01_*) -- timed live with
-    HIP events on the launch stream (torch's current stream), shape by shape with the driver's own split factors,
-    weighted by the launch counts.  Algorithmic FLOPs per launch = 2 * M * 27 * 128 * 32."""
-    from multimodal_survival_prediction_amd import ops
+    dense-layer 3x3x3 conv (58 launches per group step, the largest share of GPU time in profiles/r01_*) -- timed live
+    with HIP events on the launch stream (torch's current stream), launched exactly as the timed region launches it:
+    one launch carries the G models of a fold group (mms_conv3_bwd_weight_group), shape by shape with the driver's own
+    split factors, weighted by the launch counts.  Algorithmic FLOPs per launch = G * 2 * M * 27 * 128 * 32."""
+    import ctypes
+    from multimodal_survival_prediction_amd import _lib, ops
+    lib, S = _lib.load_library(), _lib.structs()
     tot_t, tot_f, n = 0.0, 0.0, 0
     D, H, W = dims
     g, b = torch.ones(128, device=device), torch.zeros(128, device=device)
@@ -48,23 +51,33 @@ def measure_dominant_kernel(B, dims, device, reps=20):
         gd = (D // 4 >> i, H // 4 >> i, W // 4 >> i)
         M = B * gd[0] * gd[1] * gd[2]
         ms = (M + 511) // 512 if M > 1024 else max((M + 127) // 128, 1)        # dn_net.hip: ms3
-        y1 = torch.randn(M, 128, device=device)
-        s, q = y1.double().sum(0), (y1.double() ** 2).sum(0)
-        bn = ops.bnsrc(g, b, M, True, s, q)
         coords = ops.init_coords(B, gd, device)
-        dslab = torch.randn(M, 256, device=device)
-        dwp = torch.zeros(27 * 32 * 128, device=device)
+        keep, blocks = [], []
+        for _ in range(G):
+            y1 = torch.randn(M, 128, device=device)
+            s, q = y1.double().sum(0), (y1.double() ** 2).sum(0)
+            bn = ops.bnsrc(g, b, M, True, s, q)
+            dslab = torch.randn(M, 256, device=device)
+            dwp = torch.zeros(27 * 32 * 128, device=device)
+            dz = dslab[:, 64:96]
+            keep.append((y1, s, q, dslab, dwp))
+            blocks.append(S["Conv3BwdWP"](y1.data_ptr(), coords.data_ptr(), ops.dims3(gd), M, bn, dz.data_ptr(), dz.stride(0),
+                                          dwp.data_ptr(), ms, 1))
+        arr = (S["Conv3BwdWP"] * G)(*blocks)
+
+        def launch():
+            _lib.check(lib.mms_conv3_bwd_weight_group(arr, G, ops.stream()), "mms_conv3_bwd_weight_group")
         for _ in range(3):
-            ops.conv3_bwd_weight(y1, coords, gd, bn, dslab[:, 64:96], dwp, ms, tapmajor=True)
+            launch()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            ops.conv3_bwd_weight(y1, coords, gd, bn, dslab[:, 64:96], dwp, ms, tapmajor=True)
+            launch()
         e1.record()
         torch.cuda.synchronize()
         t = e0.elapsed_time(e1) * 1e-3 / reps
         tot_t += t * layers
-        tot_f += 2.0 * M * 27 * 128 * 32 * layers
+        tot_f += G * 2.0 * M * 27 * 128 * 32 * layers
         n += layers
     return tot_t / n, tot_f / n
 
@@ -106,9 +119,9 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--concurrent-folds", type=int, default=4,
-                    help="fold models trained concurrently per GPU, one HIP stream + step graph each (mode fold)")
-    ap.add_argument("--fold-group", type=int, default=1,
+    ap.add_argument("--concurrent-folds", type=int, default=2,
+                    help="fold groups trained concurrently per GPU, one HIP stream + step graph each (mode fold)")
+    ap.add_argument("--fold-group", type=int, default=5,
                     help="fold models advanced in lock-step by ONE launch sequence (FoldGroupEngine, *_group entry points); "
                          "--concurrent-folds then counts concurrent groups")
     ap.add_argument("--mode", choices=["fold", "ddp"], default="fold",
@@ -236,14 +249,14 @@ def main():
                        "concurrent_folds": F, "fold_group": G, "single_chain_patients_per_s": world * B / dt1, "single_chain_ms_per_step": dt1 * 1e3,
                        "hip_graph": not args.no_graph, "mean_train_loss": stats["sum_loss"] / max(stats["n_batches"], 1)},
         }
-        avg_t, avg_f = measure_dominant_kernel(B, dims, dev)
+        avg_t, avg_f = measure_dominant_kernel(B, dims, dev, G)
         traffic = None      # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)
         try:
             with open(os.path.join(ROOT, "profiles", "r01_pmc_conv3bwdw_traffic.json")) as f:
                 traffic = json.load(f)["avg_hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
-        out["roofline"] = {"bound": "mfma", "kernel": "tile_gemm_kernel<Conv3BwdWOp> (weight gradient of the dense-layer 3x3x3 conv, 58 launches/step)",
+        out["roofline"] = {"bound": "mfma", "kernel": f"tile_gemm_kernel<Conv3BwdWOp> (weight gradient of the dense-layer 3x3x3 conv; 58 launches per group step, {G} fold models per launch)",
                            "achieved": avg_f / avg_t / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": avg_f / avg_t / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                            "avg_launch_us": avg_t * 1e6, "avg_flops_per_launch": avg_f}

@@ -473,28 +473,42 @@ extern "C" int mms_pack_conv3(const float* w, float* wpf, float* wpb, hipStream_
     return mms_check_launch();
 }
 
-// batched variant over a device table of layer pointers (one launch per forward)
-// one workgroup per (layer, cout): the 128 x 27 canonical slice goes through LDS so reads and writes are coalesced
+// batched variant over device tables of layer pointers (one launch per forward, all models of the fold group).
+// One workgroup = (model, layer, 32 input channels): the [32 co][32 cin][27] slice is staged in LDS (odd strides: every
+// phase is bank-conflict free) so that the canonical reads (1728-B runs), the backward pack (the slice is one contiguous
+// 110 KB run of wpb) and the forward pack (128-B runs = whole cache lines) are all coalesced.
 struct TabPtrs { const void* t[MMS_MAX_GROUP]; };
+#define PACK_CO_STRIDE 865      // 32 * 27 + 1
 __global__ __launch_bounds__(256) void pack_conv3_table_kernel(const TabPtrs tabs) {
-    __shared__ float t[128 * 28];
+    extern __shared__ float t[];         // [32 co][PACK_CO_STRIDE]: element (co, cin_l, tap) at co * 865 + cin_l * 27 + tap
     const PackEntry e = ((const PackEntry*)tabs.t[blockIdx.z])[blockIdx.y];
-    const int co = blockIdx.x;
-    const float* src = e.w + (size_t)co * 128 * 27;
-    for (int idx = threadIdx.x; idx < 128 * 27; idx += 256) t[(idx / 27) * 28 + idx % 27] = src[idx];
+    const int cin0 = blockIdx.x * 32;
+    for (int idx = threadIdx.x; idx < 32 * 864; idx += 256) {
+        const int co = idx / 864, r = idx - co * 864;
+        t[co * PACK_CO_STRIDE + r] = e.w[((size_t)co * 128 + cin0) * 27 + r];
+    }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < 27 * 128; idx += 256) {
-        const int tap = idx >> 7, cin = idx & 127;
-        const float v = t[cin * 28 + tap];
-        e.wpf[((size_t)co * 27 + tap) * 128 + cin] = v;
-        e.wpb[((size_t)cin * 27 + tap) * 32 + co] = v;       // 4-byte scatter at stride 128 B: 442 KB per layer, L2-absorbed
+    float* wpb = e.wpb + (size_t)cin0 * 27 * 32;
+    for (int idx = threadIdx.x; idx < 32 * 864; idx += 256) {            // wpb[cin][tap][co]
+        const int co = idx & 31, ct = idx >> 5;                           // ct = cin_l * 27 + tap
+        wpb[idx] = t[co * PACK_CO_STRIDE + ct];
+    }
+    for (int idx = threadIdx.x; idx < 32 * 864; idx += 256) {            // wpf[co][tap][cin]
+        const int cl = idx & 31, q = idx >> 5, tap = q % 27, co = q / 27;
+        e.wpf[((size_t)co * 27 + tap) * 128 + cin0 + cl] = t[co * PACK_CO_STRIDE + cl * 27 + tap];
     }
 }
 extern "C" int mms_pack_conv3_table_group(const void* const* tables_dev, int ng, int nlayers, hipStream_t s) {
     if (!tables_dev || ng < 1 || ng > MMS_MAX_GROUP || nlayers <= 0) return MMS_ERR_ARG;
     TabPtrs tp;
     for (int g = 0; g < ng; ++g) tp.t[g] = tables_dev[g];
-    MMS_LAUNCH(pack_conv3_table_kernel, dim3(32, nlayers, ng), dim3(256), 0, s, tp);
+    constexpr int smem = 32 * PACK_CO_STRIDE * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)pack_conv3_table_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_set = true;
+    }
+    MMS_LAUNCH(pack_conv3_table_kernel, dim3(4, nlayers, ng), dim3(256), smem, s, tp);
     return mms_check_launch();
 }
 extern "C" int mms_pack_conv3_table(const void* table_dev, int nlayers, hipStream_t s) {

@@ -12,6 +12,7 @@
 #include "dn_ops.h"
 #include <string.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -27,6 +28,7 @@ constexpr int NPARAM = 364;
 struct Plan {
     int B; Dims3 in, g0, g[NB];
     int M0, M[NB];
+    long partial_rows;  // capacity of the tap-split scratch in [128]-float rows
     int R0, R[NB];     // statistic-accumulator replicas of the stem level / of each block (common.h: stat_rep)
     // byte offsets into the workspace
     size_t coords0, coords[NB], y0, argmax, slab[NB], dslab[NB], y1[NLAYER], wpf[NLAYER], wpb[NLAYER];
@@ -76,6 +78,7 @@ bool make_plan(Plan& P, int B, int D, int H, int W) {
     {   // tap-split scratch: 27 partials for blocks with M <= 1024, NSPLIT_BIG for larger ones
         size_t a = (size_t)27 * (P.M[1] > 1024 ? 1024 : P.M[1]) * 128 * 4, b2 = (size_t)3 * P.M[0] * 128 * 4;
         P.partial = take(a > b2 ? a : b2);
+        P.partial_rows = (long)((a > b2 ? a : b2) / (128 * 4));
     }
     P.tab_pack = take(sizeof(PackEntry) * NLAYER);
     P.tab_bn = take(sizeof(BnRunEntry) * NBN);
@@ -214,6 +217,25 @@ extern "C" int mms_dn121_init(void* ws, int B, int D, int H, int W, const void* 
     return MMS_OK;
 }
 
+// Tap split of the 3x3x3 convolutions (forward and backward-data): a launch should put about `target` workgroups on the
+// 256 CUs.  One model's block with M <= 1024 rows has <= 32 row tiles, so its 27 taps are spread over workgroups and
+// summed by a reduce kernel; a fold group multiplies the tiles by ng and needs less (or no) splitting.
+static int split_target(int ng) {     // measured: 864 for one model (27-way split of a 32-tile block), 256 for fold groups
+    const char* e = getenv("MMS_SPLIT_WGS");      // tuning / test override, read at launch (i.e. graph-capture) time
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : (ng > 1 ? 256 : 864);
+}
+static int conv3_nsplit(int M, int ng, long cap_rows) {
+    const long tiles = (long)((M + 31) / 32) * ng;
+    if (tiles >= 256) return 1;
+    long ns = (split_target(ng) + tiles - 1) / tiles;
+    if (ns > 27) ns = 27;
+    if (ns < 1) ns = 1;
+    int tpw = (int)((27 + ns - 1) / ns);
+    while (tpw < 27 && (long)((27 + tpw - 1) / tpw) * M > cap_rows) ++tpw;   // the partials must fit the scratch
+    return (27 + tpw - 1) / tpw;                                         // every workgroup owns >= 1 tap
+}
+
 // One model of a fold group as the drivers see it.
 struct Ctx {
     void* ws; const float* x; const float* const* prm; const void* const* buf; float* out;      // forward
@@ -260,6 +282,7 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
             const int ip = IDX.layer[l];
             Conv1FwdP c1[MMS_MAX_GROUP];
             Conv3FwdP c3[MMS_MAX_GROUP];
+            const int ns3 = conv3_nsplit(P.M[b], ng, P.partial_rows);
             FOR_G {
                 const Ctx& c = cx[g];
                 float* slab = at<float>(c.ws, P.slab[b]);
@@ -270,7 +293,7 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
                 c3[g] = Conv3FwdP{at<float>(c.ws, P.y1[l]), at<int>(c.ws, P.coords[b]), P.g[b], P.M[b], at<float>(c.ws, P.wpf[l]),
                                   slab + C, CTOT[b], mk_bn(c.ws, P.st_y1[l], 128, c.prm, ip + 3, c.buf, IDX.bn_layer2[l], P.M[b], train, P.R[b]),
                                   st(c.ws, P.st_slab[b], CTOT[b], C, false), st(c.ws, P.st_slab[b], CTOT[b], C, true),
-                                  P.M[b] <= 1024 ? at<float>(c.ws, P.partial) : nullptr, 27};   // (3-way split at M = 8192 measured slower)
+                                  ns3 > 1 ? at<float>(c.ws, P.partial) : nullptr, ns3};
                 c3[g].srep = P.R[b]; c3[g].sstride = 2 * CTOT[b];
             }
             TRY(mms_conv1_fwd_group(c1, ng, s));
@@ -337,6 +360,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
             Conv3BwdWP bw[MMS_MAX_GROUP];
             Conv1BwdP c1[MMS_MAX_GROUP];
             BnBwdApplyP ap[MMS_MAX_GROUP];
+            const int ns3 = conv3_nsplit(M, ng, P.partial_rows);
             int ms3 = M > 1024 ? (M + 511) / 512 : (M + 127) / 128; if (ms3 < 1) ms3 = 1;
             int ms1 = M > 1024 ? M / 256 : M / 128; if (ms1 < 1) ms1 = 1; if (ms1 > 32) ms1 = 32;
             FOR_G {
@@ -348,7 +372,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
                 bd[g] = Conv3BwdDataP{dslab + C, CTOT[b], at<int>(c.ws, P.coords[b]), P.g[b], M, at<float>(c.ws, P.wpb[l]),
                                       at<float>(c.ws, P.y1[l]), bn2, at<float>(c.ws, P.dbn_mid),
                                       at<double>(c.ws, P.bb_y1[l]), at<double>(c.ws, P.bb_y1[l]) + 128,
-                                      M <= 1024 ? at<float>(c.ws, P.partial) : nullptr, 27};
+                                      ns3 > 1 ? at<float>(c.ws, P.partial) : nullptr, ns3};
                 bd[g].srep = P.R[b]; bd[g].sstride = 2 * 128;
                 bw[g] = Conv3BwdWP{at<float>(c.ws, P.y1[l]), at<int>(c.ws, P.coords[b]), P.g[b], M, bn2, dslab + C, CTOT[b],
                                    at<float>(c.ws, P.dwp[l]), ms3, 1};

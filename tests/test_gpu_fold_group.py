@@ -37,7 +37,11 @@ def _kw(cls, ct, rna, clin, t, e, mask, valid):
 
 
 @pytest.mark.parametrize("cls,G", [("MultiModalSurvivalNet", 3), ("PartialModalityNet", 2), ("SimpleFusionModel", 5)])
-def test_group_step_equals_single_steps(cls, G):
+def test_group_step_equals_single_steps(cls, G, monkeypatch):
+    # same tap split (27-way) for the single models and the group: identical per-model arithmetic, so the comparison is
+    # tight; with the default, group-size dependent split the fp32 summation order differs and parity becomes statistical
+    # (ReLU-mask flips, see test_gpu_densenet.py) -- covered by test_group_default_split_statistical below
+    monkeypatch.setenv("MMS_SPLIT_WGS", "1000000")
     from multimodal_survival_prediction_amd.engine import SurvivalEngine
     from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
     B, dims, rna_dim = 4, (64, 64, 32), 1024
@@ -87,6 +91,31 @@ def test_group_step_equals_single_steps(cls, G):
             else:
                 assert rel_err(c, b) <= 2e-3, k
     print(f"{cls} x{G}: group == single steps")
+
+
+def test_group_default_split_statistical():
+    """Default (group-size dependent) tap split: first-step gradients agree with the single-model path statistically."""
+    from multimodal_survival_prediction_amd.engine import SurvivalEngine
+    from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
+    cls, G, B, dims, rna_dim = "MultiModalSurvivalNet", 4, 4, (64, 64, 32), 512
+    base = _models(cls, G, rna_dim)
+    solo = [copy.deepcopy(m).to(DEV).train() for m in base]
+    grp = [copy.deepcopy(m).to(DEV).train() for m in base]
+    se = [SurvivalEngine(m) for m in solo]
+    ge = FoldGroupEngine(grp)
+    batches = []
+    for g in range(G):
+        ct, rna, clin, t, e, mask = _batch(B, dims, rna_dim, 90 + g)
+        batches.append(dict(ct=ct, rna=rna, clinical=clin, time=t, event=e))
+        se[g].train_step(use_graph=False, **batches[g])
+    ge.train_step(batches, use_graph=False)
+    torch.cuda.synchronize()
+    for g in range(G):
+        a, b = se[g].gflat.double(), ge.engines[g].gflat.double()
+        l2 = float(((a - b) ** 2).sum().sqrt() / (a ** 2).sum().sqrt())
+        assert l2 <= 1e-2, (g, l2)                      # same bound as the network-level gradient parity tests
+        sa, sb = se[g].epoch_stats(), ge.engines[g].epoch_stats()
+        assert abs(sa["sum_loss"] - sb["sum_loss"]) <= 1e-4 * max(1.0, abs(sa["sum_loss"]))
 
 
 def test_group_subset_and_eval():
