@@ -163,7 +163,7 @@ def main():
             model.train()
             ms.append(model)
             gen = torch.Generator().manual_seed(7 + f * G + g)
-            orders.append(train_idx[torch.randperm(len(train_idx), generator=gen)].to(dev))
+            orders.append(train_idx[torch.randperm(len(train_idx), generator=gen)].to(dev if G == 1 else "cpu"))
         if G > 1:
             from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
             groups.append(FoldGroupEngine(ms, lr=1e-4, weight_decay=1e-4, adamw=False))
@@ -186,9 +186,10 @@ def main():
         f = u % nf
         k = u // nf
         with torch.cuda.stream(streams[f]):
-            if G > 1:
-                groups[f].train_step([batch_of(f * G + g, k) for g in range(members)], members=tuple(range(members)),
-                                     skip_if_unusable=True, use_graph=not args.no_graph)
+            if G > 1:     # batches named by patient index; the group gathers them from the HBM-resident cohort in one launch
+                idx = [orders[f * G + g][(k % (len(orders[f * G + g]) // B)) * B:][:B] for g in range(members)]
+                groups[f].train_step_indexed(cohort, torch.stack(idx), members=tuple(range(members)),
+                                             skip_if_unusable=True, use_graph=not args.no_graph)
             else:
                 engines[f].train_step(skip_if_unusable=True, use_graph=not args.no_graph, ddp_world=world if ddp else 1,
                                       **batch_of(f, k))
@@ -221,7 +222,9 @@ def main():
         n1 = max(args.steps // (3 * F * G), 10)
         if G > 1:
             def one(i):
-                groups[0].train_step([batch_of(0, i)], members=(0,), skip_if_unusable=True, use_graph=not args.no_graph)
+                nb0 = len(orders[0]) // B
+                groups[0].train_step_indexed(cohort, orders[0][(i % nb0) * B:][:B].view(1, B), members=(0,),
+                                             skip_if_unusable=True, use_graph=not args.no_graph)
             for i in range(3):
                 one(i)
             torch.cuda.synchronize(); D.barrier()

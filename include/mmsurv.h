@@ -320,6 +320,17 @@ typedef struct AdamP {
     int* rng;                       // [2] dropout (seed, step counter): counter += 1 after the step's kernels have used it
 } AdamP;
 
+/* Batch assembly from a device-resident cohort (the DataLoader collate of R/scripts/training/final_multimodal.py:228-236
+ * when the tensors already live in HBM): row idx[b] of each source array -> row b of its destination, all sources of
+ * all models of a fold group in ONE launch. */
+typedef struct GatherP {
+    const long long* idx; int B;    // [B] patient indices (device)
+    int nsrc;                       // sources used (<= 8)
+    const float* src[8]; float* dst[8];
+    int src_ld[8]; int dst_ld[8];   // row pitches in floats
+    int width[8];                   // floats copied per row
+} GatherP;
+
 /* ---- ABI self-description ---- */
 int mms_abi_sizeof(const char* name);      /* sizeof(struct <name>) as compiled, -1 if unknown */
 int mms_abi_version(void);
@@ -411,6 +422,7 @@ int mms_pool_bwd_group(const PoolBwdP* p, int ng, hipStream_t s);
 int mms_conv0_bwd_weight_group(const Conv0BwdWP* p, int ng, hipStream_t s);
 int mms_pack_conv3_table_group(const void* const* tables_dev, int ng, int nlayers, hipStream_t s);
 int mms_bn_running_update_group(const void* const* tables_dev, int ng, int n, float momentum, hipStream_t s);
+int mms_gather_rows_group(const GatherP* p, int ng, hipStream_t s);
 int mms_zero_regions_group(void* const* regions_dev, int ng, size_t bytes, hipStream_t s);   /* 16-B aligned regions of equal size, zero-filled by one launch */
 int mms_linear_fwd_group(const LinearFwdP* p, int ng, hipStream_t s);
 int mms_linear_bwd_group(const LinearBwdP* p, int ng, hipStream_t s);

@@ -50,8 +50,9 @@ def parse_header(path=HEADER):
             decl = decl.strip()
             if not decl:
                 continue
-            mm = re.match(r"(.*?)(\w+)$", decl, flags=re.S)
-            fields.append((mm.group(2), _ctype(mm.group(1))))
+            mm = re.match(r"(.*?)(\w+)\s*(?:\[(\d+)\])?$", decl, flags=re.S)
+            ct = _ctype(mm.group(1))
+            fields.append((mm.group(2), ct * int(mm.group(3)) if mm.group(3) else ct))
         _STRUCTS[name] = type(name, (ctypes.Structure,), {"_fields_": fields})
     for m in re.finditer(r"\bint\s+(mms_\w+)\s*\((.*?)\)\s*;", src, flags=re.S):
         args = [a.strip() for a in m.group(2).split(",") if a.strip() and a.strip() != "void"]

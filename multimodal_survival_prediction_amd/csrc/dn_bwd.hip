@@ -6,6 +6,7 @@
 #include "dn_ops.h"
 #include "tile_gemm.h"
 #include <string.h>
+#include <stdlib.h>
 
 #define Z4 make_float4(0, 0, 0, 0)
 
@@ -784,6 +785,166 @@ struct Conv0BwdWOp {
         }
     }
 };
+// ------------------------------------------------------------------------------------------------------
+// conv0 backward-weight, LDS-staged form (the default; the tile-GEMM op above remains for grids that are not a
+// multiple of the 2x4x4 box).  The GEMM form gathers x[patch(m, k)] with one scalar load per (voxel, tap) and re-reads
+// dbn0/y0 once per 64-tap tile (6x); here a workgroup walks boxes of 2x4x4 = 32 output voxels, stages the box's input
+// region (9 x 13 x 13 voxels of the single input channel) and its 32 x 64 dy0 values in LDS once, and feeds the MFMAs
+// straight from LDS: A[tap][voxel] = region[koff(tap) + moff(voxel)] (one ds_read_b32 per operand, no im2col image),
+// B[voxel][ch] = dy0.  Each wave owns 3 of the 11 tap tiles x both channel tiles (96 accumulator VGPRs), so the whole
+// 343 x 64 gradient of the workgroup's voxel range lives in registers and dbn0/y0/x are read exactly once.
+// Algorithmic bytes per output voxel: 64 ch x 4 B x 2 (dbn0, y0) + ~8 x 4 B of x = 544 B; FLOPs: 2 * 343 * 64.
+// ------------------------------------------------------------------------------------------------------
+#define C0_REG (9 * 13 * 13)        // 1521
+#define C0_DYP 68
+// Work distribution: the boxes of all models of the group form one pool that is dealt evenly over gridDim.x workgroups
+// (a multiple of the CU count: the kernel is MFMA-bound, so an uneven deal costs its full imbalance); a workgroup whose
+// range crosses a model boundary flushes its accumulators there (grp.zdim = number of models).
+__global__ __launch_bounds__(256) void conv0_bwd_weight_kernel(const Grp<Conv0BwdWP> grp) {
+    __shared__ float xs[2][C0_REG + 7];
+    __shared__ float dys[2][32 * C0_DYP];
+    __shared__ float cst[5 * 64];
+    __shared__ float Cs[4][32 * 65];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kq = lane >> 5;
+    float *cA = cst, *cB = cst + 64, *cC = cst + 128, *cM = cst + 192, *cR = cst + 256;
+    const int D0 = grp.p[0].out.D, H0 = grp.p[0].out.H, W0 = grp.p[0].out.W, Di = grp.p[0].in.D, Hi = grp.p[0].in.H, Wi = grp.p[0].in.W;
+    const int bh = H0 >> 2, bw = W0 >> 2, bps = (D0 >> 1) * bh * bw;          // boxes per sample
+    const int nbox = (grp.p[0].M / (D0 * H0 * W0)) * bps;                      // boxes per model
+    const int total = nbox * grp.zdim;
+    const int per = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int g0 = blockIdx.x * per, g1 = g0 + per < total ? g0 + per : total;
+
+    // per-lane operand offsets: tap tiles T = wave + 4t; voxel pairs q (voxel = 2q + kq)
+    int koff[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        int tap = 32 * (wave + 4 * t) + li;
+        tap = tap < 343 ? tap : 342;                 // padded taps compute a duplicate that the epilogue drops
+        koff[t] = (tap / 49) * 169 + ((tap / 7) % 7) * 13 + tap % 7;
+    }
+    int moff[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int v = 2 * q + kq;
+        moff[q] = (v >> 4) * 2 * 169 + ((v >> 2) & 3) * 2 * 13 + (v & 3) * 2;
+    }
+    const bool t2ok = wave + 8 < 11;                // wave 3 owns tap tiles 3 and 7 only
+
+  for (int gs = g0; gs < g1;) {
+    const int model = gs / nbox, seg_end = (model + 1) * nbox < g1 ? (model + 1) * nbox : g1;
+    const int b0 = gs - model * nbox, b1 = seg_end - model * nbox;
+    gs = seg_end;
+    const Conv0BwdWP& p = grp.p[model];
+    __syncthreads();                          // the previous segment is done with cst / xs / dys
+    if (tid < 64) {
+        float mu, rs;
+        bn_mean_rstd(p.bn, tid, mu, rs);
+        cA[tid] = p.bn.gamma[tid] * rs;
+        const double t1 = rep_sum(p.bb.s1, tid, p.bb.nrep, p.bb.rep_stride), t2 = rep_sum(p.bb.s2, tid, p.bb.nrep, p.bb.rep_stride);
+        cB[tid] = (float)(t1 * (double)p.bn.inv_count);
+        cC[tid] = (float)(t2 * (double)p.bn.inv_count);
+        cM[tid] = mu; cR[tid] = rs;
+        if (b0 == 0 && p.dgamma) {            // exactly one workgroup owns a model's first box
+            p.dgamma[tid] += (float)t2;
+            p.dbeta[tid] += (float)t1;
+        }
+    }
+    __syncthreads();
+    // staging roles: 6 region elements per thread; dy: voxel tid >> 3, channels (tid & 7) * 8 .. + 7
+    const int sv = tid >> 3, sc0 = (tid & 7) * 8;
+    float xr[6];
+    float4 rg0, rg1, ry0, ry1;
+    auto gload = [&](int bx) {
+        const int b = bx / bps, r = bx - b * bps, bz = r / (bh * bw), r2 = r - bz * (bh * bw), by = r2 / bw, bxw = r2 - by * bw;
+        const int od0 = 2 * bz, oh0 = 4 * by, ow0 = 4 * bxw, id0 = 2 * od0 - 3, ih0 = 2 * oh0 - 3, iw0 = 2 * ow0 - 3;
+        const float* xb = p.x + (size_t)b * Di * Hi * Wi;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int e = tid + 256 * i, rd = e / 169, e2 = e - rd * 169, rh = e2 / 13, rw = e2 - rh * 13;
+            const int id = id0 + rd, ih = ih0 + rh, iw = iw0 + rw;
+            const bool ok = e < C0_REG && (unsigned)id < (unsigned)Di && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi;
+            xr[i] = ok ? xb[((size_t)id * Hi + ih) * Wi + iw] : 0.f;
+        }
+        const int m = ((b * D0 + od0 + (sv >> 4)) * H0 + oh0 + ((sv >> 2) & 3)) * W0 + ow0 + (sv & 3);
+        const float* gp = p.dbn + (size_t)m * 64 + sc0;
+        const float* yp = p.y0 + (size_t)m * 64 + sc0;
+        rg0 = *(const float4*)gp; rg1 = *(const float4*)(gp + 4);
+        ry0 = *(const float4*)yp; ry1 = *(const float4*)(yp + 4);
+    };
+    auto dyv = [&](float g, float y, int n) { return cA[n] * (g - cB[n] - (y - cM[n]) * cR[n] * cC[n]); };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { const int e = tid + 256 * i; if (e < C0_REG) xs[buf][e] = xr[i]; }
+        float* d = &dys[buf][sv * C0_DYP + sc0];
+        *(float4*)d = make_float4(dyv(rg0.x, ry0.x, sc0), dyv(rg0.y, ry0.y, sc0 + 1), dyv(rg0.z, ry0.z, sc0 + 2), dyv(rg0.w, ry0.w, sc0 + 3));
+        *(float4*)(d + 4) = make_float4(dyv(rg1.x, ry1.x, sc0 + 4), dyv(rg1.y, ry1.y, sc0 + 5), dyv(rg1.z, ry1.z, sc0 + 6), dyv(rg1.w, ry1.w, sc0 + 7));
+    };
+
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][c][r] = 0.f;
+
+    if (b0 < b1) {
+        gload(b0);
+        sstore(0);
+        __syncthreads();
+        int buf = 0;
+        for (int bx = b0; bx < b1; ++bx) {
+#ifdef C0_NO_STAGE
+            const bool more = false;
+#else
+            const bool more = bx + 1 < b1;
+#endif
+            if (more) gload(bx + 1);
+            const float* xb = xs[buf];
+            const float* db = dys[buf];
+#ifndef C0_NO_MMA
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float bv0 = db[(2 * q + kq) * C0_DYP + li], bv1 = db[(2 * q + kq) * C0_DYP + 32 + li];
+                const float a0 = xb[koff[0] + moff[q]], a1 = xb[koff[1] + moff[q]];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv1, acc[1][1], 0, 0, 0);
+                if (t2ok) {
+                    const float a2 = xb[koff[2] + moff[q]];
+                    acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, bv0, acc[2][0], 0, 0, 0);
+                    acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, bv1, acc[2][1], 0, 0, 0);
+                }
+            }
+#endif
+            if (more) sstore(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+    // epilogue: per wave, tile by tile through LDS so that the atomics run along k (dW0[n][k] is contiguous in k)
+    float* cs = Cs[wave];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        if (t == 2 && !t2ok) break;
+        const int T = wave + 4 * t;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * kq) * 65 + 32 * c + li] = acc[t][c][r];
+        __builtin_amdgcn_wave_barrier();
+#ifndef C0_NO_EPI
+        for (int idx = lane; idx < 32 * 64; idx += 64) {
+            const int tl = idx & 31, ch = idx >> 5, tap = 32 * T + tl;
+            if (tap < 343) atomicAdd(&p.dw[ch * 343 + tap], cs[tl * 65 + ch]);
+        }
+#endif
+        __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
 extern "C" int mms_conv0_bwd_weight_group(const Conv0BwdWP* pp, int ng, hipStream_t s) {
     if (!pp || ng < 1 || ng > MMS_MAX_GROUP) return MMS_ERR_ARG;
     const Conv0BwdWP& p = *pp;
@@ -793,6 +954,18 @@ extern "C" int mms_conv0_bwd_weight_group(const Conv0BwdWP* pp, int ng, hipStrea
         if (q.M != p.M || q.msplit != p.msplit || q.in.D != p.in.D || q.in.H != p.in.H || q.in.W != p.in.W || q.out.D != p.out.D ||
             q.out.H != p.out.H || q.out.W != p.out.W) return MMS_ERR_ARG;
     }
-    return launch_tile_gemm<Conv0BwdWOp>(pp, ng, dim3(6, 1, p.msplit), s);
+    const long vox = (long)p.out.D * p.out.H * p.out.W;
+    const bool boxed = (p.out.D % 2 == 0) && (p.out.H % 4 == 0) && (p.out.W % 4 == 0) && vox > 0 && p.M % vox == 0 &&
+                       p.in.D == 2 * p.out.D && p.in.H == 2 * p.out.H && p.in.W == 2 * p.out.W;
+    if (!boxed) return launch_tile_gemm<Conv0BwdWOp>(pp, ng, dim3(6, 1, p.msplit), s);
+    Grp<Conv0BwdWP> a;
+    grp_fill(a, pp, ng, ng);
+    // workgroups: 2 per CU (the second hides the first one's staging), but at least 8 boxes of 32 voxels each
+    const long boxes = (long)ng * (p.M / 32);
+    const char* e_ = getenv("MMS_C0_NWG");
+    int nwg = e_ ? atoi(e_) : (boxes >= 256L * 8 ? 256 : (int)((boxes + 7) / 8));
+    if (nwg < 1) nwg = 1;
+    MMS_LAUNCH(conv0_bwd_weight_kernel, dim3(nwg, 1, 1), dim3(256), 0, s, a);
+    return mms_check_launch();
 }
 MMS_SINGLE(mms_conv0_bwd_weight, Conv0BwdWP)

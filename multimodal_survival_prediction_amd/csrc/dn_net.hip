@@ -361,7 +361,8 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
             Conv1BwdP c1[MMS_MAX_GROUP];
             BnBwdApplyP ap[MMS_MAX_GROUP];
             const int ns3 = conv3_nsplit(M, ng, P.partial_rows);
-            int ms3 = M > 1024 ? (M + 511) / 512 : (M + 127) / 128; if (ms3 < 1) ms3 = 1;
+            static const int rows3 = getenv("MMS_MS3_ROWS") ? atoi(getenv("MMS_MS3_ROWS")) : 512;
+            int ms3 = M > 1024 ? (M + rows3 - 1) / rows3 : (M + 127) / 128; if (ms3 < 1) ms3 = 1;
             int ms1 = M > 1024 ? M / 256 : M / 128; if (ms1 < 1) ms1 = 1; if (ms1 > 32) ms1 = 32;
             FOR_G {
                 const Ctx& c = cx[g];

@@ -547,3 +547,42 @@ extern "C" int mms_clip_adam_group(const AdamP* pp, int ng, hipStream_t s) {
 }
 MMS_SINGLE(mms_grad_sumsq, AdamP)
 MMS_SINGLE(mms_clip_adam, AdamP)
+
+// ------------------------------------------------------------------------------------------------------
+// batch assembly: gather cohort rows into the step's static input buffers (all sources, all models, one launch)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_rows_kernel(const Grp<GatherP> grp) {
+    const GatherP& p = grp.p[blockIdx.z];
+    const int b = blockIdx.y;
+    if (b >= p.B) return;
+    const long long row = p.idx[b];
+    const int t0 = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+    for (int s = 0; s < p.nsrc; ++s) {
+        const float* src = p.src[s] + (size_t)row * p.src_ld[s];
+        float* dst = p.dst[s] + (size_t)b * p.dst_ld[s];
+        const int w = p.width[s];
+        if ((w & 3) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+            for (int i = t0; i < (w >> 2); i += stride) ((float4*)dst)[i] = ((const float4*)src)[i];
+        } else {
+            for (int i = t0; i < w; i += stride) dst[i] = src[i];
+        }
+    }
+}
+extern "C" int mms_gather_rows_group(const GatherP* pp, int ng, hipStream_t s) {
+    Grp<GatherP> a;
+    if (!grp_fill(a, pp, ng, 1)) return MMS_ERR_ARG;
+    int wmax = 0;
+    for (int g = 0; g < ng; ++g) {
+        const GatherP& q = pp[g];
+        if (q.B != pp->B || q.B <= 0 || !q.idx || q.nsrc < 1 || q.nsrc > 8) return MMS_ERR_ARG;
+        for (int i = 0; i < q.nsrc; ++i) {
+            if (!q.src[i] || !q.dst[i] || q.width[i] <= 0) return MMS_ERR_ARG;
+            if (q.width[i] > wmax) wmax = q.width[i];
+        }
+    }
+    int blocks = (wmax / 4 + 1023) / 1024;       // ~4 float4 per thread on the widest source
+    if (blocks < 1) blocks = 1;
+    if (blocks > 64) blocks = 64;
+    MMS_LAUNCH(gather_rows_kernel, dim3(blocks, pp->B, ng), dim3(256), 0, s, a);
+    return mms_check_launch();
+}

@@ -316,6 +316,32 @@ class SurvivalEngine:
         else:
             P.valid.copy_(valid.reshape(-1).to(torch.float32), non_blocking=True)
 
+    def gather_block(self, P, cohort, idx_dev):
+        """GatherP (include/mmsurv.h) that assembles this plan's batch from a device-resident cohort dict
+        (data.make_cohort / cohort_to): image, rnaseq, clinical, mask, label[time, event] and, when present, a float
+        per-patient `valid` column.  idx_dev: [B] int64 device tensor that the caller refills before each launch."""
+        G = _S()["GatherP"]()
+        G.idx, G.B = idx_dev.data_ptr(), P.B
+        srcs = [(cohort["image"].view(cohort["image"].shape[0], -1), P.ct.view(P.B, -1), None),
+                (cohort["rnaseq"], P.buf["rna"], None)]
+        if "clin" in P.buf:
+            srcs.append((cohort["clinical"], P.buf["clin"], None))
+        if P.gate is not None:
+            srcs.append((cohort["mask"], P.mask, None))
+        lab = cohort["label"]
+        srcs.append((lab, P.time.view(P.B, 1), 1))
+        srcs.append((lab[:, 1:], P.event.view(P.B, 1), 1))
+        if "valid" in cohort:
+            srcs.append((cohort["valid"].view(-1, 1), P.valid.view(P.B, 1), 1))
+        G.nsrc = len(srcs)
+        for i, (a, b, w) in enumerate(srcs):
+            if a.dtype != torch.float32 or not a.is_cuda:
+                raise TypeError("gather sources must be fp32 device tensors")
+            G.src[i], G.dst[i] = a.data_ptr(), b.data_ptr()
+            G.src_ld[i], G.dst_ld[i] = a.stride(0), b.stride(0)
+            G.width[i] = w if w is not None else a.shape[1]
+        return G
+
     def train_step(self, ct, rna, clinical=None, mask=None, time=None, event=None, valid=None, skip_if_unusable=True,
                    use_graph=True, ddp_world=1):
         """One optimisation step on one batch (inputs may live on host or device).  Returns nothing: losses are

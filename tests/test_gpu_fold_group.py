@@ -156,3 +156,34 @@ def test_group_rejects_mismatched_shapes():
     arr = (S["AdamP"] * 2)(a, b)
     assert lib.mms_grad_sumsq_group(arr, 2, ops.stream()) == -1       # MMS_ERR_ARG: sizes differ
     assert lib.mms_grad_sumsq_group(arr, 9, ops.stream()) == -1       # > MMS_MAX_GROUP
+
+
+def test_indexed_step_equals_batch_step(monkeypatch):
+    """train_step_indexed (one gather launch from the device-resident cohort) == train_step on the same batches."""
+    monkeypatch.setenv("MMS_SPLIT_WGS", "1000000")
+    from multimodal_survival_prediction_amd import data
+    from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
+    cls, G, B, dims, rna_dim = "PartialModalityNet", 2, 4, (32, 32, 32), 64
+    cohort = data.cohort_to(data.make_cohort(n=24, dims=dims, rna_dim=rna_dim, seed=3, complete=False), DEV)
+    cohort["valid"] = cohort["has_survival"].float()
+    base = _models(cls, G, rna_dim)
+    A = FoldGroupEngine([copy.deepcopy(m).to(DEV).train() for m in base])
+    Bg = FoldGroupEngine([copy.deepcopy(m).to(DEV).train() for m in base])
+    rng = np.random.default_rng(0)
+    for it in range(3):
+        idx = np.stack([rng.permutation(24)[:B] for _ in range(G)])
+        batches = []
+        for g in range(G):
+            j = torch.as_tensor(idx[g], device=DEV)
+            lab = cohort["label"][j]
+            batches.append(dict(ct=cohort["image"][j], rna=cohort["rnaseq"][j], clinical=cohort["clinical"][j],
+                                mask=cohort["mask"][j], time=lab[:, 0], event=lab[:, 1], valid=cohort["valid"][j]))
+        A.train_step(batches, skip_if_unusable=False, use_graph=it > 0)
+        Bg.train_step_indexed(cohort, idx, skip_if_unusable=False, use_graph=it > 0)
+        torch.cuda.synchronize()
+        if it == 0:
+            for g in range(G):
+                assert rel_err(Bg.engines[g].gflat, A.engines[g].gflat) <= 2e-5
+    for a, b in zip(A.epoch_stats(), Bg.epoch_stats()):
+        assert a["n_batches"] == b["n_batches"] == 3 and a["n_usable"] == b["n_usable"]
+        assert abs(a["sum_loss"] - b["sum_loss"]) <= 1e-2 * max(1.0, abs(a["sum_loss"]))
