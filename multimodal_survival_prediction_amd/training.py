@@ -18,6 +18,8 @@ class FusedOptimizer:
 
     def __init__(self, model, lr=1e-4, weight_decay=1e-4, adamw=False, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0,
                  gate_entropy_weight=0.01):
+        # (a model that already belongs to a FoldGroupEngine keeps that engine: this object is then just the handle
+        # the LR schedulers talk to -- pass the same hyper-parameters to the group's constructor)
         self.engine = engine_of(model, lr=lr, weight_decay=weight_decay, adamw=adamw, betas=betas, eps=eps,
                                 max_norm=max_norm, gate_entropy_weight=gate_entropy_weight)
         self.param_groups = [dict(lr=lr, weight_decay=weight_decay)]
@@ -189,3 +191,129 @@ def validate_simple(model, loader, device):
         return 0.0, 0.5
     c = losses.ConcordanceIndex()(torch.cat(hs), torch.cat(es), torch.cat(ts)).item()
     return (total / nb if nb > 0 else 0.0), c
+
+
+# ---- K folds in lock-step (fold groups) ------------------------------------------------------------------------------
+# The reference trains its folds one after the other; they are independent, so a FoldGroupEngine advances all of them by
+# one batch with ONE launch sequence (fold_group.py).  Per fold, batch order, skipping rules, loss averaging and return
+# values are exactly those of train_epoch_<style> / validate_<style> above; only the interleaving of the folds differs.
+def _train_kwargs(style, batch):
+    """-> (keyword arguments of the fused step, skip_if_unusable) or None when the script skips the batch before the forward."""
+    if style == "final":
+        label = batch['label']
+        return dict(ct=batch['image'], rna=batch['rnaseq'], clinical=batch['clinical'], time=label[:, 0], event=label[:, 1])
+    valid = torch.as_tensor(batch['has_survival'], dtype=torch.float32)
+    if style == "partial":
+        label = batch['label']
+        return dict(ct=batch['image'], rna=batch['rnaseq'], clinical=batch['clinical'], mask=batch['mask'], time=label[:, 0],
+                    event=label[:, 1], valid=valid)
+    if style == "simple":
+        if float(valid.sum()) < 2:
+            return None                                      # simple_fusion.py:257-258
+        return dict(ct=batch['image'], rna=batch['rnaseq'], time=batch['time'].reshape(-1), event=batch['event'].reshape(-1),
+                    valid=valid)
+    raise ValueError(style)
+
+
+_SKIP_UNUSABLE = {"final": True, "partial": False, "simple": True}
+
+
+def _lockstep(loaders, members):
+    """Yield, batch position by batch position, {member: batch} of the folds that still have a batch."""
+    its = {g: iter(l) for g, l in zip(members, loaders)}
+    while its:
+        out = {}
+        for g in list(its):
+            b = next(its[g], None)
+            if b is None:
+                del its[g]
+            else:
+                out[g] = b
+        if out:
+            yield out
+
+
+def train_epoch_lockstep(group, loaders, style, members=None):
+    """One epoch of the folds `members` (default: all) of a FoldGroupEngine, each on its own loader.
+    -> per member, what train_epoch_<style> returns for that fold."""
+    members = tuple(range(len(group))) if members is None else tuple(members)
+    for g in members:
+        group.engines[g].model.train()
+        group.engines[g].reset_epoch_stats()
+    for pos in _lockstep(loaders, members):
+        by_size = {}
+        for g, batch in pos.items():
+            kw = _train_kwargs(style, batch)
+            if kw is not None:
+                by_size.setdefault(int(kw["ct"].shape[0]), []).append((g, kw))
+        for items in by_size.values():           # a ragged last batch forms its own (sub-)group step
+            group.train_step([kw for _, kw in items], members=tuple(g for g, _ in items),
+                             skip_if_unusable=_SKIP_UNUSABLE[style])
+    out = []
+    for g in members:
+        st = group.engines[g].epoch_stats()
+        if style == "final":
+            out.append(st["sum_loss"] / st["n_batches"] if st["n_batches"] > 0 else 0)
+        elif style == "partial":
+            out.append((st["sum_loss"] / st["n_usable"] if st["n_usable"] > 0 else 0,
+                        st["sum_entropy"] / st["n_batches"] if st["n_batches"] > 0 else 0))
+        else:
+            out.append(st["sum_loss"] / st["n_usable"] if st["n_usable"] > 0 else 0.0)
+    return out
+
+
+def validate_lockstep(group, loaders, style, device, members=None):
+    """validate_<style> of the folds `members`, their eval forwards issued as fold-group launches.
+    -> per member (val_loss, c_index)."""
+    members = tuple(range(len(group))) if members is None else tuple(members)
+    acc = {g: dict(total=0.0, nb=0, hs=[], ts=[], es=[]) for g in members}
+    for g in members:
+        group.engines[g].model.eval()
+    for pos in _lockstep(loaders, members):
+        by_size, meta = {}, {}
+        for g, batch in pos.items():
+            if style == "final":
+                kw = dict(ct=batch['image'], rna=batch['rnaseq'], clinical=batch['clinical'])
+            elif style == "partial":
+                kw = dict(ct=batch['image'], rna=batch['rnaseq'], clinical=batch['clinical'], mask=batch['mask'])
+            else:
+                if int(torch.as_tensor(batch['has_survival']).sum()) < 2:
+                    continue
+                kw = dict(ct=batch['image'], rna=batch['rnaseq'])
+            meta[g] = batch
+            by_size.setdefault(int(kw["ct"].shape[0]), []).append((g, kw))
+        for items in by_size.values():
+            outs = group.forward_eval([kw for _, kw in items], members=tuple(g for g, _ in items))
+            for (g, _), (hz, _gate) in zip(items, outs):
+                batch, a = meta[g], acc[g]
+                if style == "final":
+                    label = _t(batch['label'], device)
+                    h, t, e = hz.clone(), label[:, 0], label[:, 1]
+                    a["total"] += losses.cox_loss(h, e, t).item(); a["nb"] += 1
+                elif style == "partial":
+                    label = _t(batch['label'], device)
+                    smask = torch.as_tensor(batch['has_survival'], dtype=torch.bool, device=device)
+                    if int(smask.sum()) == 0:
+                        continue
+                    h, t, e = hz[smask].clone(), label[smask, 0], label[smask, 1]
+                    if not (h.shape[0] >= 2 and float(e.sum()) > 0):
+                        continue
+                    a["total"] += losses.cox_loss(h, e, t).item(); a["nb"] += 1
+                else:
+                    smask = torch.as_tensor(batch['has_survival'], dtype=torch.bool, device=device)
+                    time, event = _t(batch['time'].reshape(-1), device), _t(batch['event'].reshape(-1), device)
+                    h, t, e = hz[smask].clone(), time[smask], event[smask].float()
+                    if float(e.sum()) == 0:
+                        continue
+                    a["total"] += losses.neg_partial_log_likelihood(h, e, t).item(); a["nb"] += 1
+                a["hs"].append(h); a["ts"].append(t); a["es"].append(e)
+    out = []
+    for g in members:
+        a = acc[g]
+        if not a["hs"]:
+            out.append((0.0 if style == "simple" else 0, 0.5))
+            continue
+        H, E, T = torch.cat(a["hs"]), torch.cat(a["es"]), torch.cat(a["ts"])
+        c = losses.ConcordanceIndex()(H, E, T).item() if style == "simple" else losses.calculate_cindex(H, E, T)
+        out.append((a["total"] / a["nb"] if a["nb"] > 0 else 0, c))
+    return out

@@ -32,3 +32,49 @@ def save_json(path, obj):
     os.makedirs(os.path.dirname(path), exist_ok=True)
     with open(path, "w") as f:
         json.dump(obj, f, indent=2)
+
+
+def lockstep_enabled(n_local_folds):
+    """Folds of this rank train in lock-step as one fold group (MMS_LOCKSTEP=0 restores fold-after-fold order)."""
+    return env_int("MMS_LOCKSTEP", 1) != 0 and 2 <= n_local_folds <= 8
+
+
+def cv_lockstep(style, models, loaders, group_kw, num_epochs, patience, make_scheduler, ckpt_path, device, rank, fold_names,
+                log_every=5):
+    """The per-fold epoch loop of the three scripts (train, validate, scheduler, best-checkpoint, early stopping) run for
+    all local folds at once: one FoldGroupEngine advances every still-active fold by one batch per launch sequence.
+    loaders: [(train_loader, val_loader)] per fold; make_scheduler(optimizer) -> object with step(metric) or step();
+    patience None = no early stopping (simple_fusion.py).  -> per fold dict(best_c_index, best_epoch, patients_per_sec)."""
+    import inspect
+    import time
+    from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
+    from multimodal_survival_prediction_amd.training import FusedOptimizer, train_epoch_lockstep, validate_lockstep
+    group = FoldGroupEngine(models, **group_kw)
+    opts = [FusedOptimizer(m, lr=group_kw.get("lr", 1e-4), weight_decay=group_kw.get("weight_decay", 1e-4)) for m in models]
+    scheds = [make_scheduler(o) for o in opts]
+    takes_metric = [len(inspect.signature(s.step).parameters) > 0 for s in scheds]
+    st = [dict(best=0.0, best_epoch=0, bad=0, done=False, t=0.0, n=0) for _ in models]
+    for epoch in range(1, num_epochs + 1):
+        active = [g for g in range(len(models)) if not st[g]["done"]]
+        if not active:
+            break
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        tr = train_epoch_lockstep(group, [loaders[g][0] for g in active], style, members=active)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        n_ep = sum(len(loaders[g][0].idx) for g in active)
+        va = validate_lockstep(group, [loaders[g][1] for g in active], style, device, members=active)
+        for g, trg, (val_loss, c) in zip(active, tr, va):
+            s = st[g]
+            s["t"] += dt; s["n"] += n_ep                       # the group's aggregate rate while this fold was active
+            scheds[g].step(c) if takes_metric[g] else scheds[g].step()
+            if c > s["best"]:
+                s["best"], s["best_epoch"], s["bad"] = c, epoch, 0
+                torch.save(models[g].state_dict(), ckpt_path(fold_names[g]))
+            else:
+                s["bad"] += 1
+                if patience is not None and s["bad"] >= patience:
+                    s["done"] = True
+            if epoch % log_every == 0 or epoch == 1:
+                print(f"[rank {rank}] fold {fold_names[g]} epoch {epoch:3d}: train={trg} val_loss={val_loss:.4f} "
+                      f"C-index={c:.4f} best={s['best']:.4f}", flush=True)
+    return [dict(best_c_index=s["best"], best_epoch=s["best_epoch"], patients_per_sec=s["n"] / max(s["t"], 1e-9)) for s in st]

@@ -15,7 +15,7 @@ import time
 import numpy as np
 import torch
 
-from _common import env_float, env_int, save_json, setup_device
+from _common import cv_lockstep, env_float, env_int, lockstep_enabled, save_json, setup_device
 
 from multimodal_survival_prediction_amd import data, distributed as D
 from multimodal_survival_prediction_amd.losses import calculate_cindex, cox_loss, gate_entropy_loss  # noqa: F401
@@ -45,7 +45,21 @@ def main():
     folds = data.kfold_indices(len(survival), N_FOLDS, seed=SEED)
     os.makedirs("models/partial_modality", exist_ok=True)
     local = []
-    for fold in D.folds_of_rank(N_FOLDS, world, rank):
+    my_folds = list(D.folds_of_rank(N_FOLDS, world, rank))
+    if lockstep_enabled(len(my_folds)):
+        splits = [(np.concatenate([survival[folds[f][0]], non_survival]), survival[folds[f][1]]) for f in my_folds]
+        loaders = [(data.BatchLoader(cohort, tr_all, BATCH_SIZE, shuffle=True, seed=SEED + f),
+                    data.BatchLoader(cohort, va_s, BATCH_SIZE, shuffle=False)) for f, (tr_all, va_s) in zip(my_folds, splits)]
+        models = [PartialModalityNet().to(device) for _ in my_folds]
+        res = cv_lockstep("partial", models, loaders,
+                          dict(lr=LEARNING_RATE, weight_decay=1e-4, adamw=False, gate_entropy_weight=GATE_ENTROPY_WEIGHT),
+                          NUM_EPOCHS, PATIENCE, lambda o: ReduceLROnPlateau(o, mode="max", factor=0.5, patience=5),
+                          lambda name: f"models/partial_modality/fold_{name}_best.pth", device, rank, [f + 1 for f in my_folds])
+        local = [{"fold": f + 1, "best_c_index": r["best_c_index"], "train_size": int(len(tr_all)),
+                  "train_survival_size": int(len(folds[f][0])), "val_size": int(len(va_s)), "patients_per_sec": r["patients_per_sec"]}
+                 for f, r, (tr_all, va_s) in zip(my_folds, res, splits)]
+        my_folds = []
+    for fold in my_folds:
         tr, va = folds[fold]
         train_all = np.concatenate([survival[tr], non_survival])          # (:508-513)
         val_survival = survival[va]

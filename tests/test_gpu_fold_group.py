@@ -187,3 +187,44 @@ def test_indexed_step_equals_batch_step(monkeypatch):
     for a, b in zip(A.epoch_stats(), Bg.epoch_stats()):
         assert a["n_batches"] == b["n_batches"] == 3 and a["n_usable"] == b["n_usable"]
         assert abs(a["sum_loss"] - b["sum_loss"]) <= 1e-2 * max(1.0, abs(a["sum_loss"]))
+
+
+@pytest.mark.parametrize("style", ["final", "partial", "simple"])
+def test_lockstep_epoch_matches_sequential(style, monkeypatch):
+    """train_epoch_lockstep / validate_lockstep == train_epoch_<style> / validate_<style> fold by fold (ragged fold sizes:
+    the last batch positions run as sub-groups)."""
+    monkeypatch.setenv("MMS_SPLIT_WGS", "1000000")
+    from multimodal_survival_prediction_amd import data, models as HM, training as T
+    from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
+    dims, rna_dim, K, B = (32, 32, 32), 48, 3, 4
+    cohort = data.cohort_to(data.make_cohort(n=29, dims=dims, rna_dim=rna_dim, seed=5, complete=(style != "partial")), DEV)
+    folds = data.kfold_indices(29, K, seed=1)
+    cls = {"final": "MultiModalSurvivalNet", "partial": "PartialModalityNet", "simple": "SimpleFusionModel"}[style]
+    bstyle = "simple" if style == "simple" else "final"
+    def loaders(f):
+        return (data.BatchLoader(cohort, folds[f][0], B, shuffle=True, seed=10 + f, style=bstyle),
+                data.BatchLoader(cohort, folds[f][1], B, shuffle=False, style=bstyle))
+    base = []
+    for f in range(K):
+        torch.manual_seed(f)
+        base.append(getattr(HM, cls)(rna_dim=rna_dim))
+    kw = dict(lr=1e-4, weight_decay=1e-4, adamw=(style == "simple"))
+    # sequential: the reference's order
+    seq = []
+    for f in range(K):
+        m = copy.deepcopy(base[f]).to(DEV)
+        opt = T.FusedOptimizer(m, **kw)
+        tl, vl = loaders(f)
+        tr = getattr(T, "train_epoch_" + style)(m, tl, opt, DEV)
+        va = getattr(T, "validate_" + style)(m, vl, DEV)
+        seq.append((tr, va))
+    grp_models = [copy.deepcopy(b).to(DEV) for b in base]
+    ge = FoldGroupEngine(grp_models, **kw)
+    ls = [loaders(f) for f in range(K)]
+    tr = T.train_epoch_lockstep(ge, [l[0] for l in ls], style)
+    va = T.validate_lockstep(ge, [l[1] for l in ls], style, DEV)
+    for f in range(K):
+        a, b = np.atleast_1d(np.asarray(seq[f][0], dtype=float)), np.atleast_1d(np.asarray(tr[f], dtype=float))
+        assert np.allclose(a, b, rtol=2e-2, atol=2e-3), (f, a, b)        # one epoch of chaotic fp32 training: loose on the mean loss
+        assert abs(seq[f][1][0] - va[f][0]) <= 5e-2 * max(1.0, abs(seq[f][1][0])), (f, seq[f][1], va[f])
+        assert abs(seq[f][1][1] - va[f][1]) <= 0.15, (f, seq[f][1], va[f])   # C-index over <= 10 patients: one swapped pair = 0.02-0.1
