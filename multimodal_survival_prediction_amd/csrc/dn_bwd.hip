@@ -181,6 +181,17 @@ struct Conv3BwdWOp {
     int tap, mb, me, avoff[4], bvoff, tapoff_b, asoff, bsoff, k0s;
     unsigned sel;
     buf_rsrc_t ry, rz;
+    // XCD placement: the 27 tap workgroups of one (model, row chunk) pair read the same y1 / dz rows.  Dealt round-robin
+    // they land on all 8 XCDs and every L2 streams every chunk (measured: 12x the algorithmic bytes at the fabric);
+    // with the pairs partitioned over the XCDs (pair % 8) each L2 only sees its own chunks.  z = chunk * 27 + tap.
+    static __device__ void zremap(int flat, int zdim, int nflat, int& gi, int& z) {
+        const int pairs = nflat / 27, ms = zdim / 27;
+        if ((pairs & 7) == 0) {
+            const int x = flat & 7, slot = flat >> 3, pair = (slot / 27) * 8 + x;
+            gi = pair / ms;
+            z = (pair - gi * ms) * 27 + slot % 27;
+        } else { gi = flat / zdim; z = flat - gi * zdim; }
+    }
     __device__ void setup(const Params& p, int, int, int z, float* extra, int tid) {
         const int c0 = (tid & 31) * 4;
 #pragma unroll

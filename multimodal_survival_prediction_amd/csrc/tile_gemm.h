@@ -52,6 +52,12 @@ struct TileGemmCfg {
     static constexpr size_t smem_bytes() { return (main_floats() + Op::EXTRA) * sizeof(float); }
 };
 
+// Optional Op hook: static void zremap(int flat, int zdim, int nflat, int& gi, int& z) -- decodes blockIdx.z (flat over
+// models x zdim) itself, e.g. to keep the workgroups that share operand rows on one XCD (workgroups are dealt to the 8
+// XCDs round-robin by linear id).  Default: gi = flat / zdim, z = flat % zdim.
+template <class Op, class = void> struct has_zremap { static constexpr bool value = false; };
+template <class Op> struct has_zremap<Op, decltype((void)&Op::zremap)> { static constexpr bool value = true; };
+
 // Op::SPEC = true: wave-specialised variant, 512 threads.  Waves 0-3 ("consumers") only read LDS and issue MFMAs;
 // waves 4-7 ("producers") only run the loaders, transforms and LDS stores.  Each SIMD then hosts one consumer and
 // one producer wave, so the dependent-MFMA issue gaps (64 cycles each) are filled by the other wave's VALU/VMEM work
@@ -59,7 +65,9 @@ struct TileGemmCfg {
 // about a third of a one-wave-per-SIMD kernel's time, serialised.
 template <class Op>
 __global__ __launch_bounds__(Op::SPEC ? 512 : 256) void tile_gemm_kernel(const Grp<typename Op::Params> grp) {
-    const int gi = blockIdx.z / grp.zdim;                  // model of the fold group
+    int gi, z;                                             // model of the fold group, the op's own z index
+    if constexpr (has_zremap<Op>::value) Op::zremap((int)blockIdx.z, grp.zdim, (int)gridDim.z, gi, z);
+    else { gi = blockIdx.z / grp.zdim; z = blockIdx.z - gi * grp.zdim; }
     const typename Op::Params& p = grp.p[gi];
     constexpr int WM = Op::WM, WN = Op::WN, WK = Op::WK;
     static_assert(WM * WN * WK == 4, "4 waves per workgroup");
@@ -81,7 +89,7 @@ __global__ __launch_bounds__(Op::SPEC ? 512 : 256) void tile_gemm_kernel(const G
     // Placement only affects speed, never results.
     int bx = blockIdx.x;
     if ((gridDim.x & 7) == 0) bx = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const int m0 = bx * TM, n0 = blockIdx.y * TN, z = blockIdx.z - gi * grp.zdim;
+    const int m0 = bx * TM, n0 = blockIdx.y * TN;
 
     Op op;
     op.setup(p, m0, n0, z, extra, tid);
