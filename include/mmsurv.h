@@ -69,6 +69,11 @@ typedef struct Conv1FwdP {
     int pool;                       // 1: AvgPool3d(2,2) of relu(bn(x)) before the GEMM (== conv then pool)
     Dims3 in;                       // input grid (pool=1)
     int srep; int sstride;          // statistic-accumulator replicas written by this op: workgroup x adds to replica x % srep (stride in doubles)
+    /* optional split of the K (input-channel) loop over ksplit workgroups per 32x32 tile (small M: the loop is a chain of
+       dependent memory round trips).  Each publishes its partial tile in `partial` [ksplit][M][N] and takes a ticket in
+       `counters` [tiles]; the LAST one to arrive sums the partials in fixed order (deterministic), writes y and the
+       statistics -- no second launch.  counters must be zero on entry (the fixing workgroup re-arms them). */
+    float* partial; int ksplit; unsigned* counters;
 } Conv1FwdP;
 
 // ---- 3x3x3 conv, pad 1 (dense-layer conv2): slab[:, coff:coff+32] = conv3(relu(bn(y1)), W) ---------------

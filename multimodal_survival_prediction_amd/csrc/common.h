@@ -35,6 +35,28 @@ __device__ __forceinline__ double rep_sum(const double* a, int c, int nrep, int 
     return s;
 }
 
+// Split fixup without a second launch: every workgroup of an output tile publishes its partial, then takes a ticket; the
+// one that draws the last ticket returns true -- it may then read all partials of the tile -- and re-arms the counter for
+// the next launch.  No workgroup ever waits for another, so there is nothing to deadlock.
+// Cross-XCD visibility WITHOUT fences: a device-scope fence is a whole-L2 write-back + invalidate per workgroup (measured:
+// 1.5x slower step).  Instead the partials are written with agent-scope relaxed atomic stores (global_store ... sc1:
+// write-through to the memory side) and read back with agent-scope atomic loads (sc1: never served from this XCD's L2);
+// the only ordering needed is "my stores have been acknowledged before my ticket", i.e. s_waitcnt vmcnt(0) + the barrier.
+__device__ __forceinline__ void pstore(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float pload(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool tile_last_arriver(unsigned* counter, unsigned nsplit, int tid) {
+    __shared__ unsigned s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's partial stores are acknowledged
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = atomicAdd(counter, 1u);
+        s_last = (old == nsplit - 1u) ? 1u : 0u;
+        if (old == nsplit - 1u) atomicExch(counter, 0u);
+    }
+    __syncthreads();
+    return s_last != 0u;
+}
+
 // mean / rstd of channel c.  The batch variance is the biased one (what torch normalises with).
 __device__ __forceinline__ void bn_mean_rstd(const BnSrc& b, int c, float& mean, float& rstd) {
     if (b.train) {
@@ -53,6 +75,9 @@ __device__ __forceinline__ void bn_mean_rstd(const BnSrc& b, int c, float& mean,
 // dependent math so a workgroup pays ONE memory round trip for its constants instead of NJ serialized ones.
 template <int NJ>
 __device__ __forceinline__ void bn_consts_to_lds(const BnSrc& b, int C, int tid, float* o_mean, float* o_sc, float* o_beta) {
+#ifdef MMS_ABLATE_SETUP
+    return;
+#endif
     double s[NJ], q[NJ];
     float g[NJ], be[NJ], rm[NJ], rv[NJ];
 #pragma unroll

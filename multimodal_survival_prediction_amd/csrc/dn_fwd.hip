@@ -36,7 +36,7 @@ __device__ __forceinline__ void tile_col_stats(double* osum, double* osumsq, int
 // ------------------------------------------------------------------------------------------------------
 // 1x1x1 conv
 // ------------------------------------------------------------------------------------------------------
-template <int WM_, int WN_, int WK_, bool POOL>
+template <int WM_, int WN_, int WK_, bool POOL, bool KSPLIT = false>
 struct Conv1FwdOp {
     typedef Conv1FwdP Params;
     static constexpr int WM = WM_, WN = WN_, WK = WK_, AMODE = LD_K4, BMODE = LD_K4;
@@ -60,7 +60,12 @@ struct Conv1FwdOp {
             ((int*)extra)[3072 + tid] = base;
         }
     }
-    __device__ void krange(const Params& p, int, int& kb, int& ke) { kb = 0; ke = p.K; }
+    __device__ void krange(const Params& p, int z, int& kb, int& ke) {
+        if (KSPLIT) {
+            const int per = (((p.K + 127) / 128 + p.ksplit - 1) / p.ksplit) * 128;   // whole K-steps (TK = 128) per workgroup
+            kb = z * per; ke = kb + per < p.K ? kb + per : p.K;
+        } else { kb = 0; ke = p.K; }
+    }
     __device__ float4 act4(const float4 v, int k) const {
         float4 r;
         r.x = fmaxf(bn_apply(v.x, mean[k], sc[k], beta[k]), 0.f);
@@ -95,8 +100,27 @@ struct Conv1FwdOp {
         return ok ? *(const float4*)(p.w + (size_t)n * p.K + k) : make_float4(0, 0, 0, 0);
     }
     __device__ float4 b_tx(const Params&, int, const float4& v, int, int, bool) const { return v; }
-    __device__ void epilogue(const Params& p, int m0_, int n0, int, const float* Cs, int tid, bool active) {
+    __device__ void epilogue(const Params& p, int m0_, int n0, int z, const float* Cs, int tid, bool active) {
         if (!active) return;
+        if (KSPLIT) {        // publish the partial tile; the last-arriving workgroup of the tile sums them (fixed order)
+            for (int idx = tid; idx < TM * TN; idx += 256) {
+                const int r = idx / TN, c = idx % TN, m = m0_ + r, n = n0 + c;
+                if (m < p.M && n < p.N) pstore(&p.partial[((size_t)z * p.M + m) * p.N + n], Cs[r * (TN + 1) + c]);
+            }
+            if (!tile_last_arriver(p.counters + (m0_ / TM) * ((p.N + TN - 1) / TN) + n0 / TN, (unsigned)p.ksplit, tid)) return;
+            float* C = const_cast<float*>(Cs);
+            for (int idx = tid; idx < TM * TN; idx += 256) {
+                const int r = idx / TN, c = idx % TN, m = m0_ + r, n = n0 + c;
+                float v[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) v[t] = (t < p.ksplit && m < p.M && n < p.N) ? pload(&p.partial[((size_t)t * p.M + m) * p.N + n]) : 0.f;
+                float a = 0.f;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) a += v[t];
+                C[r * (TN + 1) + c] = a;
+            }
+            __syncthreads();
+        }
         store_tile<TM, TN>(p.y, p.ldy, p.M, p.N, m0_, n0, Cs, tid);
         tile_col_stats<TM, TN>(stat_rep(p.osum, p.srep, p.sstride), stat_rep(p.osumsq, p.srep, p.sstride), p.M, p.N, m0_, n0, Cs, tid);
     }
@@ -120,6 +144,12 @@ extern "C" int mms_conv1_fwd_group(const Conv1FwdP* pp, int ng, hipStream_t s) {
                       : launch_tile_gemm<Conv1FwdOp<2, 2, 1, false>>(pp, ng, g, s);
     }
     dim3 g((p.M + 31) / 32, (p.N + 31) / 32, 1);
+    if (p.partial && p.counters && p.ksplit > 1 && !p.pool) {
+        if (p.ksplit > 8 || (long)(p.ksplit - 1) * ((((p.K + 127) / 128 + p.ksplit - 1) / p.ksplit) * 128) >= p.K) return MMS_ERR_ARG;   // every slice owns >= 1 channel
+        for (int i = 1; i < ng; ++i) if (pp[i].ksplit != p.ksplit || !pp[i].partial || !pp[i].counters) return MMS_ERR_ARG;
+        g.z = p.ksplit;
+        return launch_tile_gemm<Conv1FwdOp<1, 1, 4, false, true>>(pp, ng, g, s);
+    }
     return p.pool ? launch_tile_gemm<Conv1FwdOp<1, 1, 4, true>>(pp, ng, g, s)
                   : launch_tile_gemm<Conv1FwdOp<1, 1, 4, false>>(pp, ng, g, s);
 }
@@ -207,7 +237,8 @@ struct Conv3FwdOp {
     __device__ float4 b_tx(const Params&, int, const float4& v, int, int, bool) const { return v; }
     __device__ void epilogue(const Params& p, int m0_, int n0, int z, const float* Cs, int tid, bool active) {
         if (!active) return;
-        if (SPLIT) {
+        if (SPLIT) {      // (a last-arriver fixup as in Conv1FwdOp was measured here too: slower than the reduce launch -- one
+                          // workgroup reading up to 27 partial tiles is a longer serial tail than the launch it saves)
             store_tile<TM, TN>(p.partial + (size_t)z * p.M * 32, 32, p.M, 32, m0_, n0, Cs, tid);
             return;
         }

@@ -36,6 +36,7 @@ struct Plan {
     // fp64 statistic accumulators (one contiguous region, zeroed once per step)
     size_t stats_begin, stats_end;
     size_t st_y0, st_slab[NB], st_y1[NLAYER];          // forward (sum | sumsq), each 2*C doubles
+    size_t counters;                                   // split-fixup tickets (zeroed at init, re-armed by their users)
     size_t bb_y0, bb_y1[NLAYER], bb_in[NLAYER], bb_tr[3];   // backward (s1 | s2)
     size_t total;
 };
@@ -94,6 +95,7 @@ bool make_plan(Plan& P, int B, int D, int H, int W) {
     for (int i = 0; i < NLAYER; ++i) P.bb_in[i] = take((size_t)P.R[blk_of[i]] * 2 * 1024 * 8);
     for (int i = 0; i < 3; ++i) P.bb_tr[i] = take((size_t)P.R[i] * 2 * 1024 * 8);
     P.stats_end = o;
+    P.counters = take(4096 * 4);
     P.total = o;
     return true;
 }
@@ -207,6 +209,7 @@ extern "C" int mms_dn121_init(void* ws, int B, int D, int H, int W, const void* 
         if (b < 3) set_bn(IDX.bn_trans[b], P.st_slab[b], CTOT[b], CTOT[b], P.M[b], P.R[b]);
         else set_bn(IDX.bn5, P.st_slab[b], CTOT[b], CTOT[b], P.M[b], P.R[b]);
     }
+    if (hipMemsetAsync(at<void>(ws, P.counters), 0, 4096 * 4, s) != hipSuccess) return MMS_ERR_LAUNCH;
     hipError_t e1 = hipMemcpyAsync(at<void>(ws, P.tab_pack), pk, sizeof(pk), hipMemcpyHostToDevice, s);
     hipError_t e2 = hipMemcpyAsync(at<void>(ws, P.tab_bn), bn, sizeof(bn), hipMemcpyHostToDevice, s);
     hipError_t e3 = hipStreamSynchronize(s);   // pk/bn are stack arrays
@@ -235,6 +238,9 @@ static int conv3_nsplit(int M, int ng, long cap_rows) {
     while (tpw < 27 && (long)((27 + tpw - 1) / tpw) * M > cap_rows) ++tpw;   // the partials must fit the scratch
     return (27 + tpw - 1) / tpw;                                         // every workgroup owns >= 1 tap
 }
+
+// MMS_CONV1_KSPLIT=0: never split the conv1 K loop over workgroups (A/B tests; group-vs-single parity tests)
+static bool conv1_ksplit_on() { const char* e = getenv("MMS_CONV1_KSPLIT"); return !(e && e[0] == '0'); }
 
 // One model of a fold group as the drivers see it.
 struct Ctx {
@@ -283,6 +289,10 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
             Conv1FwdP c1[MMS_MAX_GROUP];
             Conv3FwdP c3[MMS_MAX_GROUP];
             const int ns3 = conv3_nsplit(P.M[b], ng, P.partial_rows);
+            // conv1 at small M is a chain of dependent K-steps on a handful of workgroups: one K-step per workgroup instead
+            int ks1 = 1;
+            if (conv1_ksplit_on() && (long)((P.M[b] + 31) / 32) * 4 * ng <= 128 && C >= 256 && (long)((C + 127) / 128) * P.M[b] <= P.partial_rows)
+                ks1 = (C + 127) / 128;
             FOR_G {
                 const Ctx& c = cx[g];
                 float* slab = at<float>(c.ws, P.slab[b]);
@@ -290,6 +300,7 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
                                   mk_bn(c.ws, P.st_slab[b], CTOT[b], c.prm, ip, c.buf, IDX.bn_layer1[l], P.M[b], train, P.R[b]),
                                   st(c.ws, P.st_y1[l], 128, 0, false), st(c.ws, P.st_y1[l], 128, 0, true), 0, Dims3{0, 0, 0}};
                 c1[g].srep = P.R[b]; c1[g].sstride = 2 * 128;
+                if (ks1 > 1) { c1[g].partial = at<float>(c.ws, P.partial); c1[g].ksplit = ks1; c1[g].counters = at<unsigned>(c.ws, P.counters); }
                 c3[g] = Conv3FwdP{at<float>(c.ws, P.y1[l]), at<int>(c.ws, P.coords[b]), P.g[b], P.M[b], at<float>(c.ws, P.wpf[l]),
                                   slab + C, CTOT[b], mk_bn(c.ws, P.st_y1[l], 128, c.prm, ip + 3, c.buf, IDX.bn_layer2[l], P.M[b], train, P.R[b]),
                                   st(c.ws, P.st_slab[b], CTOT[b], C, false), st(c.ws, P.st_slab[b], CTOT[b], C, true),

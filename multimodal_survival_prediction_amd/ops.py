@@ -40,10 +40,12 @@ def init_coords(B, dims, device):
     return out
 
 
-def conv1_fwd(x, K, w, y, bn, M, osum=None, osumsq=None, pool=False, in_dims=(0, 0, 0)):
-    """x: [Min, ldx] slab (first K columns); w: [N, K]; y: [M, ldy] view (column offset applied by slicing)."""
+def conv1_fwd(x, K, w, y, bn, M, osum=None, osumsq=None, pool=False, in_dims=(0, 0, 0), partial=None, ksplit=0,
+              counters=None):
+    """x: [Min, ldx] slab (first K columns); w: [N, K]; y: [M, ldy] view (column offset applied by slicing).
+    partial/ksplit/counters: split the K loop over workgroups with a last-arriver fixup (Conv1FwdP in mmsurv.h)."""
     p = _S()["Conv1FwdP"](ptr(x), x.stride(0), M, K, ptr(w), w.shape[0], ptr(y), y.stride(0), bn,
-                          ptr(osum), ptr(osumsq), 1 if pool else 0, dims3(in_dims))
+                          ptr(osum), ptr(osumsq), 1 if pool else 0, dims3(in_dims), 0, 0, ptr(partial), ksplit, ptr(counters))
     call("mms_conv1_fwd", p)
 
 

@@ -48,6 +48,32 @@ def test_conv1_fwd(ops, B, dims, K, N, ld, train):
         assert_close(oq, (cl(ref).double() ** 2).sum(0), 1e-4, "conv1 sumsq")
 
 
+@pytest.mark.parametrize("M,K,ksplit", [(128, 640, 5), (16, 992, 8), (100, 288, 3), (128, 256, 2)])
+def test_conv1_fwd_ksplit(ops, M, K, ksplit):
+    """K loop split over workgroups + last-arriver fixup (no second launch): same y and statistics as the unsplit kernel;
+    repeated launches reuse the self-re-arming ticket counters."""
+    torch.manual_seed(3)
+    N, ld = 128, 1024
+    slab = torch.randn(M, ld, device=DEV) * 1.5 + 0.3
+    g, b = torch.rand(K, device=DEV) + 0.5, torch.randn(K, device=DEV) * 0.1
+    w = torch.randn(N, K, device=DEV) / K ** 0.5
+    s, q = slab[:, :K].double().sum(0).contiguous(), (slab[:, :K].double() ** 2).sum(0).contiguous()
+    bn = ops.bnsrc(g, b, M, True, s, q)
+    y0 = torch.zeros(M, N, device=DEV); s0, q0 = stats(DEV, N)
+    ops.conv1_fwd(slab, K, w, y0, bn, M, s0, q0)
+    partial = torch.full((ksplit * M * N,), float("nan"), device=DEV)
+    counters = torch.zeros(64, dtype=torch.int32, device=DEV)
+    for rep in range(3):
+        y1 = torch.zeros(M, N, device=DEV); s1, q1 = stats(DEV, N)
+        ops.conv1_fwd(slab, K, w, y1, bn, M, s1, q1, partial=partial, ksplit=ksplit, counters=counters)
+        torch.cuda.synchronize()
+        assert int(counters.abs().sum()) == 0                    # re-armed
+        assert_close(y1, y0, 2e-6, "ksplit y")
+        assert_close(s1, s0, 1e-6, "ksplit sum"); assert_close(q1, q0, 1e-6, "ksplit sumsq")
+    a = torch.relu((slab[:, :K].double() - (s / M)) / torch.sqrt(q / M - (s / M) ** 2 + 1e-5) * g.double() + b.double())
+    assert_close(y1, a @ w.double().t(), 1e-4, "ksplit y vs fp64 reference")
+
+
 @pytest.mark.parametrize("B,dims,K", [(4, (16, 16, 8), 256), (2, (8, 8, 4), 512), (4, (4, 4, 2), 1024)])
 def test_transition_fwd(ops, B, dims, K):
     torch.manual_seed(1)

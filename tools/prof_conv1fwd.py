@@ -1,0 +1,35 @@
+"""Microbench of conv1 forward (BN+ReLU prologue, 1x1x1 conv, stats epilogue) at a DenseNet block shape for a group of G."""
+import sys, os, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multimodal_survival_prediction_amd import ops, _lib
+dev = "cuda:0"
+blk = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 640
+G = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+reps = 30
+B, (D, H, W) = 4, (64, 64, 32)
+gd = (D // 4 >> blk, H // 4 >> blk, W // 4 >> blk)
+M = B * gd[0] * gd[1] * gd[2]
+CT = (256, 512, 1024, 1024)[blk]
+lib, S = _lib.load_library(), _lib.structs()
+keep, blocks = [], []
+for g in range(G):
+    slab = torch.randn(M, CT, device=dev)
+    w = torch.randn(128, K, device=dev) * 0.05
+    y1 = torch.zeros(M, 128, device=dev)
+    s, q = slab.double().sum(0), (slab.double() ** 2).sum(0)
+    bn = ops.bnsrc(torch.ones(CT, device=dev), torch.zeros(CT, device=dev), M, True, s, q)
+    os_, oq = torch.zeros(128, dtype=torch.float64, device=dev), torch.zeros(128, dtype=torch.float64, device=dev)
+    keep.append((slab, w, y1, s, q, os_, oq))
+    p = S["Conv1FwdP"](slab.data_ptr(), CT, M, K, w.data_ptr(), 128, y1.data_ptr(), 128, bn, os_.data_ptr(), oq.data_ptr(), 0, ops.dims3((0, 0, 0)))
+    blocks.append(p)
+arr = (S["Conv1FwdP"] * G)(*blocks)
+def launch():
+    _lib.check(lib.mms_conv1_fwd_group(arr, G, ops.stream()), "conv1_fwd_group")
+for _ in range(5): launch()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(reps): launch()
+e1.record(); torch.cuda.synchronize()
+print(f"block {blk + 1} M={M} K={K} G={G}: conv1 fwd avg {e0.elapsed_time(e1) * 1e3 / reps:.1f} us")
