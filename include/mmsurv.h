@@ -428,6 +428,7 @@ int mms_conv0_bwd_weight_group(const Conv0BwdWP* p, int ng, hipStream_t s);
 int mms_pack_conv3_table_group(const void* const* tables_dev, int ng, int nlayers, hipStream_t s);
 int mms_bn_running_update_group(const void* const* tables_dev, int ng, int n, float momentum, hipStream_t s);
 int mms_gather_rows_group(const GatherP* p, int ng, hipStream_t s);
+int mms_unpack_conv3_grads_group(const float* const* scratch, float* const* const* dw, int ng, int nlayers, hipStream_t s);  /* scratch[g]: model g's [nlayers][27][32][128] tap-major scratch; dw[g][i]: canonical gradient of layer i; nlayers <= 58 */
 int mms_zero_regions_group(void* const* regions_dev, int ng, size_t bytes, hipStream_t s);   /* 16-B aligned regions of equal size, zero-filled by one launch */
 int mms_linear_fwd_group(const LinearFwdP* p, int ng, hipStream_t s);
 int mms_linear_bwd_group(const LinearBwdP* p, int ng, hipStream_t s);

@@ -267,6 +267,35 @@ __global__ __launch_bounds__(256) void unpack_conv3_grads_kernel(const UnpackTab
         dst[idx] += t[tap * 129 + cin];
     }
 }
+// fold-group form: the scratch of layer i of model g is scratch[g] + i * 27*32*128 (how the driver lays it out), so a table
+// entry is just the destination pointer: 8 models x 58 layers x 8 B = 3.7 KB of kernarg, one launch for the group
+struct UnpackGroup { const float* scratch[MMS_MAX_GROUP]; float* dw[MMS_MAX_GROUP][58]; };
+__global__ __launch_bounds__(256) void unpack_conv3_grads_group_kernel(const UnpackGroup tab) {
+    __shared__ float t[27 * 129];
+    const int co = blockIdx.x, layer = blockIdx.y, g = blockIdx.z;
+    const float* scratch = tab.scratch[g] + (size_t)layer * 27 * 32 * 128;
+    for (int idx = threadIdx.x; idx < 27 * 128; idx += 256) {
+        const int tap = idx >> 7, cin = idx & 127;
+        t[tap * 129 + cin] = scratch[((size_t)tap * 32 + co) * 128 + cin];
+    }
+    __syncthreads();
+    float* dst = tab.dw[g][layer] + (size_t)co * 128 * 27;
+    for (int idx = threadIdx.x; idx < 27 * 128; idx += 256) {
+        const int cin = idx / 27, tap = idx % 27;
+        dst[idx] += t[tap * 129 + cin];
+    }
+}
+extern "C" int mms_unpack_conv3_grads_group(const float* const* scratch, float* const* const* dw, int ng, int nlayers, hipStream_t s) {
+    if (nlayers <= 0) return MMS_OK;
+    if (!scratch || !dw || ng < 1 || ng > MMS_MAX_GROUP || nlayers > 58) return MMS_ERR_ARG;
+    UnpackGroup t;
+    for (int g = 0; g < ng; ++g) {
+        t.scratch[g] = scratch[g];
+        for (int i = 0; i < nlayers; ++i) t.dw[g][i] = dw[g][i];
+    }
+    MMS_LAUNCH(unpack_conv3_grads_group_kernel, dim3(32, nlayers, ng), dim3(256), 0, s, t);
+    return mms_check_launch();
+}
 extern "C" int mms_unpack_conv3_grads(const void* table_host, int nlayers, hipStream_t s) {
     if (nlayers <= 0) return MMS_OK;
     if (nlayers > 64) return MMS_ERR_ARG;
@@ -708,6 +737,66 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const Grp<PoolBwdP> grp) 
         atomicAdd(&stat_rep(p.s2, p.srep, p.sstride)[c], red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
     }
 }
+// Brick form (default when the conv0 grid is a multiple of 2 x 4 x WT): a workgroup owns a 2 x 4 x WT brick of conv0-grid
+// voxels; the <= 2 x 3 x (WT/2+1) pooled voxels whose windows can reach it are staged in LDS once (argmax byte + gradient,
+// coalesced 64-channel rows), so a voxel's 8 candidates cost 16 LDS reads instead of 16 global loads (8 of them 1-byte).
+template <int WT>
+__global__ __launch_bounds__(256) void pool_bwd_brick_kernel(const Grp<PoolBwdP> grp) {
+    const PoolBwdP& p = grp.p[blockIdx.z];
+    constexpr int WO = WT / 2 + 1, NC = 2 * 3 * WO;
+    __shared__ float cg[NC][64];
+    __shared__ uint8_t ca[NC][64];
+    __shared__ double red[2][4][64];
+    const int c = threadIdx.x & 63, vr = threadIdx.x >> 6;
+    const int Di = p.in.D, Hi = p.in.H, Wi = p.in.W, Do = p.out.D, Ho = p.out.H, Wo = p.out.W;
+    const int nwt = Wi / WT, nhb = Hi / 4, ndb = Di / 2;
+    int r = blockIdx.x;
+    const int wt = r % nwt; r /= nwt;
+    const int hb = r % nhb; r /= nhb;
+    const int db = r % ndb, b = r / ndb;
+    const int w0 = wt * WT, ow0 = w0 >> 1;
+    for (int cand = vr; cand < NC; cand += 4) {
+        const int dd = cand / (3 * WO), hh = (cand / WO) % 3, ww = cand % WO;
+        const int od = db + dd, oh = 2 * hb + hh, ow = ow0 + ww;
+        const bool ok = od < Do && oh < Ho && ow < Wo;
+        const size_t mo = ok ? ((size_t)(b * Do + od) * Ho + oh) * Wo + ow : 0;
+        cg[cand][c] = ok ? p.dslab[mo * p.ld + c] : 0.f;
+        ca[cand][c] = ok ? p.argmax[mo * 64 + c] : (uint8_t)255;
+    }
+    float mu, rs;
+    bn_mean_rstd(p.bn, c, mu, rs);
+    const float ga = p.bn.gamma[c], be = p.bn.beta[c];
+    __syncthreads();
+    double s1 = 0, s2 = 0;
+    for (int v = vr; v < 8 * WT; v += 4) {
+        const int di = v / (4 * WT), hi = (v / WT) & 3, wi = v % WT;
+        const int id = 2 * db + di, ih = 4 * hb + hi, iw = w0 + wi;
+        const size_t m = ((size_t)(b * Di + id) * Hi + ih) * Wi + iw;
+        const float y = p.y0[m * 64 + c];
+        float g = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int kd = k >> 2, kh = (k >> 1) & 1, kw = k & 1;
+            const int dd = (di + kd) >> 1, hh = (hi + kh) >> 1, ww = (wi + kw) >> 1;
+            const int od = db + dd, oh = 2 * hb + hh, ow = ow0 + ww;
+            const bool ok = (kd == 0 || (id & 1)) && (kh == 0 || (ih & 1)) && (kw == 0 || (iw & 1));
+            const int tap = ((id - 2 * od + 1) * 3 + (ih - 2 * oh + 1)) * 3 + (iw - 2 * ow + 1);
+            const int cand = (dd * 3 + hh) * WO + ww;
+            g += (ok && ca[cand][c] == tap) ? cg[cand][c] : 0.f;
+        }
+        const float xh = (y - mu) * rs;
+        g = fmaf(ga, xh, be) > 0.f ? g : 0.f;
+        p.dbn[m * 64 + c] = g;
+        s1 += g; s2 += (double)g * xh;
+    }
+    red[0][vr][c] = s1; red[1][vr][c] = s2;
+    __syncthreads();
+    if (vr == 0) {
+        atomicAdd(&stat_rep(p.s1, p.srep, p.sstride)[c], red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+        atomicAdd(&stat_rep(p.s2, p.srep, p.sstride)[c], red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    }
+}
+
 extern "C" int mms_pool_bwd_group(const PoolBwdP* pp, int ng, hipStream_t s) {
     Grp<PoolBwdP> a;
     if (!grp_fill(a, pp, ng, 1)) return MMS_ERR_ARG;
@@ -718,6 +807,14 @@ extern "C" int mms_pool_bwd_group(const PoolBwdP* pp, int ng, hipStream_t s) {
         const PoolBwdP& q = pp[g];
         if (q.B != p.B || q.in.D != p.in.D || q.in.H != p.in.H || q.in.W != p.in.W || q.out.D != p.out.D || q.out.H != p.out.H ||
             q.out.W != p.out.W) return MMS_ERR_ARG;
+    }
+    if (p.in.D % 2 == 0 && p.in.H % 4 == 0 && p.in.W % 16 == 0) {
+        if (p.in.W % 32 == 0) {
+            MMS_LAUNCH(pool_bwd_brick_kernel<32>, dim3(p.B * (p.in.D / 2) * (p.in.H / 4) * (p.in.W / 32), 1, ng), dim3(256), 0, s, a);
+        } else {
+            MMS_LAUNCH(pool_bwd_brick_kernel<16>, dim3(p.B * (p.in.D / 2) * (p.in.H / 4) * (p.in.W / 16), 1, ng), dim3(256), 0, s, a);
+        }
+        return mms_check_launch();
     }
     MMS_LAUNCH(pool_bwd_kernel, dim3((Min + 63) / 64, 1, ng), dim3(256), 0, s, a);
     return mms_check_launch();

@@ -138,6 +138,7 @@ inline BnSrc mk_bn(void* ws, size_t st_off, int Ctot_, const float* const* prm, 
 extern "C" int mms_init_coords(int*, int, int, int, int, hipStream_t);
 extern "C" int mms_pack_conv3_table_group(const void* const*, int, int, hipStream_t);
 extern "C" int mms_unpack_conv3_grads(const void*, int, hipStream_t);
+extern "C" int mms_unpack_conv3_grads_group(const float* const*, float* const* const*, int, int, hipStream_t);
 extern "C" int mms_bn_running_update_group(const void* const*, int, int, float, hipStream_t);
 extern "C" int mms_zero_regions_group(void* const*, int, size_t, hipStream_t);
 extern "C" int mms_conv0_fwd_group(const Conv0FwdP*, int, hipStream_t);
@@ -471,10 +472,18 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
     if (side && side_pending) {
         if (hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) return MMS_ERR_LAUNCH;
     }
-    FOR_G {
-        UnpackEntry up[NLAYER];
-        for (int i = 0; i < NLAYER; ++i) { up[i].scratch = at<float>(cx[g].ws, P.dwp[i]); up[i].dw = cx[g].grd[IDX.layer[i] + 5]; }
-        TRY(mms_unpack_conv3_grads(up, NLAYER, s));
+    {   // tap-major scratch -> canonical conv2 gradients, one launch for the group (the dwp regions are consecutive takes)
+        static_assert(NLAYER == 58, "UnpackGroup is sized for DenseNet121");
+        const float* scr[MMS_MAX_GROUP];
+        float* dwt[MMS_MAX_GROUP][NLAYER];
+        float* const* dwp_[MMS_MAX_GROUP];
+        if (P.dwp[1] - P.dwp[0] != (size_t)27 * 32 * 128 * 4) return MMS_ERR_ARG;
+        FOR_G {
+            scr[g] = at<float>(cx[g].ws, P.dwp[0]);
+            for (int i = 0; i < NLAYER; ++i) dwt[g][i] = cx[g].grd[IDX.layer[i] + 5];
+            dwp_[g] = dwt[g];
+        }
+        TRY(mms_unpack_conv3_grads_group(scr, dwp_, ng, NLAYER, s));
     }
     return MMS_OK;
 }

@@ -473,11 +473,21 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(const Grp<AdamP> grp) {
     const AdamP& p = grp.p[blockIdx.z];
     __shared__ double red[4];
     const long long n4 = p.n >> 2, stride = (long long)gridDim.x * 256;
-    float a = 0.f;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    float a = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {          // 4 independent 16-B loads in flight per thread
+        const float4 g0 = ((const float4*)p.g)[i], g1 = ((const float4*)p.g)[i + stride], g2 = ((const float4*)p.g)[i + 2 * stride],
+                     g3 = ((const float4*)p.g)[i + 3 * stride];
+        a = fmaf(g0.x, g0.x, a); a = fmaf(g0.y, g0.y, a); a = fmaf(g0.z, g0.z, a); a = fmaf(g0.w, g0.w, a);
+        a1 = fmaf(g1.x, g1.x, a1); a1 = fmaf(g1.y, g1.y, a1); a1 = fmaf(g1.z, g1.z, a1); a1 = fmaf(g1.w, g1.w, a1);
+        a2 = fmaf(g2.x, g2.x, a2); a2 = fmaf(g2.y, g2.y, a2); a2 = fmaf(g2.z, g2.z, a2); a2 = fmaf(g2.w, g2.w, a2);
+        a3 = fmaf(g3.x, g3.x, a3); a3 = fmaf(g3.y, g3.y, a3); a3 = fmaf(g3.z, g3.z, a3); a3 = fmaf(g3.w, g3.w, a3);
+    }
+    for (; i < n4; i += stride) {
         const float4 g = ((const float4*)p.g)[i];
         a = fmaf(g.x, g.x, a); a = fmaf(g.y, g.y, a); a = fmaf(g.z, g.z, a); a = fmaf(g.w, g.w, a);
     }
+    a += a1 + a2 + a3;
     if (blockIdx.x == 0 && threadIdx.x < (p.n & 3)) { const float g = p.g[(n4 << 2) + threadIdx.x]; a = fmaf(g, g, a); }
     const double t = block_sum_d((double)a, red);
     if (threadIdx.x == 0) {
@@ -531,8 +541,8 @@ static bool adam_group(Grp<AdamP>& a, const AdamP* pp, int ng) {
 extern "C" int mms_grad_sumsq_group(const AdamP* pp, int ng, hipStream_t s) {
     Grp<AdamP> a;
     if (!adam_group(a, pp, ng)) return MMS_ERR_ARG;
-    long long blocks = (pp->n / 4 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    long long blocks = (pp->n / 16 + 255) / 256;          // 4 float4 per thread and trip
+    if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     MMS_LAUNCH(grad_sumsq_kernel, dim3((unsigned)blocks, 1, ng), dim3(256), 0, s, a);
     return mms_check_launch();
