@@ -3,6 +3,7 @@
 // final_multimodal.py:66-71, partial_modality_training.py:171-176, simple_fusion.py:182-187.
 #include "dn_ops.h"
 #include "tile_gemm.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------------
 // shared epilogue pieces
@@ -350,6 +351,123 @@ struct Conv0FwdOp {
     }
 };
 
+// ------------------------------------------------------------------------------------------------------
+// conv0, LDS-staged form (default; the tile-GEMM op above remains for grids that are not a multiple of 4x4x4).
+// The GEMM form gathers x[patch(m, tap)] with one predicated scalar load per (voxel, tap).  Here a workgroup walks boxes
+// of 4x4x4 output voxels: the box's 13^3 input region is staged in LDS once (double-buffered) and the A operand of every
+// MFMA is read straight from it -- A[voxel][tap] = region[moff(voxel) + koff(tap)], one ds_read_b32, no im2col image.
+// The 343 x 32 weight slice of a wave's channel tile lives in 172 VGPRs for the whole launch (B operand, loaded once per
+// model), so the steady state is: 9 global loads per thread and box, then 172 MFMAs per wave fed by LDS only.
+// 4 waves = 2 voxel tiles (d-slices {0,1} / {2,3} of the box) x 2 channel tiles.  Boxes of all models are pooled over
+// gridDim.x workgroups (grp.zdim = number of models) as in conv0_bwd_weight_kernel.
+// ------------------------------------------------------------------------------------------------------
+#define C0F_REG (13 * 13 * 13)      // 2197
+__host__ __device__ constexpr int c0f_koff(int tap) { return (tap / 49) * 169 + ((tap / 7) % 7) * 13 + tap % 7; }
+__global__ __launch_bounds__(256) void conv0_fwd_box_kernel(const Grp<Conv0FwdP> grp) {
+    __shared__ float xs[2][C0F_REG + 3];
+    __shared__ float Cs[4][32 * 33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kq = lane >> 5;
+    const int vt = wave >> 1, ct = wave & 1;                       // voxel tile, channel tile
+    const int D0 = grp.p[0].out.D, H0 = grp.p[0].out.H, W0 = grp.p[0].out.W, Di = grp.p[0].in.D, Hi = grp.p[0].in.H, Wi = grp.p[0].in.W;
+    const int bh = H0 >> 2, bw = W0 >> 2, bps = (D0 >> 2) * bh * bw;
+    const int nbox = (grp.p[0].M / (D0 * H0 * W0)) * bps;
+    const int total = nbox * grp.zdim;
+    const int per = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int g0 = blockIdx.x * per, g1 = g0 + per < total ? g0 + per : total;
+    const int dl = 2 * vt + (li >> 4), hl = (li >> 2) & 3, wl = li & 3;
+    const int moff = dl * 2 * 169 + hl * 2 * 13 + wl * 2;
+    float* cs = Cs[wave];
+    __syncthreads();
+
+    for (int gs = g0; gs < g1;) {
+        const int model = gs / nbox, seg_end = (model + 1) * nbox < g1 ? (model + 1) * nbox : g1;
+        const int b0 = gs - model * nbox, b1 = seg_end - model * nbox;
+        gs = seg_end;
+        const Conv0FwdP& p = grp.p[model];
+        float breg[172];                                       // W[32*ct + li][2s + kq], s = 0..171 (tap 343 = padding)
+        {
+            const float* wrow = p.w + (size_t)(32 * ct + li) * 343;
+#pragma unroll
+            for (int s = 0; s < 172; ++s) breg[s] = (2 * s + kq < 343) ? wrow[2 * s + kq] : 0.f;
+        }
+        double ssum = 0, ssq = 0;
+        float xr[9];
+        auto gload = [&](int bx) {
+            const int b = bx / bps, r = bx - b * bps, bz = r / (bh * bw), r2 = r - bz * (bh * bw), by = r2 / bw, bxw = r2 - by * bw;
+            const int id0 = 8 * bz - 3, ih0 = 8 * by - 3, iw0 = 8 * bxw - 3;
+            const float* xb = p.x + (size_t)b * Di * Hi * Wi;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const int e = tid + 256 * i, rd = e / 169, e2 = e - rd * 169, rh = e2 / 13, rw = e2 - rh * 13;
+                const int id = id0 + rd, ih = ih0 + rh, iw = iw0 + rw;
+                const bool ok = e < C0F_REG && (unsigned)id < (unsigned)Di && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi;
+                xr[i] = ok ? xb[((size_t)id * Hi + ih) * Wi + iw] : 0.f;
+            }
+        };
+        auto sstore = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) { const int e = tid + 256 * i; if (e < C0F_REG) xs[buf][e] = xr[i]; }
+        };
+        __syncthreads();                                       // previous segment done with xs
+        gload(b0);
+        sstore(0);
+        __syncthreads();
+        int buf = 0;
+        for (int bx = b0; bx < b1; ++bx) {
+            const bool more = bx + 1 < b1;
+            if (more) gload(bx + 1);
+            // tap offsets are compile-time constants of the unrolled step: the two lane halves differ by koff(2s+1) - koff(2s)
+            // (1, 7 or 85), so the address is one of three per-lane bases plus an immediate -- no index arithmetic per MFMA.
+            // Two accumulators alternate so that consecutive MFMAs do not wait on each other's result.
+            const float* xb = xs[buf] + moff;
+            f32x16 acc, acc2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 172; s += 2) {
+                constexpr int dummy = 0; (void)dummy;
+                const int k0 = c0f_koff(2 * s), k1 = c0f_koff(2 * s + 1 < 343 ? 2 * s + 1 : 342);
+                const int k2 = c0f_koff(2 * s + 2), k3 = c0f_koff(2 * s + 3 < 343 ? 2 * s + 3 : 342);
+                const float a = xb[k0 + kq * (k1 - k0)];
+                const float a2 = xb[k2 + kq * (k3 - k2)];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, breg[s], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, breg[s + 1], acc2, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+            // statistics (channel 32*ct + li, this lane's 16 voxel rows) and the store through a per-wave LDS transpose
+            float fs = 0.f, fq = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { fs += acc[r]; fq = fmaf(acc[r], acc[r], fq); }
+            ssum += fs; ssq += fq;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * kq) * 33 + li] = acc[r];
+            __builtin_amdgcn_wave_barrier();
+            {
+                const int b = bx / bps, r = bx - b * bps, bz = r / (bh * bw), r2 = r - bz * (bh * bw), by = r2 / bw, bxw = r2 - by * bw;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int v = 2 * i + kq;                  // voxel of this wave's tile
+                    const int od = 4 * bz + 2 * vt + (v >> 4), oh = 4 * by + ((v >> 2) & 3), ow = 4 * bxw + (v & 3);
+                    const size_t m = ((size_t)(b * D0 + od) * H0 + oh) * W0 + ow;
+                    p.y[m * 64 + 32 * ct + li] = cs[v * 33 + li];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (more) sstore(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+        if (p.osum) {
+            ssum += __shfl_xor(ssum, 32, 64); ssq += __shfl_xor(ssq, 32, 64);
+            if (kq == 0) {
+                atomicAdd(&stat_rep(p.osum, p.srep, p.sstride)[32 * ct + li], ssum);
+                atomicAdd(&stat_rep(p.osumsq, p.srep, p.sstride)[32 * ct + li], ssq);
+            }
+        }
+    }
+}
+
 extern "C" int mms_conv0_fwd_group(const Conv0FwdP* pp, int ng, hipStream_t s) {
     if (!pp || ng < 1 || ng > MMS_MAX_GROUP) return MMS_ERR_ARG;
     const Conv0FwdP& p = *pp;
@@ -357,9 +475,20 @@ extern "C" int mms_conv0_fwd_group(const Conv0FwdP* pp, int ng, hipStream_t s) {
     for (int g = 1; g < ng; ++g) {
         const Conv0FwdP& q = pp[g];
         if (q.M != p.M || q.in.D != p.in.D || q.in.H != p.in.H || q.in.W != p.in.W || q.out.D != p.out.D || q.out.H != p.out.H ||
-            q.out.W != p.out.W) return MMS_ERR_ARG;
+            q.out.W != p.out.W || (q.osum == nullptr) != (p.osum == nullptr)) return MMS_ERR_ARG;
     }
-    return launch_tile_gemm<Conv0FwdOp>(pp, ng, dim3((p.M + 63) / 64, 1, 1), s);
+    const long vox = (long)p.out.D * p.out.H * p.out.W;
+    const bool boxed = (p.out.D % 4 == 0) && (p.out.H % 4 == 0) && (p.out.W % 4 == 0) && vox > 0 && p.M % vox == 0 &&
+                       p.in.D == 2 * p.out.D && p.in.H == 2 * p.out.H && p.in.W == 2 * p.out.W;
+    if (!boxed) return launch_tile_gemm<Conv0FwdOp>(pp, ng, dim3((p.M + 63) / 64, 1, 1), s);
+    Grp<Conv0FwdP> a;
+    grp_fill(a, pp, ng, ng);
+    const long boxes = (long)ng * (p.M / 64);
+    const char* e_ = getenv("MMS_C0F_NWG");
+    int nwg = e_ ? atoi(e_) : (boxes >= 512L * 4 ? 512 : (boxes >= 256L * 2 ? 256 : (int)boxes));
+    if (nwg < 1) nwg = 1;
+    MMS_LAUNCH(conv0_fwd_box_kernel, dim3(nwg, 1, 1), dim3(256), 0, s, a);
+    return mms_check_launch();
 }
 MMS_SINGLE(mms_conv0_fwd, Conv0FwdP)
 

