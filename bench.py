@@ -7,11 +7,14 @@ clip_grad_norm_(1.0).  A "step" is one pass of the hot path over one batch of 4 
 zero-grad, forward, Cox partial likelihood, backward, clip, Adam -- all inside one replayed HIP graph.  The cohort is
 resident in HBM before the timed region; per step the batch is gathered device-to-device into the graph's static buffers.
 
-K-fold cross-validation trains 5 independent models, and at batch 4 one model's step is a chain of ~570 small dependent
-kernels that leaves most of the 256 CUs idle.  Each rank therefore trains F folds CONCURRENTLY (default F = 4 = one per
-hardware queue, the measured optimum): one model + optimiser + step graph + HIP stream per fold, the K timed steps
-dealt round-robin over the F fold models.  Per-model semantics are untouched (each step is the same graph as with F = 1);
-`config.single_chain_patients_per_s` reports the F = 1 rate measured in the same run.
+K-fold cross-validation trains independent models of one shape, and at batch 4 one model's step is a chain of ~560 small
+dependent kernels that leaves most of the 256 CUs idle.  Fold models are therefore advanced in lock-step as FOLD GROUPS
+(DESIGN.md section 3a): every launch of the step carries the parameter blocks of all G models of a group, and F groups run
+concurrently on F streams (one step graph each).  Default: F = 2 groups x G = 10 models = 20 fold models in flight (four
+5-fold cross-validations; the reference's own experiment set is 3-5 scripts x 5 folds), the K timed steps dealt over
+them.  Per-model semantics are untouched (tests/test_gpu_fold_group.py).  The same run also reports, in `config`, one
+5-fold CV alone on the GPU (5 lock-step models, `one_cv_5_lockstep_patients_per_s`) and ONE model alone
+(`single_chain_patients_per_s`).
 
   python bench.py [--gpus N] [--steps K] [--warmup W]            (N>1: launched by torch.distributed.run)
 N>1 shards K-fold units over ranks (fold k -> rank k mod N, no data-path collective): weak scaling.
@@ -113,15 +116,15 @@ def cpu_baseline(cohort, train_idx, steps, B):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=240)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--concurrent-folds", type=int, default=2,
                     help="fold groups trained concurrently per GPU, one HIP stream + step graph each (mode fold)")
-    ap.add_argument("--fold-group", type=int, default=5,
+    ap.add_argument("--fold-group", type=int, default=10,
                     help="fold models advanced in lock-step by ONE launch sequence (FoldGroupEngine, *_group entry points); "
                          "--concurrent-folds then counts concurrent groups")
     ap.add_argument("--mode", choices=["fold", "ddp"], default="fold",
@@ -150,7 +153,7 @@ def main():
     folds = data.kfold_indices(cohort["n"], 5, seed=42)
     ddp = args.mode == "ddp" and world > 1
     F = 1 if ddp else max(1, args.concurrent_folds)
-    G = 1 if ddp else max(1, min(args.fold_group, 8))
+    G = 1 if ddp else max(1, min(args.fold_group, 10))
     engines, groups, streams, orders = [], [], [], []          # engines/orders: one per fold model, index f * G + g
     for f in range(F):
         ms = []
@@ -214,8 +217,8 @@ def main():
         return D.max_over_ranks(time.perf_counter() - t0, dev)
 
     run(max(args.warmup, 3 * F * G), F)                           # includes each fold model's / group's graph capture
-    if G > 1 and args.steps % G:
-        run(args.steps % G, 1)                                    # the ragged tail's sub-group graph, captured outside the timed region
+    if G > 1 and args.steps % (F * G):
+        run(args.steps, F)                                        # the exact timed schedule once, untimed: captures the ragged tail's sub-group graph
     dt = timed(args.steps, F)
     # single chain: ONE fold model alone on the GPU (no grouping, no concurrency), same graph-replayed step
     if F * G > 1:
@@ -237,6 +240,22 @@ def main():
             dt1 = timed(n1, 1) / n1
     else:
         dt1 = dt / args.steps
+    # one 5-fold cross-validation alone on the GPU: 5 models in lock-step, nothing else running (sub-group of group 0)
+    dt5 = None
+    if G >= 5:
+        def cv5(i):
+            idx = [orders[g][(i % (len(orders[g]) // B)) * B:][:B] for g in range(5)]
+            groups[0].train_step_indexed(cohort, torch.stack(idx), members=(0, 1, 2, 3, 4), skip_if_unusable=True,
+                                         use_graph=not args.no_graph)
+        n5 = max(args.steps // (2 * F * G), 6)
+        for i in range(3):
+            cv5(i)
+        torch.cuda.synchronize(); D.barrier()
+        t0 = time.perf_counter()
+        for i in range(n5):
+            cv5(i)
+        torch.cuda.synchronize(); D.barrier()
+        dt5 = D.max_over_ranks(time.perf_counter() - t0, dev) / (5 * n5)
     stats = engines[0].epoch_stats()
 
     if rank == 0:
@@ -249,7 +268,8 @@ def main():
                                    "109 synthetic complete patients, 5-fold split, batch 4, Adam lr 1e-4 wd 1e-4, clip 1.0",
                        "global_batch": world * B, "parallelism": (f"ddp x{world} (flat gradient all-reduce per step, local BN + local Cox risk set)" if ddp else
                                        f"kfold-shard x{world} ranks x {F} concurrent groups x {G} lock-step fold models per GPU (one stream + step graph per group, no collective)"),
-                       "concurrent_folds": F, "fold_group": G, "single_chain_patients_per_s": world * B / dt1, "single_chain_ms_per_step": dt1 * 1e3,
+                       "concurrent_folds": F, "fold_group": G, "fold_models_in_flight": F * G,
+                       "one_cv_5_lockstep_patients_per_s": (world * B / dt5) if dt5 else None, "single_chain_patients_per_s": world * B / dt1, "single_chain_ms_per_step": dt1 * 1e3,
                        "hip_graph": not args.no_graph, "mean_train_loss": stats["sum_loss"] / max(stats["n_batches"], 1)},
         }
         avg_t, avg_f = measure_dominant_kernel(B, dims, dev, G)

@@ -31,7 +31,7 @@ typedef struct ihipEvent_t* hipEvent_t;
 #define MMS_OK 0
 #define MMS_ERR_ARG (-1)
 #define MMS_ERR_LAUNCH (-2)
-#define MMS_MAX_GROUP 8      /* models per fold-group launch (the *_group entry points) */
+#define MMS_MAX_GROUP 10     /* models per fold-group launch (the *_group entry points): 10 x the largest block (Conv1BwdP) stays under the 4 KB kernarg limit */
 
 #ifdef __cplusplus
 extern "C" {

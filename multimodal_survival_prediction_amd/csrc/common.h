@@ -11,7 +11,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Fold groups: one launch advances up to MMS_MAX_GROUP independent models of identical shape (the K-fold models of the
 // reference's cross-validation loop, final_multimodal.py:316-402).  The kernel argument is the array of the models'
-// parameter blocks BY VALUE (<= 8 x 328 B, kernarg segment); the model index is an extra grid dimension: blockIdx.z for
+// parameter blocks BY VALUE (<= 10 x 352 B, kernarg segment); the model index is an extra grid dimension: blockIdx.z for
 // plain kernels, blockIdx.z / zdim for the tile-GEMM core (whose own z = blockIdx.z % zdim).  Per-model work is exactly
 // the single-model kernel's: grouping changes placement only, never results.
 template <class P> struct Grp { P p[MMS_MAX_GROUP]; int zdim; };

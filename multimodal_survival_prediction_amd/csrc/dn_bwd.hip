@@ -269,7 +269,8 @@ __global__ __launch_bounds__(256) void unpack_conv3_grads_kernel(const UnpackTab
 }
 // fold-group form: the scratch of layer i of model g is scratch[g] + i * 27*32*128 (how the driver lays it out), so a table
 // entry is just the destination pointer: 8 models x 58 layers x 8 B = 3.7 KB of kernarg, one launch for the group
-struct UnpackGroup { const float* scratch[MMS_MAX_GROUP]; float* dw[MMS_MAX_GROUP][58]; };
+#define UNPACK_MAXG 7        // 7 x 58 x 8 B + 56 B = 3.3 KB of kernarg; larger groups take two launches
+struct UnpackGroup { const float* scratch[UNPACK_MAXG]; float* dw[UNPACK_MAXG][58]; };
 __global__ __launch_bounds__(256) void unpack_conv3_grads_group_kernel(const UnpackGroup tab) {
     __shared__ float t[27 * 129];
     const int co = blockIdx.x, layer = blockIdx.y, g = blockIdx.z;
@@ -288,13 +289,18 @@ __global__ __launch_bounds__(256) void unpack_conv3_grads_group_kernel(const Unp
 extern "C" int mms_unpack_conv3_grads_group(const float* const* scratch, float* const* const* dw, int ng, int nlayers, hipStream_t s) {
     if (nlayers <= 0) return MMS_OK;
     if (!scratch || !dw || ng < 1 || ng > MMS_MAX_GROUP || nlayers > 58) return MMS_ERR_ARG;
-    UnpackGroup t;
-    for (int g = 0; g < ng; ++g) {
-        t.scratch[g] = scratch[g];
-        for (int i = 0; i < nlayers; ++i) t.dw[g][i] = dw[g][i];
+    for (int g0 = 0; g0 < ng; g0 += UNPACK_MAXG) {
+        const int n = ng - g0 < UNPACK_MAXG ? ng - g0 : UNPACK_MAXG;
+        UnpackGroup t;
+        for (int g = 0; g < n; ++g) {
+            t.scratch[g] = scratch[g0 + g];
+            for (int i = 0; i < nlayers; ++i) t.dw[g][i] = dw[g0 + g][i];
+        }
+        MMS_LAUNCH(unpack_conv3_grads_group_kernel, dim3(32, nlayers, n), dim3(256), 0, s, t);
+        const int rc = mms_check_launch();
+        if (rc != MMS_OK) return rc;
     }
-    MMS_LAUNCH(unpack_conv3_grads_group_kernel, dim3(32, nlayers, ng), dim3(256), 0, s, t);
-    return mms_check_launch();
+    return MMS_OK;
 }
 extern "C" int mms_unpack_conv3_grads(const void* table_host, int nlayers, hipStream_t s) {
     if (nlayers <= 0) return MMS_OK;

@@ -33,10 +33,10 @@ class _GroupPlan:
 
 
 class FoldGroupEngine:
-    MAX = 8      # MMS_MAX_GROUP
+    MAX = 10     # MMS_MAX_GROUP
 
     def __init__(self, models, **engine_kw):
-        """models: 2..8 modules of the same class/shape, already on the GPU and not yet bound to an engine."""
+        """models: 1..10 modules of the same class/shape, already on the GPU and not yet bound to an engine."""
         if not 1 <= len(models) <= self.MAX:
             raise ValueError("a fold group holds 1..%d models" % self.MAX)
         self.lib = _lib.load_library()

@@ -36,7 +36,7 @@ def save_json(path, obj):
 
 def lockstep_enabled(n_local_folds):
     """Folds of this rank train in lock-step as one fold group (MMS_LOCKSTEP=0 restores fold-after-fold order)."""
-    return env_int("MMS_LOCKSTEP", 1) != 0 and 2 <= n_local_folds <= 8
+    return env_int("MMS_LOCKSTEP", 1) != 0 and 2 <= n_local_folds <= 10
 
 
 def cv_lockstep(style, models, loaders, group_kw, num_epochs, patience, make_scheduler, ckpt_path, device, rank, fold_names,

@@ -155,7 +155,7 @@ def test_group_rejects_mismatched_shapes():
                         torch.zeros(1, device=DEV))
     arr = (S["AdamP"] * 2)(a, b)
     assert lib.mms_grad_sumsq_group(arr, 2, ops.stream()) == -1       # MMS_ERR_ARG: sizes differ
-    assert lib.mms_grad_sumsq_group(arr, 9, ops.stream()) == -1       # > MMS_MAX_GROUP
+    assert lib.mms_grad_sumsq_group(arr, 11, ops.stream()) == -1      # > MMS_MAX_GROUP
 
 
 def test_indexed_step_equals_batch_step(monkeypatch):
