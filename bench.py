@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--timed-only", action="store_true", help="profiling aid: stop after the timed region (no extra legs, no JSON)")
     ap.add_argument("--concurrent-folds", type=int, default=2,
                     help="fold groups trained concurrently per GPU, one HIP stream + step graph each (mode fold)")
     ap.add_argument("--fold-group", type=int, default=10,
@@ -220,6 +221,11 @@ def main():
     if G > 1 and args.steps % (F * G):
         run(args.steps, F)                                        # the exact timed schedule once, untimed: captures the ragged tail's sub-group graph
     dt = timed(args.steps, F)
+    if args.timed_only:
+        if rank == 0:
+            print(f"timed-only: {world * args.steps * B / dt:.1f} patients/s, {dt / args.steps * 1e3:.3f} ms/step", flush=True)
+        D.barrier()
+        return
     # single chain: ONE fold model alone on the GPU (no grouping, no concurrency), same graph-replayed step
     if F * G > 1:
         n1 = max(args.steps // (3 * F * G), 10)

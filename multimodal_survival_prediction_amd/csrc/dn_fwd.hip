@@ -276,6 +276,151 @@ __global__ __launch_bounds__(256) void conv3_fwd_reduce_kernel(const Grp<Conv3Fw
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// 3x3x3 conv, multi-tap form for the large blocks (rows per model >= 1024, W <= 16).
+// Conv3FwdOp loads and BN+ReLU-transforms a tile's A rows once PER TAP (27x).  Rows are voxels in (d, h, w) order, so the
+// 9 taps of one kd read rows m + (kh-1)*W + (kw-1): a window of TM + 2(W+1) consecutive rows.  This kernel stages that
+// window of relu(bn(y1)) in LDS once per kd (3x per tile instead of 27x) and reads the A operand of each tap from the
+// shifted slot; the weight operand of a tap goes from L1/L2 straight into the MFMA register layout (prefetched one tap
+// ahead), so there is no weight tile in LDS and no barrier per tap.  Zero padding = a per-(row, tap) 0/1 factor on the A registers (4 VALU per 4 MFMAs).
+// Workgroup = 64 rows x 32 output channels; 4 waves = 2 row tiles x 2 halves of the 128 input channels (summed through
+// LDS at the end); 27 taps x 32 MFMAs per wave.  LDS: window (64 + 2*17) x 132 floats + 2 weight tiles = 85.5 KB.
+// ------------------------------------------------------------------------------------------------------
+#define C3M_TM 64
+#define C3M_PITCH 132
+#define C3M_MAXHALO 17
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv3_fwd_mt_kernel(const Grp<Conv3FwdP> grp) {
+    const Conv3FwdP& p = grp.p[blockIdx.z];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* img = smem;                                               // [nrows][132]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kq = lane >> 5;
+    const int rt = wave >> 1, kh2 = wave & 1;
+    int bx = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bx = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);      // XCD-contiguous row ranges
+    const int m0 = bx * C3M_TM;
+    const int W = p.g.W, HW = p.g.H * p.g.W, halo = W + 1, nrows = C3M_TM + 2 * halo;
+    const int c4 = (tid & 31) * 4;
+    float mean[4], sc[4], beta[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float mu, rstd;
+        bn_mean_rstd(p.bn, c4 + j, mu, rstd);
+        mean[j] = mu; sc[j] = p.bn.gamma[c4 + j] * rstd; beta[j] = p.bn.beta[c4 + j];
+    }
+    const int myrow = m0 + rt * 32 + li;
+    const unsigned m9 = myrow < p.M ? tap_mask9(p.coords[myrow], p.g, false) : 0u;
+    f32x16 acc, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+
+    // B operand: straight from global memory (L1/L2-resident packed weights) into the MFMA register layout, one tap ahead:
+    // lane (kq, co = li) needs W[co][tap][64*kh2 + 8q + 4kq .. +3], q = 0..7 -- 8 x 16 B per lane and tap.  No LDS tile,
+    // hence no per-tap barrier: the window is read-only during a kd phase and the waves drift freely (the two waves that
+    // share a channel half hit the same lines in L1).
+    const float* wlane = p.wp + (size_t)li * (27 * 128) + 64 * kh2 + 4 * kq;
+    float4 bA[8], bB[8];
+    auto bload = [&](float4 (&b)[8], int tap) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) b[q] = *(const float4*)(wlane + tap * 128 + 8 * q);
+    };
+    // window rows: loaded into registers ahead of the kd phase that needs them (wload), transformed + stored at its start (wstore)
+    constexpr int NI = ((C3M_TM + 2 * C3M_MAXHALO) * 32 + 255) / 256;      // 13
+    float4 wv[NI];
+    unsigned wok = 0;
+    auto wload = [&](int kd) __attribute__((always_inline)) {
+        const int base = m0 - halo + (kd - 1) * HW;
+        wok = 0;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int s = (tid >> 5) + 8 * i, src = base + s;
+            const bool ok = s < nrows && src >= 0 && src < p.M;
+            wok |= (ok ? 1u : 0u) << i;
+            wv[i] = ok ? *(const float4*)(p.y1 + (size_t)src * 128 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto wstore = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int s = (tid >> 5) + 8 * i;
+            if (s < nrows) {
+                const float z = (wok >> i) & 1u ? 1.f : 0.f;
+                *(float4*)&img[s * C3M_PITCH + c4] =
+                    make_float4(z * fmaxf(bn_apply(wv[i].x, mean[0], sc[0], beta[0]), 0.f), z * fmaxf(bn_apply(wv[i].y, mean[1], sc[1], beta[1]), 0.f),
+                                z * fmaxf(bn_apply(wv[i].z, mean[2], sc[2], beta[2]), 0.f), z * fmaxf(bn_apply(wv[i].w, mean[3], sc[3], beta[3]), 0.f));
+            }
+        }
+    };
+    auto mma = [&](int tap, const float4 (&b)[8]) __attribute__((always_inline)) {
+        const int kd = tap / 9, t9 = tap - 9 * kd, kh = t9 / 3, kw = t9 - 3 * kh;
+        const unsigned sel = (1u << kd) | (8u << kh) | (64u << kw);
+        const float mk = (m9 & sel) == sel ? 1.f : 0.f;
+        const float* ar = img + (rt * 32 + li + halo + (kh - 1) * W + (kw - 1)) * C3M_PITCH + 64 * kh2 + 4 * kq;
+        float4 a[8];
+#ifdef C3M_NO_AREAD
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] = make_float4(mk, mk + q, mk * 2, 1.f);
+#else
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] = *(const float4*)(ar + 8 * q);
+#endif
+#ifdef C3M_NO_MASK
+#define MK_(x) (x)
+#else
+#define MK_(x) ((x) * mk)
+#endif
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {        // two accumulators: consecutive MFMAs never wait for each other's result
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(MK_(a[q].x), b[q].x, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(MK_(a[q].y), b[q].y, acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(MK_(a[q].z), b[q].z, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(MK_(a[q].w), b[q].w, acc2, 0, 0, 0);
+        }
+    };
+    auto step = [&](int tap, const float4 (&cur)[8], float4 (&nxt)[8]) __attribute__((always_inline)) {
+        const int t9 = tap % 9;
+#ifndef C3M_NO_BLOAD
+        if (tap + 1 < 27) bload(nxt, tap + 1);
+#endif
+        if (t9 == 5 && tap + 4 < 27) wload(tap / 9 + 1);             // next kd's rows: in flight during taps 5..8
+        mma(tap, cur);
+        if (t9 == 8 && tap + 1 < 27) { __syncthreads(); wstore(); __syncthreads(); }   // all waves are done with this window
+    };
+    bload(bA, 0);
+    wload(0);
+    wstore();
+    __syncthreads();
+#pragma unroll 1
+    for (int tap = 0; tap < 26; tap += 2) {
+        step(tap, bA, bB);
+        step(tap + 1, bB, bA);
+    }
+    step(26, bA, bB);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+    __syncthreads();                                                 // window -> Cs alias
+    // ---- epilogue: add the two channel halves, write the 32 slab columns, batch statistics
+    float* Cs = smem;                                                // [64][33], aliases the window
+    const int crow = rt * 32 + 4 * kq;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (kh2 == h) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float* c = &Cs[(crow + (r & 3) + 8 * (r >> 2)) * 33 + li];
+                if (h == 0) *c = acc[r]; else *c += acc[r];
+            }
+        }
+        __syncthreads();
+    }
+    store_tile<C3M_TM, 32>(p.out, p.ldo, p.M, 32, m0, 0, Cs, tid);
+    tile_col_stats<C3M_TM, 32>(stat_rep(p.osum, p.srep, p.sstride), stat_rep(p.osumsq, p.srep, p.sstride), p.M, 32, m0, 0, Cs, tid);
+}
+static inline bool conv3_mt_ok(int M, const Dims3& g) {
+    const char* e = getenv("MMS_CONV3_MT");
+    if (e && e[0] == '0') return false;
+    return M >= 1024 && g.W + 1 <= C3M_MAXHALO;
+}
+
 extern "C" int mms_conv3_fwd_group(const Conv3FwdP* pp, int ng, hipStream_t s) {
     if (!pp || ng < 1 || ng > MMS_MAX_GROUP) return MMS_ERR_ARG;
     const Conv3FwdP& p = *pp;
@@ -284,6 +429,20 @@ extern "C" int mms_conv3_fwd_group(const Conv3FwdP* pp, int ng, hipStream_t s) {
         const Conv3FwdP& q = pp[g];
         if (q.M != p.M || q.ldo % 4 != 0 || q.g.D != p.g.D || q.g.H != p.g.H || q.g.W != p.g.W || (q.partial == nullptr) != (p.partial == nullptr) ||
             q.nsplit != p.nsplit) return MMS_ERR_ARG;
+    }
+    if (!p.partial && conv3_mt_ok(p.M, p.g)) {
+        constexpr int smem_max = (C3M_TM + 2 * C3M_MAXHALO) * C3M_PITCH * (int)sizeof(float);
+        int smem = (C3M_TM + 2 * (p.g.W + 1)) * C3M_PITCH * (int)sizeof(float);       // W = 8: 43 KB -> 3 workgroups per CU
+        if (getenv("MMS_C3M_PAD")) smem += atoi(getenv("MMS_C3M_PAD")) * 1024;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute((const void*)conv3_fwd_mt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem_max);
+            attr_set = true;
+        }
+        Grp<Conv3FwdP> a;
+        grp_fill(a, pp, ng, 1);
+        MMS_LAUNCH(conv3_fwd_mt_kernel, dim3((p.M + C3M_TM - 1) / C3M_TM, 1, ng), dim3(256), smem, s, a);
+        return mms_check_launch();
     }
     if (p.partial) {
         if (p.nsplit < 1 || p.nsplit > 27) return MMS_ERR_ARG;

@@ -97,7 +97,9 @@ def test_transition_fwd(ops, B, dims, K):
     assert_close(os_, cl(ref).double().sum(0), 1e-4, "transition sum")
 
 
-@pytest.mark.parametrize("B,dims", [(4, (16, 16, 8)), (2, (8, 8, 4)), (4, (4, 4, 2)), (4, (2, 2, 1)), (3, (5, 3, 2))])
+# (M >= 1024 rows with W <= 16 and no tap split takes the multi-tap kernel conv3_fwd_mt_kernel: cases 1 and 6-8; 7 = ragged last tile)
+@pytest.mark.parametrize("B,dims", [(4, (16, 16, 8)), (2, (8, 8, 4)), (4, (4, 4, 2)), (4, (2, 2, 1)), (3, (5, 3, 2)),
+                                    (4, (8, 8, 4)), (3, (7, 7, 8)), (2, (8, 16, 16))])
 @pytest.mark.parametrize("train", [True, False])
 @pytest.mark.parametrize("split", [0, 27, 3, 5])
 def test_conv3_fwd(ops, B, dims, train, split):

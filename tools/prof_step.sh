@@ -1,13 +1,13 @@
 #!/bin/bash
 # single-chain per-kernel profile of one training step (GPU box): prints the top kernels by time per step
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd /tmp; export TMPDIR=/tmp
-rm -rf /tmp/pstep; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pstep -- python3 $R/bench.py --steps ${STEPS:-20} --warmup 4 --no-cpu-baseline --concurrent-folds 1 --fold-group ${GROUP:-1} > /tmp/pstep.log 2>&1
+rm -rf /tmp/pstep; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pstep -- python3 $R/bench.py --steps ${STEPS:-20} --warmup 4 --no-cpu-baseline --timed-only --concurrent-folds 1 --fold-group ${GROUP:-1} > /tmp/pstep.log 2>&1
 python3 - <<'PY'
 import csv,glob,collections
 f=glob.glob('/tmp/pstep/*/*_kernel_trace.csv')[0]
 rows=list(csv.DictReader(open(f))); rows.sort(key=lambda r:int(r['Start_Timestamp']))
 ends=[i for i,r in enumerate(rows) if 'clip_adam' in r['Kernel_Name']]
-skip=int(__import__('os').environ.get('SKIP','16'))
+skip=int(__import__('os').environ.get('SKIP','0'))
 a,b=ends[-6-skip],ends[-2-skip]; seg=rows[a+1:b+1]; n=4
 agg=collections.defaultdict(lambda:[0,0])
 for r in seg:
