@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void conv3_fwd_reduce_kernel(const Grp<Conv3Fw
 }
 
 // ------------------------------------------------------------------------------------------------------
-// 3x3x3 conv, multi-tap form for the large blocks (rows per model >= 1024, W <= 16).
+// 3x3x3 conv, multi-tap form for launches with many rows (>= 512 tiles of 64 rows over the group, W <= 16).
 // Conv3FwdOp loads and BN+ReLU-transforms a tile's A rows once PER TAP (27x).  Rows are voxels in (d, h, w) order, so the
 // 9 taps of one kd read rows m + (kh-1)*W + (kw-1): a window of TM + 2(W+1) consecutive rows.  This kernel stages that
 // window of relu(bn(y1)) in LDS once per kd (3x per tile instead of 27x) and reads the A operand of each tap from the
@@ -389,8 +389,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     wload(0);
     wstore();
     __syncthreads();
+#ifndef C3M_TAPS
+#define C3M_TAPS 26
+#endif
 #pragma unroll 1
-    for (int tap = 0; tap < 26; tap += 2) {
+    for (int tap = 0; tap < C3M_TAPS; tap += 2) {
         step(tap, bA, bB);
         step(tap + 1, bB, bA);
     }
@@ -415,10 +418,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     store_tile<C3M_TM, 32>(p.out, p.ldo, p.M, 32, m0, 0, Cs, tid);
     tile_col_stats<C3M_TM, 32>(stat_rep(p.osum, p.srep, p.sstride), stat_rep(p.osumsq, p.srep, p.sstride), p.M, 32, m0, 0, Cs, tid);
 }
-static inline bool conv3_mt_ok(int M, const Dims3& g) {
+// Used when the launch has >= 512 of its 64-row tiles (2 per CU): with fewer, the 32-row tiles of the GEMM form fill the chip
+// better (measured: one model's block 1, 128 tiles: 50 us vs 40 us; ten models' block 2, 160 tiles: 52 vs 50 us).
+static inline bool conv3_mt_ok(int M, int ng, const Dims3& g) {
     const char* e = getenv("MMS_CONV3_MT");
     if (e && e[0] == '0') return false;
-    return M >= 1024 && g.W + 1 <= C3M_MAXHALO;
+    if (e && e[0] == '2') return M >= 1024 && g.W + 1 <= C3M_MAXHALO;      // force (tests)
+    return (long)((M + C3M_TM - 1) / C3M_TM) * ng >= 512 && g.W + 1 <= C3M_MAXHALO;
 }
 
 extern "C" int mms_conv3_fwd_group(const Conv3FwdP* pp, int ng, hipStream_t s) {
@@ -430,7 +436,7 @@ extern "C" int mms_conv3_fwd_group(const Conv3FwdP* pp, int ng, hipStream_t s) {
         if (q.M != p.M || q.ldo % 4 != 0 || q.g.D != p.g.D || q.g.H != p.g.H || q.g.W != p.g.W || (q.partial == nullptr) != (p.partial == nullptr) ||
             q.nsplit != p.nsplit) return MMS_ERR_ARG;
     }
-    if (!p.partial && conv3_mt_ok(p.M, p.g)) {
+    if (!p.partial && conv3_mt_ok(p.M, ng, p.g)) {
         constexpr int smem_max = (C3M_TM + 2 * C3M_MAXHALO) * C3M_PITCH * (int)sizeof(float);
         int smem = (C3M_TM + 2 * (p.g.W + 1)) * C3M_PITCH * (int)sizeof(float);       // W = 8: 43 KB -> 3 workgroups per CU
         if (getenv("MMS_C3M_PAD")) smem += atoi(getenv("MMS_C3M_PAD")) * 1024;

@@ -21,7 +21,9 @@ def _d(t):
 
 
 @pytest.mark.parametrize("B,dims,C,Ctot,ms", [(2, (4, 4, 2), 64, 256, 1), (4, (8, 8, 4), 96, 256, 4), (3, (2, 2, 1), 512, 1024, 1),
-                                              (2, (16, 16, 8), 224, 256, 16)])
+                                              (2, (16, 16, 8), 224, 256, 16),
+                                              # shapes that take the multi-tap forward kernel in the layer's forward: ragged last tile, W = 16
+                                              (3, (7, 7, 8), 64, 256, 4), (2, (8, 16, 16), 96, 256, 8)])
 @pytest.mark.parametrize("split", [0, 27, 3])
 def test_dense_layer_backward(ops, B, dims, C, Ctot, ms, split):
     """One _DenseLayer: norm1-relu-conv1-norm2-relu-conv2 + cat; gradient w.r.t. every parameter and the input slab."""

@@ -102,7 +102,8 @@ def test_transition_fwd(ops, B, dims, K):
                                     (4, (8, 8, 4)), (3, (7, 7, 8)), (2, (8, 16, 16))])
 @pytest.mark.parametrize("train", [True, False])
 @pytest.mark.parametrize("split", [0, 27, 3, 5])
-def test_conv3_fwd(ops, B, dims, train, split):
+def test_conv3_fwd(ops, B, dims, train, split, monkeypatch):
+    monkeypatch.setenv("MMS_CONV3_MT", "2")      # take the multi-tap kernel whenever the shape allows it (default: only for >= 512 tiles)
     torch.manual_seed(2)
     M = B * dims[0] * dims[1] * dims[2]
     y1 = torch.randn(B, 128, *dims) + 0.1
