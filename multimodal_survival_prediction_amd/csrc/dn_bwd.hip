@@ -464,7 +464,8 @@ extern "C" int mms_conv1_bwd_data_group(const Conv1BwdP* pp, int ng, hipStream_t
     if (p.M <= 0 || p.K % 32 != 0 || p.N % 32 != 0 || p.ldx % 4 != 0 || p.lddy % 4 != 0) return MMS_ERR_ARG;
     if (p.has_bn_out && p.N != 128) return MMS_ERR_ARG;
     if (!conv1_bwd_same(pp, ng)) return MMS_ERR_ARG;
-    const bool big = (long)p.M * p.K >= 256L * 64 * 64;
+    const int big_ng = getenv("MMS_BIG_NG") ? atoi(getenv("MMS_BIG_NG")) : 1;      // 1: count the whole group's tiles (0: tests that need ng-independent arithmetic)
+    const bool big = (long)p.M * p.K * (big_ng ? ng : 1) >= 256L * 64 * 64;
     if (big) {
         dim3 g((p.M + 63) / 64, (p.K + 63) / 64, 1);
         return p.pool ? launch_tile_gemm<Conv1BwdDataOp<2, 2, 1, true>>(pp, ng, g, s)

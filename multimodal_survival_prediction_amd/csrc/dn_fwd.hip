@@ -138,7 +138,8 @@ extern "C" int mms_conv1_fwd_group(const Conv1FwdP* pp, int ng, hipStream_t s) {
             q.in.W != p.in.W) return MMS_ERR_ARG;
     }
     // big M: 64x64 tiles, no in-workgroup K split; small M: 32x32 tiles with the 4 waves splitting K
-    const bool big = (long)p.M * p.N >= 256L * 64 * 64;
+    const int big_ng = getenv("MMS_BIG_NG") ? atoi(getenv("MMS_BIG_NG")) : 1;      // 1: count the whole group's tiles (0: tests that need ng-independent arithmetic)
+    const bool big = (long)p.M * p.N * (big_ng ? ng : 1) >= 256L * 64 * 64;
     if (big) {
         dim3 g((p.M + 63) / 64, (p.N + 63) / 64, 1);
         return p.pool ? launch_tile_gemm<Conv1FwdOp<2, 2, 1, true>>(pp, ng, g, s)
