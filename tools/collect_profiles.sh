@@ -7,7 +7,7 @@ cp $(ls /tmp/pf1/*/*_kernel_stats.csv | head -1) $O/kernel_stats.csv
 # 2. PMC passes (kernel-trace only) on the dominant kernel, group launches, per block shape
 for blk in 0 1 2 3; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    rm -rf /tmp/pm; rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pm -- python3 $R/tools/prof_conv3bwdw.py $blk 10 5 > /dev/null 2>&1
+    rm -rf /tmp/pm; rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pm -- python3 $R/tools/prof_conv3bwdw.py $blk 10 10 > /dev/null 2>&1
     f=$(ls /tmp/pm/*/*_counter_collection.csv | head -1)
     python3 - "$f" $blk $c >> $O/pmc_conv3bwdw.txt <<'PY'
 import csv,sys
@@ -20,4 +20,6 @@ done
 # 3. plain default bench line (no profiler)
 cd $R && python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 # 4. per-grid breakdown of one group step
+TOPN=400 GROUP=10 STEPS=80 bash $R/tools/prof_step.sh > $O/group10_step_breakdown.txt 2>&1
 TOPN=400 GROUP=5 STEPS=40 bash $R/tools/prof_step.sh > $O/group5_step_breakdown.txt 2>&1
+python3 $R/tools/make_traffic_json.py $O/pmc_conv3bwdw.txt 10 > $O/pmc_conv3bwdw_traffic.json
