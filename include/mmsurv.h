@@ -325,6 +325,19 @@ typedef struct AdamP {
     int* rng;                       // [2] dropout (seed, step counter): counter += 1 after the step's kernels have used it
 } AdamP;
 
+/* Learnable missing-modality bias (R/scripts/training/flexible_multimodal.py:205-206,243-250): per feature segment s
+ * (image 128 | RNA 256 columns of the fused vector)   feats[m][j] = feats[m][j]*mask[m][s] + bias_s[j]*(1 - mask[m][s]),
+ * in place; backward: dbias_s[j] += sum_m dfeats[m][j]*(1 - mask[m][s]);  dfeats[m][j] *= mask[m][s]. */
+typedef struct MixP {
+    float* feats; int ld; int M;
+    const float* mask; int ldm;     // [M][ldm], column s = has-modality flag of segment s
+    int nseg;                       // <= 4
+    int seg_begin[4]; int seg_width[4];
+    const float* bias[4];
+    float* dfeats; int ldd;         // backward only
+    float* dbias[4];
+} MixP;
+
 /* Batch assembly from a device-resident cohort (the DataLoader collate of R/scripts/training/final_multimodal.py:228-236
  * when the tensors already live in HBM): row idx[b] of each source array -> row b of its destination, all sources of
  * all models of a fold group in ONE launch. */
@@ -382,6 +395,8 @@ int mms_linear_bwd(const LinearBwdP* p, hipStream_t s);
 int mms_gate_fwd(const GateP* p, hipStream_t s);
 int mms_gate_bwd(const GateP* p, hipStream_t s);
 int mms_gate_entropy(const float* gate, int M, float scale, float* loss, float* dgate, hipStream_t s);  /* gate_entropy_loss value (+= into *loss) and gradient */
+int mms_missing_mix_fwd(const MixP* p, hipStream_t s);        /* R/scripts/training/flexible_multimodal.py:243-250 */
+int mms_missing_mix_bwd(const MixP* p, hipStream_t s);
 int mms_cox_fwd_bwd(const CoxP* p, hipStream_t s);
 int mms_cindex_counts(const CindexP* p, hipStream_t s);
 int mms_grad_sumsq(const AdamP* p, hipStream_t s);             /* sum of squares of the flat gradient (fp64 atomics) */
@@ -427,6 +442,8 @@ int mms_pool_bwd_group(const PoolBwdP* p, int ng, hipStream_t s);
 int mms_conv0_bwd_weight_group(const Conv0BwdWP* p, int ng, hipStream_t s);
 int mms_pack_conv3_table_group(const void* const* tables_dev, int ng, int nlayers, hipStream_t s);
 int mms_bn_running_update_group(const void* const* tables_dev, int ng, int n, float momentum, hipStream_t s);
+int mms_missing_mix_fwd_group(const MixP* p, int ng, hipStream_t s);
+int mms_missing_mix_bwd_group(const MixP* p, int ng, hipStream_t s);
 int mms_gather_rows_group(const GatherP* p, int ng, hipStream_t s);
 int mms_unpack_conv3_grads_group(const float* const* scratch, float* const* const* dw, int ng, int nlayers, hipStream_t s);  /* scratch[g]: model g's [nlayers][27][32][128] tap-major scratch; dw[g][i]: canonical gradient of layer i; nlayers <= 58 */
 int mms_zero_regions_group(void* const* regions_dev, int ng, size_t bytes, hipStream_t s);   /* 16-B aligned regions of equal size, zero-filled by one launch */

@@ -596,3 +596,52 @@ extern "C" int mms_gather_rows_group(const GatherP* pp, int ng, hipStream_t s) {
     MMS_LAUNCH(gather_rows_kernel, dim3(blocks, pp->B, ng), dim3(256), 0, s, a);
     return mms_check_launch();
 }
+
+// ------------------------------------------------------------------------------------------------------
+// learnable missing-modality bias (flexible_multimodal.py:243-250): one thread per feature column
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void missing_mix_kernel(const Grp<MixP> grp, int bwd) {
+    const MixP& p = grp.p[blockIdx.z];
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    int s = -1;
+    for (int t = 0; t < p.nseg; ++t) if (j >= p.seg_begin[t] && j < p.seg_begin[t] + p.seg_width[t]) s = t;
+    if (s < 0) return;
+    const int jl = j - p.seg_begin[s];
+    if (!bwd) {
+        const float b = p.bias[s][jl];
+        for (int m = 0; m < p.M; ++m) {
+            const float mk = p.mask[(size_t)m * p.ldm + s];
+            float* f = &p.feats[(size_t)m * p.ld + j];
+            *f = *f * mk + b * (1.f - mk);
+        }
+    } else {
+        float acc = 0.f;
+        for (int m = 0; m < p.M; ++m) {
+            const float mk = p.mask[(size_t)m * p.ldm + s];
+            float* d = &p.dfeats[(size_t)m * p.ldd + j];
+            acc = fmaf(*d, 1.f - mk, acc);
+            *d = *d * mk;
+        }
+        if (p.dbias[s]) p.dbias[s][jl] += acc;
+    }
+}
+static int mix_launch(const MixP* pp, int ng, int bwd, hipStream_t s) {
+    Grp<MixP> a;
+    if (!grp_fill(a, pp, ng, 1)) return MMS_ERR_ARG;
+    int wmax = 0;
+    for (int g = 0; g < ng; ++g) {
+        const MixP& q = pp[g];
+        if (q.M != pp->M || q.M <= 0 || q.nseg != pp->nseg || q.nseg < 1 || q.nseg > 4 || !q.mask) return MMS_ERR_ARG;
+        if (bwd ? !q.dfeats : !q.feats) return MMS_ERR_ARG;
+        for (int t = 0; t < q.nseg; ++t) {
+            if (q.seg_begin[t] != pp->seg_begin[t] || q.seg_width[t] != pp->seg_width[t] || !q.bias[t]) return MMS_ERR_ARG;
+            if (q.seg_begin[t] + q.seg_width[t] > wmax) wmax = q.seg_begin[t] + q.seg_width[t];
+        }
+    }
+    MMS_LAUNCH(missing_mix_kernel, dim3((wmax + 255) / 256, 1, ng), dim3(256), 0, s, a, bwd);
+    return mms_check_launch();
+}
+extern "C" int mms_missing_mix_fwd_group(const MixP* pp, int ng, hipStream_t s) { return mix_launch(pp, ng, 0, s); }
+extern "C" int mms_missing_mix_bwd_group(const MixP* pp, int ng, hipStream_t s) { return mix_launch(pp, ng, 1, s); }
+MMS_SINGLE(mms_missing_mix_fwd, MixP)
+MMS_SINGLE(mms_missing_mix_bwd, MixP)

@@ -67,6 +67,34 @@ def head_program(model):
         bufs = dict(rna=r[0].in_features, r1=1024, r2=512, feats=384, f1=256, f2=128, hz=1)
         return dict(kind=kind, width=384, ct_cols=256, lins=lins, gate=None, bufs=bufs, encoder=model.image_encoder,
                     n_pre=3)
+    if kind == "FlexibleMultimodalModel":      # flexible_multimodal.py:157-256: simple-fusion heads, [image | rna] order, missing bias
+        r, f = model.rna_encoder, model.fusion
+        lins = [
+            _Lin(r[0], ("rna", 0), ("r1", 0), False, need_dx=False),
+            _Lin(r[4], ("r1", 0), ("r2", 0), False, pro_bn=r[1], pro_drop=r[3]),
+            _Lin(r[8], ("r2", 0), ("feats", 128), True, pro_bn=r[5], pro_drop=r[7]),
+            _Lin(f[0], ("feats", 0), ("f1", 0), False),
+            _Lin(f[4], ("f1", 0), ("f2", 0), True, pro_bn=f[1], pro_drop=f[3]),
+            _Lin(f[7], ("f2", 0), ("hz", 0), False, pro_drop=f[6]),
+        ]
+        bufs = dict(rna=r[0].in_features, r1=1024, r2=512, feats=384, f1=256, f2=128, hz=1)
+        return dict(kind=kind, width=384, ct_cols=0, lins=lins, gate=None, bufs=bufs, encoder=model.image_encoder, n_pre=3,
+                    mix=dict(biases=[model.missing_image_bias, model.missing_rna_bias], segs=[(0, 128), (128, 256)]))
+    if kind == "RNASeqSurvivalModel":          # train_rnaseq_only.py:126-151: [Linear, BN1d, ReLU, Dropout] x n + Linear(., 1)
+        mods = list(model.mlp)
+        lin_idx = [i for i, m in enumerate(mods) if isinstance(m, nn.Linear)]
+        lins, bufs = [], dict(rna=mods[0].in_features)
+        for n, i in enumerate(lin_idx):
+            src = ("rna", 0) if n == 0 else ("h%d" % n, 0)
+            last = n == len(lin_idx) - 1
+            dst = ("hz", 0) if last else ("h%d" % (n + 1), 0)
+            if not last:
+                bufs["h%d" % (n + 1)] = mods[i].out_features
+            pro_bn = mods[lin_idx[n - 1] + 1] if n > 0 else None
+            pro_drop = mods[lin_idx[n - 1] + 3] if n > 0 else None
+            lins.append(_Lin(mods[i], src, dst, False, pro_bn=pro_bn, pro_drop=pro_drop, need_dx=n > 0))
+        bufs["hz"] = 1
+        return dict(kind=kind, width=0, ct_cols=0, lins=lins, gate=None, bufs=bufs, encoder=None, n_pre=0)
     raise TypeError("unsupported model %s" % kind)
 
 
@@ -93,7 +121,8 @@ class SurvivalEngine:
         n = self.flat.numel()
         self.m = torch.zeros(n, device=self.device)
         self.v = torch.zeros(n, device=self.device)
-        self.adamw = bool(adamw) if adamw is not None else self.prog["kind"] == "SimpleFusionModel"
+        self.adamw = bool(adamw) if adamw is not None else self.prog["kind"] in ("SimpleFusionModel", "FlexibleMultimodalModel",
+                                                                                 "RNASeqSurvivalModel")
         self.hyper = torch.tensor([lr, betas[0], betas[1], eps, weight_decay, max_norm], device=self.device)
         self.sumsq = self._slots["sumsq"] if "sumsq" in self._slots else torch.zeros(1, dtype=torch.float64, device=self.device)
         self.entropy = self._slots["entropy"] if "entropy" in self._slots else torch.zeros(1, device=self.device)
@@ -146,15 +175,17 @@ class SurvivalEngine:
 
     # ---- plans -----------------------------------------------------------------------------------
     def plan(self, B, dims):
-        key = (B,) + tuple(dims)
+        dims = tuple(dims) if dims is not None else ()
+        key = (B,) + dims
         if key in self.plans:
             return self.plans[key]
         self._check_params()
         P = _Plan()
-        P.B, P.dims = B, tuple(dims)
+        P.B, P.dims = B, dims
         dev = self.device
         prog = self.prog
-        D, H, W = dims
+        P.has_enc = prog["encoder"] is not None
+        D, H, W = dims if P.has_enc else (1, 1, 1)
         P.ct = torch.zeros(B, 1, D, H, W, device=dev)
         P.buf = {k: torch.zeros(B, w, device=dev) for k, w in prog["bufs"].items()}
         P.dbuf = {k: torch.zeros(B, w, device=dev) for k, w in prog["bufs"].items() if k not in ("rna", "clin")}
@@ -166,23 +197,24 @@ class SurvivalEngine:
         P.lse = torch.zeros(B, device=dev)
         # encoder: DenseNet121-3D (MONAI topology) or the reference's 3-conv fallback
         enc = prog["encoder"]
-        P.fallback = isinstance(enc, nn.Sequential)
-        eparams = list(enc.parameters())
-        ebufs = list(enc.buffers())
-        npar, nbuf = (12, 9) if P.fallback else (364, 363)
-        assert len(eparams) == npar and len(ebufs) == nbuf
-        nbytes = ctypes.c_size_t(0)
-        wsfn = self.lib.mms_fb_workspace_bytes if P.fallback else self.lib.mms_dn121_workspace_bytes
-        _lib.check(wsfn(B, D, H, W, ctypes.byref(nbytes)), "workspace_bytes")
-        P.ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
-        P.ptab = (ctypes.c_void_p * npar)(*[p.data_ptr() for p in eparams])
-        P.btab = (ctypes.c_void_p * nbuf)(*[b.data_ptr() for b in ebufs])
         gmap = {id(p): g for p, g in zip(self.params, self.gviews)}
-        P.gtab = (ctypes.c_void_p * npar)(*[gmap[id(p)].data_ptr() for p in eparams])
-        if P.fallback:
-            _lib.check(self.lib.mms_fb_init(P.ws.data_ptr(), B, D, H, W, P.btab, ops.stream()), "mms_fb_init")
-        else:
-            _lib.check(self.lib.mms_dn121_init(P.ws.data_ptr(), B, D, H, W, P.ptab, P.btab, ops.stream()), "mms_dn121_init")
+        P.fallback = isinstance(enc, nn.Sequential)
+        if P.has_enc:
+            eparams = list(enc.parameters())
+            ebufs = list(enc.buffers())
+            npar, nbuf = (12, 9) if P.fallback else (364, 363)
+            assert len(eparams) == npar and len(ebufs) == nbuf
+            nbytes = ctypes.c_size_t(0)
+            wsfn = self.lib.mms_fb_workspace_bytes if P.fallback else self.lib.mms_dn121_workspace_bytes
+            _lib.check(wsfn(B, D, H, W, ctypes.byref(nbytes)), "workspace_bytes")
+            P.ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+            P.ptab = (ctypes.c_void_p * npar)(*[p.data_ptr() for p in eparams])
+            P.btab = (ctypes.c_void_p * nbuf)(*[b.data_ptr() for b in ebufs])
+            P.gtab = (ctypes.c_void_p * npar)(*[gmap[id(p)].data_ptr() for p in eparams])
+            if P.fallback:
+                _lib.check(self.lib.mms_fb_init(P.ws.data_ptr(), B, D, H, W, P.btab, ops.stream()), "mms_fb_init")
+            else:
+                _lib.check(self.lib.mms_dn121_init(P.ws.data_ptr(), B, D, H, W, P.ptab, P.btab, ops.stream()), "mms_dn121_init")
         # head launches (train / eval variants)
         P.lin_fwd = {True: [], False: []}
         P.lin_bwd = []
@@ -216,6 +248,19 @@ class SurvivalEngine:
                                      P.buf["fused"], P.dbuf["fused"], self.ent_weight, P.dbuf["feats"],
                                      gmap[id(g1.weight)], gmap[id(g1.bias)], gmap[id(g2.weight)], gmap[id(g2.bias)],
                                      self.entropy)
+        P.mix = None
+        if prog.get("mix") is not None:            # learnable missing-modality bias between the encoders and the fusion MLP
+            mx = prog["mix"]
+            P.mask2 = torch.ones(B, len(mx["segs"]), device=dev)
+            M = _S()["MixP"]()
+            fe, dfe = P.buf["feats"], P.dbuf["feats"]
+            M.feats, M.ld, M.M = fe.data_ptr(), fe.stride(0), B
+            M.mask, M.ldm, M.nseg = P.mask2.data_ptr(), P.mask2.stride(0), len(mx["segs"])
+            M.dfeats, M.ldd = dfe.data_ptr(), dfe.stride(0)
+            for i, ((b0, w), bias) in enumerate(zip(mx["segs"], mx["biases"])):
+                M.seg_begin[i], M.seg_width[i] = b0, w
+                M.bias[i], M.dbias[i] = bias.data_ptr(), gmap[id(bias)].data_ptr()
+            P.mix = M
         hz = P.buf["hz"]
         P.cox = _S()["CoxP"](hz.data_ptr(), 1, P.time.data_ptr(), P.event.data_ptr(), P.valid.data_ptr(), B, 1.0,
                              P.lse.data_ptr(), P.dbuf["hz"].data_ptr(), 1, P.cox_out.data_ptr())
@@ -237,12 +282,13 @@ class SurvivalEngine:
     def _forward(self, P, train):
         st = ops.stream()
         lib, prog = self.lib, self.prog
-        B, (D, H, W) = P.B, P.dims
-        feats = P.buf["feats"]
-        out = feats[:, prog["ct_cols"]:]
-        fwd = lib.mms_fb_forward if P.fallback else lib.mms_dn121_forward
-        _lib.check(fwd(P.ws.data_ptr(), B, D, H, W, P.ct.data_ptr(), P.ptab, P.btab, out.data_ptr(),
-                       feats.stride(0), 1 if train else 0, st), "encoder forward")
+        B, (D, H, W) = P.B, (P.dims if P.has_enc else (1, 1, 1))
+        if P.has_enc:
+            feats = P.buf["feats"]
+            out = feats[:, prog["ct_cols"]:]
+            fwd = lib.mms_fb_forward if P.fallback else lib.mms_dn121_forward
+            _lib.check(fwd(P.ws.data_ptr(), B, D, H, W, P.ct.data_ptr(), P.ptab, P.btab, out.data_ptr(),
+                           feats.stride(0), 1 if train else 0, st), "encoder forward")
         lf = P.lin_fwd[train]
         n_pre = prog["n_pre"]
         for i in range(n_pre):
@@ -250,6 +296,8 @@ class SurvivalEngine:
         if P.gate is not None:
             self.entropy.zero_()
             _lib.check(lib.mms_gate_fwd(ctypes.byref(P.gate), st), "mms_gate_fwd")
+        if P.mix is not None:
+            _lib.check(lib.mms_missing_mix_fwd(ctypes.byref(P.mix), st), "mms_missing_mix_fwd")
         for i in range(n_pre, len(lf)):
             _lib.check(lib.mms_linear_fwd(ctypes.byref(lf[i]), st), "mms_linear_fwd")
 
@@ -257,14 +305,18 @@ class SurvivalEngine:
         """dbuf['hz'] holds dL/dhazard; accumulates every parameter gradient into gflat."""
         st = ops.stream()
         lib, prog = self.lib, self.prog
-        B, (D, H, W) = P.B, P.dims
+        B, (D, H, W) = P.B, (P.dims if P.has_enc else (1, 1, 1))
         n_pre = prog["n_pre"]
         for i in range(len(P.lin_bwd) - 1, n_pre - 1, -1):
             _lib.check(lib.mms_linear_bwd(ctypes.byref(P.lin_bwd[i]), st), "mms_linear_bwd")
         if P.gate is not None:
             _lib.check(lib.mms_gate_bwd(ctypes.byref(P.gate), st), "mms_gate_bwd")
+        if P.mix is not None:
+            _lib.check(lib.mms_missing_mix_bwd(ctypes.byref(P.mix), st), "mms_missing_mix_bwd")
         for i in range(n_pre - 1, -1, -1):
             _lib.check(lib.mms_linear_bwd(ctypes.byref(P.lin_bwd[i]), st), "mms_linear_bwd")
+        if not P.has_enc:
+            return
         dfe = P.dbuf["feats"]
         dct = dfe[:, prog["ct_cols"]:]
         # The weight-gradient fork (mms_dn121_backward_mt) is off by default: measured, it neither helps a single chain
@@ -301,13 +353,14 @@ class SurvivalEngine:
         # (dropout counter and the epoch accumulators self.acc are advanced inside mms_grad_sumsq: AdamP.acc / .rng)
 
     # ---- public: fused training step ------------------------------------------------------------------
-    def load_batch(self, P, ct, rna, clinical=None, mask=None, time=None, event=None, valid=None):
-        P.ct.copy_(ct.reshape(P.ct.shape), non_blocking=True)
+    def load_batch(self, P, ct=None, rna=None, clinical=None, mask=None, time=None, event=None, valid=None):
+        if P.has_enc:
+            P.ct.copy_(ct.reshape(P.ct.shape), non_blocking=True)
         P.buf["rna"].copy_(rna, non_blocking=True)
         if clinical is not None and "clin" in P.buf:
             P.buf["clin"].copy_(clinical.reshape(P.buf["clin"].shape), non_blocking=True)
         if mask is not None:
-            P.mask.copy_(mask, non_blocking=True)
+            (P.mask2 if P.mix is not None else P.mask).copy_(mask, non_blocking=True)
         if time is not None:
             P.time.copy_(time.reshape(-1), non_blocking=True)
             P.event.copy_(event.reshape(-1).to(torch.float32), non_blocking=True)
@@ -322,12 +375,15 @@ class SurvivalEngine:
         per-patient `valid` column.  idx_dev: [B] int64 device tensor that the caller refills before each launch."""
         G = _S()["GatherP"]()
         G.idx, G.B = idx_dev.data_ptr(), P.B
-        srcs = [(cohort["image"].view(cohort["image"].shape[0], -1), P.ct.view(P.B, -1), None),
-                (cohort["rnaseq"], P.buf["rna"], None)]
+        srcs = [(cohort["rnaseq"], P.buf["rna"], None)]
+        if P.has_enc:
+            srcs.append((cohort["image"].view(cohort["image"].shape[0], -1), P.ct.view(P.B, -1), None))
         if "clin" in P.buf:
             srcs.append((cohort["clinical"], P.buf["clin"], None))
         if P.gate is not None:
             srcs.append((cohort["mask"], P.mask, None))
+        if P.mix is not None:            # [has_image, has_rnaseq] = the first columns of the cohort's modality mask
+            srcs.append((cohort["mask"], P.mask2, P.mask2.shape[1]))
         lab = cohort["label"]
         srcs.append((lab, P.time.view(P.B, 1), 1))
         srcs.append((lab[:, 1:], P.event.view(P.B, 1), 1))
@@ -342,15 +398,15 @@ class SurvivalEngine:
             G.width[i] = w if w is not None else a.shape[1]
         return G
 
-    def train_step(self, ct, rna, clinical=None, mask=None, time=None, event=None, valid=None, skip_if_unusable=True,
+    def train_step(self, ct=None, rna=None, clinical=None, mask=None, time=None, event=None, valid=None, skip_if_unusable=True,
                    use_graph=True, ddp_world=1):
         """One optimisation step on one batch (inputs may live on host or device).  Returns nothing: losses are
         accumulated on the device (`epoch_stats()`), exactly one host sync per epoch instead of one per batch.
         ddp_world > 1: data-parallel step -- this rank's shard of the global batch; the flat gradient buffer is averaged
         over ranks (ONE all-reduce of the contiguous 56-69 MB buffer) between the backward and the clip+Adam kernels.
         BatchNorm statistics and the Cox risk set stay rank-local."""
-        B = ct.shape[0]
-        P = self.plan(B, tuple(ct.shape[-3:]))
+        B = rna.shape[0]
+        P = self.plan(B, tuple(ct.shape[-3:]) if ct is not None else None)
         self.load_batch(P, ct, rna, clinical, mask, time, event, valid)
         if ddp_world > 1:
             from . import distributed as D
@@ -420,10 +476,10 @@ class SurvivalEngine:
             restore()
         P.graphs[key].replay()
 
-    def forward_eval(self, ct, rna, clinical=None, mask=None, use_graph=True):
+    def forward_eval(self, ct=None, rna=None, clinical=None, mask=None, use_graph=True):
         """Eval-mode forward -> (hazard [B] view of a static buffer, gate [B,3] or None)."""
-        B = ct.shape[0]
-        P = self.plan(B, tuple(ct.shape[-3:]))
+        B = rna.shape[0]
+        P = self.plan(B, tuple(ct.shape[-3:]) if ct is not None else None)
         self.load_batch(P, ct, rna, clinical, mask)
         if use_graph:
             if "eval" not in P.graphs:

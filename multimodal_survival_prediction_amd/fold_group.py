@@ -70,27 +70,30 @@ class FoldGroupEngine:
     # ---- plans -----------------------------------------------------------------------------------
     def plan(self, B, dims, members=None):
         members = tuple(range(len(self.engines))) if members is None else tuple(members)
-        key = (B,) + tuple(dims) + (members,)
+        key = (B,) + (tuple(dims) if dims is not None else ()) + (members,)
         if key in self.plans:
             return self.plans[key]
         eng = [self.engines[i] for i in members]
         Ps = [e.plan(B, dims) for e in eng]
-        if any(P.fallback for P in Ps):
+        if any(P.fallback and P.has_enc for P in Ps):
             raise NotImplementedError("fold groups drive the DenseNet121-3D encoder; the 3-conv fallback encoder has no "
                                       "group entry points (train those folds one at a time)")
         GP = _GroupPlan()
-        GP.members, GP.eng, GP.Ps, GP.B, GP.dims = members, eng, Ps, B, tuple(dims)
+        GP.members, GP.eng, GP.Ps, GP.B, GP.dims = members, eng, Ps, B, (tuple(dims) if dims is not None else ())
         prog = eng[0].prog
         GP.ng = len(eng)
-        GP.ws = _ptrs([P.ws.data_ptr() for P in Ps])
-        GP.x = _ptrs([P.ct.data_ptr() for P in Ps])
-        GP.params = _ptrs([ctypes.addressof(P.ptab) for P in Ps])
-        GP.buffers = _ptrs([ctypes.addressof(P.btab) for P in Ps])
-        GP.grads = _ptrs([ctypes.addressof(P.gtab) for P in Ps])
-        cc = prog["ct_cols"]
-        GP.out = _ptrs([P.buf["feats"][:, cc:].data_ptr() for P in Ps])
-        GP.dout = _ptrs([P.dbuf["feats"][:, cc:].data_ptr() for P in Ps])
-        GP.ld = Ps[0].buf["feats"].stride(0)
+        GP.has_enc = Ps[0].has_enc
+        if GP.has_enc:
+            GP.ws = _ptrs([P.ws.data_ptr() for P in Ps])
+            GP.x = _ptrs([P.ct.data_ptr() for P in Ps])
+            GP.params = _ptrs([ctypes.addressof(P.ptab) for P in Ps])
+            GP.buffers = _ptrs([ctypes.addressof(P.btab) for P in Ps])
+            GP.grads = _ptrs([ctypes.addressof(P.gtab) for P in Ps])
+            cc = prog["ct_cols"]
+            GP.out = _ptrs([P.buf["feats"][:, cc:].data_ptr() for P in Ps])
+            GP.dout = _ptrs([P.dbuf["feats"][:, cc:].data_ptr() for P in Ps])
+            GP.ld = Ps[0].buf["feats"].stride(0)
+        GP.mix = _arr([P.mix for P in Ps]) if Ps[0].mix is not None else None
         nl = len(prog["lins"])
         GP.lin_fwd = {t: [_arr([P.lin_fwd[t][i] for P in Ps]) for i in range(nl)] for t in (True, False)}
         GP.lin_bwd = [_arr([P.lin_bwd[i] for P in Ps]) for i in range(nl)]
@@ -108,15 +111,18 @@ class FoldGroupEngine:
         st = ops.stream()
         lib, ng = self.lib, GP.ng
         prog = GP.eng[0].prog
-        B, (D, H, W) = GP.B, GP.dims
-        _lib.check(lib.mms_dn121_forward_group(ng, GP.ws, B, D, H, W, GP.x, GP.params, GP.buffers, GP.out, GP.ld,
-                                               1 if train else 0, st), "mms_dn121_forward_group")
+        if GP.has_enc:
+            B, (D, H, W) = GP.B, GP.dims
+            _lib.check(lib.mms_dn121_forward_group(ng, GP.ws, B, D, H, W, GP.x, GP.params, GP.buffers, GP.out, GP.ld,
+                                                   1 if train else 0, st), "mms_dn121_forward_group")
         lf = GP.lin_fwd[train]
         n_pre = prog["n_pre"]
         for i in range(n_pre):
             _lib.check(lib.mms_linear_fwd_group(lf[i], ng, st), "mms_linear_fwd_group")
         if GP.gate is not None:
             _lib.check(lib.mms_gate_fwd_group(GP.gate, ng, st), "mms_gate_fwd_group")
+        if GP.mix is not None:
+            _lib.check(lib.mms_missing_mix_fwd_group(GP.mix, ng, st), "mms_missing_mix_fwd_group")
         for i in range(n_pre, len(lf)):
             _lib.check(lib.mms_linear_fwd_group(lf[i], ng, st), "mms_linear_fwd_group")
 
@@ -132,7 +138,6 @@ class FoldGroupEngine:
         st = ops.stream()
         lib, ng = self.lib, GP.ng
         prog = GP.eng[0].prog
-        B, (D, H, W) = GP.B, GP.dims
         self._zero(GP)
         self._forward(GP, True)
         _lib.check(lib.mms_cox_fwd_bwd_group(GP.cox, ng, st), "mms_cox_fwd_bwd_group")
@@ -141,10 +146,14 @@ class FoldGroupEngine:
             _lib.check(lib.mms_linear_bwd_group(GP.lin_bwd[i], ng, st), "mms_linear_bwd_group")
         if GP.gate is not None:
             _lib.check(lib.mms_gate_bwd_group(GP.gate, ng, st), "mms_gate_bwd_group")
+        if GP.mix is not None:
+            _lib.check(lib.mms_missing_mix_bwd_group(GP.mix, ng, st), "mms_missing_mix_bwd_group")
         for i in range(n_pre - 1, -1, -1):
             _lib.check(lib.mms_linear_bwd_group(GP.lin_bwd[i], ng, st), "mms_linear_bwd_group")
-        _lib.check(lib.mms_dn121_backward_group(ng, GP.ws, B, D, H, W, GP.x, GP.params, GP.dout, GP.ld, GP.grads, st),
-                   "mms_dn121_backward_group")
+        if GP.has_enc:
+            B, (D, H, W) = GP.B, GP.dims
+            _lib.check(lib.mms_dn121_backward_group(ng, GP.ws, B, D, H, W, GP.x, GP.params, GP.dout, GP.ld, GP.grads, st),
+                       "mms_dn121_backward_group")
         ad = GP.adam[bool(skip_if_unusable)]
         _lib.check(lib.mms_grad_sumsq_group(ad, ng, st), "mms_grad_sumsq_group")
         _lib.check(lib.mms_clip_adam_group(ad, ng, st), "mms_clip_adam_group")
@@ -186,10 +195,11 @@ class FoldGroupEngine:
         members = tuple(range(len(self.engines))) if members is None else tuple(members)
         if len(batches) != len(members):
             raise ValueError("one batch per member")
-        ct0 = batches[0]["ct"]
-        B, dims = ct0.shape[0], tuple(ct0.shape[-3:])
+        has_enc = self.engines[0].prog["encoder"] is not None
+        B = batches[0]["rna"].shape[0]
+        dims = tuple(batches[0]["ct"].shape[-3:]) if has_enc else None
         for b in batches:
-            if b["ct"].shape[0] != B or tuple(b["ct"].shape[-3:]) != dims:
+            if b["rna"].shape[0] != B or (has_enc and tuple(b["ct"].shape[-3:]) != dims):
                 raise ValueError("fold-group batches must share one shape; split ragged tails into their own step")
         GP = self.plan(B, dims, members)
         for e, P, b in zip(GP.eng, GP.Ps, batches):
@@ -208,7 +218,8 @@ class FoldGroupEngine:
         idx = torch.as_tensor(indices, dtype=torch.int64)
         if idx.dim() != 2 or idx.shape[0] != len(members):
             raise ValueError("indices must be [len(members)][B]")
-        B, dims = idx.shape[1], tuple(cohort["image"].shape[-3:])
+        B = idx.shape[1]
+        dims = tuple(cohort["image"].shape[-3:]) if self.engines[0].prog["encoder"] is not None else None
         GP = self.plan(B, dims, members)
         key = id(cohort)
         cache = GP.__dict__.setdefault("gather", {})
@@ -242,8 +253,8 @@ class FoldGroupEngine:
     def forward_eval(self, batches, members=None, use_graph=True):
         """Eval-mode forward of every member -> list of (hazard [B] view, gate [B,3] or None) per member."""
         members = tuple(range(len(self.engines))) if members is None else tuple(members)
-        ct0 = batches[0]["ct"]
-        B, dims = ct0.shape[0], tuple(ct0.shape[-3:])
+        B = batches[0]["rna"].shape[0]
+        dims = tuple(batches[0]["ct"].shape[-3:]) if self.engines[0].prog["encoder"] is not None else None
         GP = self.plan(B, dims, members)
         for e, P, b in zip(GP.eng, GP.Ps, batches):
             e.load_batch(P, **b)

@@ -1,8 +1,8 @@
-"""The reference's three survival networks as drop-in nn.Modules whose forward/backward run on the HIP engine.
+"""The reference's survival networks as drop-in nn.Modules whose forward/backward run on the HIP engine.
 
 Constructor signatures, forward signatures, sub-module names (state_dict keys) and parameter creation order are
-the reference's (final_multimodal.py:59-150, partial_modality_training.py:165-277, simple_fusion.py:160-236, MONAI
-branch).  The nn.Sequential containers only own parameters; they are never called.  Parameters stay ordinary
+the reference's (final_multimodal.py:59-150, partial_modality_training.py:165-277, simple_fusion.py:160-236,
+flexible_multimodal.py:157-256, train_rnaseq_only.py:126-151; MONAI branch).  The nn.Sequential containers only own parameters; they are never called.  Parameters stay ordinary
 autograd leaves: `torch.optim.Adam(model.parameters())`, `clip_grad_norm_`, `state_dict()/load_state_dict()` keep
 working (the autograd-compatible path), while `training.train_epoch_*` drive the fused HIP-graph step.
 """
@@ -43,7 +43,7 @@ class _Net(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, model, ct, rna, clinical, mask):
         eng = engine_of(model)
-        P = eng.plan(ct.shape[0], tuple(ct.shape[-3:]))
+        P = eng.plan(rna.shape[0], tuple(ct.shape[-3:]) if ct is not None else None)
         eng.load_batch(P, ct, rna, clinical, mask)
         eng._forward(P, model.training)
         ctx.eng, ctx.P, ctx.train = eng, P, model.training
@@ -76,13 +76,13 @@ class _Net(torch.autograd.Function):
 
 
 def _run(model, ct, rna, clinical, mask):
-    if not ct.is_cuda:
+    if not rna.is_cuda or (ct is not None and not ct.is_cuda):
         raise RuntimeError("%s (HIP): inputs must be on an MI355X device; there is no CPU fallback" % type(model).__name__)
     anchor = next(model.parameters())
     if torch.is_grad_enabled() and model.training:
         return _Net.apply(anchor, model, ct, rna, clinical, mask)
     eng = engine_of(model)
-    P = eng.plan(ct.shape[0], tuple(ct.shape[-3:]))
+    P = eng.plan(rna.shape[0], tuple(ct.shape[-3:]) if ct is not None else None)
     eng.load_batch(P, ct, rna, clinical, mask)
     eng._forward(P, model.training)
     return P.buf["hz"][:, 0].clone(), (P.gatew.clone() if P.gate is not None else None)
@@ -139,3 +139,47 @@ class SimpleFusionModel(nn.Module):
 
     def forward(self, image, rnaseq):
         return _run(self, image, rnaseq, None, None)[0]
+
+
+class FlexibleMultimodalModel(nn.Module):
+    """flexible_multimodal.py:157-256: SimpleFusion heads on [image | rna] features with a LEARNABLE bias standing in for a
+    missing modality (mask (B,2) = [has_image, has_rnaseq]).  Parameter creation order (image_encoder, rna_encoder, the two
+    biases via torch.randn, fusion) is the reference's, so a seeded construction draws the same initial weights."""
+
+    def __init__(self, rna_dim=5005, img_feature_dim=128, rna_feature_dim=256):
+        super().__init__()
+        if img_feature_dim != 128 or rna_feature_dim != 256:
+            raise ValueError("kernel widths are fixed to the reference defaults (img 128, rna 256)")
+        self.image_encoder = _ct_encoder(img_feature_dim)
+        self.use_monai = USE_MONAI
+        if USE_MONAI:
+            self.image_pool = nn.AdaptiveAvgPool3d(1)
+        self.rna_encoder = nn.Sequential(
+            nn.Linear(rna_dim, 1024), nn.BatchNorm1d(1024), nn.ReLU(), nn.Dropout(0.3),
+            nn.Linear(1024, 512), nn.BatchNorm1d(512), nn.ReLU(), nn.Dropout(0.3),
+            nn.Linear(512, rna_feature_dim), nn.ReLU())
+        self.missing_image_bias = nn.Parameter(torch.randn(img_feature_dim))
+        self.missing_rna_bias = nn.Parameter(torch.randn(rna_feature_dim))
+        self.fusion = nn.Sequential(
+            nn.Linear(img_feature_dim + rna_feature_dim, 256), nn.BatchNorm1d(256), nn.ReLU(), nn.Dropout(0.3),
+            nn.Linear(256, 128), nn.ReLU(), nn.Dropout(0.2), nn.Linear(128, 1))
+
+    def forward(self, image, rnaseq, mask):
+        return _run(self, image, rnaseq, None, mask)[0]
+
+
+class RNASeqSurvivalModel(nn.Module):
+    """train_rnaseq_only.py:126-151: MLP 5005 -> 1024 -> 512 -> 256 -> 1 ([Linear, BatchNorm1d, ReLU, Dropout(0.3)] per hidden
+    layer); forward returns the (B, 1) log-hazard like the reference."""
+
+    def __init__(self, input_dim=5005, hidden_dims=[1024, 512, 256]):
+        super().__init__()
+        layers, in_dim = [], input_dim
+        for h in hidden_dims:
+            layers.extend([nn.Linear(in_dim, h), nn.BatchNorm1d(h), nn.ReLU(), nn.Dropout(0.3)])
+            in_dim = h
+        layers.append(nn.Linear(in_dim, 1))
+        self.mlp = nn.Sequential(*layers)
+
+    def forward(self, rnaseq):
+        return _run(self, None, rnaseq, None, None)[0].unsqueeze(1)

@@ -193,6 +193,79 @@ def validate_simple(model, loader, device):
     return (total / nb if nb > 0 else 0.0), c
 
 
+# ---- flexible_multimodal.py (rows of SURVEY section 8f: same kernels, learnable missing-modality bias) ---------------------
+def train_epoch_flexible(model, loader, optimizer, device):
+    """flexible_multimodal.py:262-303: the simple_fusion loop with the (B,2) modality mask as a third model input."""
+    if not isinstance(optimizer, FusedOptimizer):
+        raise TypeError("train_epoch_flexible drives the fused step; pass a FusedOptimizer")
+    model.train()
+    eng = optimizer.engine
+    eng.reset_epoch_stats()
+    for batch in loader:
+        valid = torch.as_tensor(batch['has_survival'], dtype=torch.float32)
+        if float(valid.sum()) < 2:
+            continue                                   # :276-277
+        eng.train_step(batch['image'], batch['rnaseq'], mask=batch['mask'][:, :2], time=batch['time'].reshape(-1),
+                       event=batch['event'].reshape(-1), valid=valid, skip_if_unusable=True)     # :287-288
+    st = eng.epoch_stats()
+    return st["sum_loss"] / st["n_usable"] if st["n_usable"] > 0 else 0.0
+
+
+def validate_flexible(model, loader, device):
+    """flexible_multimodal.py:305-357."""
+    model.eval()
+    eng = engine_of(model)
+    total, nb, hs, ts, es = 0.0, 0, [], [], []
+    for batch in loader:
+        smask = torch.as_tensor(batch['has_survival'], dtype=torch.bool, device=device)
+        if int(smask.sum()) < 2:
+            continue
+        time, event = _t(batch['time'].reshape(-1), device), _t(batch['event'].reshape(-1), device)
+        hz, _ = eng.forward_eval(batch['image'], batch['rnaseq'], mask=batch['mask'][:, :2])
+        h, t, e = hz[smask].clone(), time[smask], event[smask].float()
+        if float(e.sum()) == 0:
+            continue
+        total += losses.neg_partial_log_likelihood(h, e, t).item()
+        nb += 1
+        hs.append(h); ts.append(t); es.append(e)
+    if not hs:
+        return 0.0, 0.5
+    c = losses.ConcordanceIndex()(torch.cat(hs), torch.cat(es), torch.cat(ts)).item()
+    return (total / nb if nb > 0 else 0.0), c
+
+
+# ---- train_rnaseq_only.py ------------------------------------------------------------------------------------------------
+def train_epoch_rnaseq(model, loader, optimizer, device):
+    """train_rnaseq_only.py:157-176: NPLL on the whole batch, every batch steps, NO gradient clipping (build the
+    FusedOptimizer with max_norm=0), mean over len(loader)."""
+    if not isinstance(optimizer, FusedOptimizer):
+        raise TypeError("train_epoch_rnaseq drives the fused step; pass a FusedOptimizer(model, adamw=True, max_norm=0)")
+    model.train()
+    eng = optimizer.engine
+    eng.reset_epoch_stats()
+    for batch in loader:
+        eng.train_step(None, batch['rnaseq'], time=batch['time'].reshape(-1), event=batch['event'].reshape(-1),
+                       skip_if_unusable=False)       # a batch without events yields loss 0 / zero gradients, and still steps (:168-172)
+    st = eng.epoch_stats()
+    return st["sum_loss"] / st["n_batches"] if st["n_batches"] > 0 else 0.0
+
+
+def validate_rnaseq(model, loader, device):
+    """train_rnaseq_only.py:178-209."""
+    model.eval()
+    eng = engine_of(model)
+    total, nb, hs, ts, es = 0.0, 0, [], [], []
+    for batch in loader:
+        time, event = _t(batch['time'].reshape(-1), device), _t(batch['event'].reshape(-1), device).float()
+        hz, _ = eng.forward_eval(None, batch['rnaseq'])
+        h = hz.clone()
+        total += losses.neg_partial_log_likelihood(h, event, time).item()
+        nb += 1
+        hs.append(h); ts.append(time); es.append(event)
+    c = losses.ConcordanceIndex()(torch.cat(hs), torch.cat(es), torch.cat(ts)).item()
+    return total / nb, c
+
+
 # ---- K folds in lock-step (fold groups) ------------------------------------------------------------------------------
 # The reference trains its folds one after the other; they are independent, so a FoldGroupEngine advances all of them by
 # one batch with ONE launch sequence (fold_group.py).  Per fold, batch order, skipping rules, loss averaging and return
@@ -202,20 +275,25 @@ def _train_kwargs(style, batch):
     if style == "final":
         label = batch['label']
         return dict(ct=batch['image'], rna=batch['rnaseq'], clinical=batch['clinical'], time=label[:, 0], event=label[:, 1])
+    if style == "rnaseq":
+        return dict(rna=batch['rnaseq'], time=batch['time'].reshape(-1), event=batch['event'].reshape(-1))
     valid = torch.as_tensor(batch['has_survival'], dtype=torch.float32)
     if style == "partial":
         label = batch['label']
         return dict(ct=batch['image'], rna=batch['rnaseq'], clinical=batch['clinical'], mask=batch['mask'], time=label[:, 0],
                     event=label[:, 1], valid=valid)
-    if style == "simple":
+    if style in ("simple", "flexible"):
         if float(valid.sum()) < 2:
-            return None                                      # simple_fusion.py:257-258
-        return dict(ct=batch['image'], rna=batch['rnaseq'], time=batch['time'].reshape(-1), event=batch['event'].reshape(-1),
-                    valid=valid)
+            return None                                      # simple_fusion.py:257-258, flexible_multimodal.py:276-277
+        kw = dict(ct=batch['image'], rna=batch['rnaseq'], time=batch['time'].reshape(-1), event=batch['event'].reshape(-1),
+                  valid=valid)
+        if style == "flexible":
+            kw["mask"] = batch['mask'][:, :2]
+        return kw
     raise ValueError(style)
 
 
-_SKIP_UNUSABLE = {"final": True, "partial": False, "simple": True}
+_SKIP_UNUSABLE = {"final": True, "partial": False, "simple": True, "flexible": True, "rnaseq": False}
 
 
 def _lockstep(loaders, members):
@@ -245,14 +323,14 @@ def train_epoch_lockstep(group, loaders, style, members=None):
         for g, batch in pos.items():
             kw = _train_kwargs(style, batch)
             if kw is not None:
-                by_size.setdefault(int(kw["ct"].shape[0]), []).append((g, kw))
+                by_size.setdefault(int(kw["rna"].shape[0]), []).append((g, kw))
         for items in by_size.values():           # a ragged last batch forms its own (sub-)group step
             group.train_step([kw for _, kw in items], members=tuple(g for g, _ in items),
                              skip_if_unusable=_SKIP_UNUSABLE[style])
     out = []
     for g in members:
         st = group.engines[g].epoch_stats()
-        if style == "final":
+        if style in ("final", "rnaseq"):
             out.append(st["sum_loss"] / st["n_batches"] if st["n_batches"] > 0 else 0)
         elif style == "partial":
             out.append((st["sum_loss"] / st["n_usable"] if st["n_usable"] > 0 else 0,
@@ -276,12 +354,16 @@ def validate_lockstep(group, loaders, style, device, members=None):
                 kw = dict(ct=batch['image'], rna=batch['rnaseq'], clinical=batch['clinical'])
             elif style == "partial":
                 kw = dict(ct=batch['image'], rna=batch['rnaseq'], clinical=batch['clinical'], mask=batch['mask'])
+            elif style == "rnaseq":
+                kw = dict(rna=batch['rnaseq'])
             else:
                 if int(torch.as_tensor(batch['has_survival']).sum()) < 2:
                     continue
                 kw = dict(ct=batch['image'], rna=batch['rnaseq'])
+                if style == "flexible":
+                    kw["mask"] = batch['mask'][:, :2]
             meta[g] = batch
-            by_size.setdefault(int(kw["ct"].shape[0]), []).append((g, kw))
+            by_size.setdefault(int(kw["rna"].shape[0]), []).append((g, kw))
         for items in by_size.values():
             outs = group.forward_eval([kw for _, kw in items], members=tuple(g for g, _ in items))
             for (g, _), (hz, _gate) in zip(items, outs):
@@ -299,6 +381,10 @@ def validate_lockstep(group, loaders, style, device, members=None):
                     if not (h.shape[0] >= 2 and float(e.sum()) > 0):
                         continue
                     a["total"] += losses.cox_loss(h, e, t).item(); a["nb"] += 1
+                elif style == "rnaseq":
+                    t, e = _t(batch['time'].reshape(-1), device), _t(batch['event'].reshape(-1), device).float()
+                    h = hz.clone()
+                    a["total"] += losses.neg_partial_log_likelihood(h, e, t).item(); a["nb"] += 1
                 else:
                     smask = torch.as_tensor(batch['has_survival'], dtype=torch.bool, device=device)
                     time, event = _t(batch['time'].reshape(-1), device), _t(batch['event'].reshape(-1), device)
@@ -311,9 +397,10 @@ def validate_lockstep(group, loaders, style, device, members=None):
     for g in members:
         a = acc[g]
         if not a["hs"]:
-            out.append((0.0 if style == "simple" else 0, 0.5))
+            out.append((0.0 if style in ("simple", "flexible", "rnaseq") else 0, 0.5))
             continue
         H, E, T = torch.cat(a["hs"]), torch.cat(a["es"]), torch.cat(a["ts"])
-        c = losses.ConcordanceIndex()(H, E, T).item() if style == "simple" else losses.calculate_cindex(H, E, T)
+        c = (losses.ConcordanceIndex()(H, E, T).item() if style in ("simple", "flexible", "rnaseq")
+             else losses.calculate_cindex(H, E, T))
         out.append((a["total"] / a["nb"] if a["nb"] > 0 else 0, c))
     return out

@@ -89,3 +89,32 @@ def train_epoch_simple(model, loader, optimizer, device):
         total += loss.item()
         nb += 1
     return total / nb if nb > 0 else 0.0
+
+
+def train_epoch_rnaseq(model, loader, optimizer, device="cpu"):
+    """train_rnaseq_only.py:157-176: NPLL on the whole batch, NO gradient clipping, mean over len(loader)."""
+    model.train()
+    total = 0.0
+    for batch in loader:
+        rnaseq = batch['rnaseq'].to(device)
+        time, event = batch['time'].squeeze().to(device), batch['event'].squeeze().to(device)
+        optimizer.zero_grad()
+        loss = neg_partial_log_likelihood(model(rnaseq).squeeze(), event, time)
+        loss.backward()
+        optimizer.step()
+        total += loss.item()
+    return total / len(loader)
+
+
+def validate_rnaseq(model, loader, device="cpu"):
+    """train_rnaseq_only.py:178-209."""
+    model.eval()
+    total, hs, ts, es = 0.0, [], [], []
+    with torch.no_grad():
+        for batch in loader:
+            rnaseq = batch['rnaseq'].to(device)
+            time, event = batch['time'].squeeze().to(device), batch['event'].squeeze().to(device)
+            hz = model(rnaseq).squeeze()
+            total += neg_partial_log_likelihood(hz, event, time).item()
+            hs.extend(hz.cpu().numpy()); ts.extend(time.cpu().numpy()); es.extend(event.cpu().numpy())
+    return total / len(loader), concordance_index_np(hs, es, ts)

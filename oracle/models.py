@@ -118,3 +118,54 @@ class SimpleFusionModel(nn.Module):
         img_feat = self.image_encoder(image).view(B, -1)
         fused = torch.cat([rna_feat, img_feat], dim=1)         # :233
         return self.fusion(fused).squeeze(1)
+
+
+class FlexibleMultimodalModel(nn.Module):
+    """flexible_multimodal.py:157-256 -- SimpleFusion-style heads, features ordered [image | rna] (:252), a learnable
+    bias replaces a missing modality's features (:205-206, :243-250).  Creation order: image_encoder, rna_encoder,
+    missing_image_bias, missing_rna_bias (torch.randn), fusion."""
+
+    def __init__(self, rna_dim=5005, img_feature_dim=128, rna_feature_dim=256, use_monai=True):
+        super().__init__()
+        if use_monai:
+            self.image_encoder = DenseNet121(spatial_dims=3, in_channels=1, out_channels=img_feature_dim,
+                                             pretrained=False)
+            self.use_monai = True
+            self.image_pool = nn.AdaptiveAvgPool3d(1)
+        else:
+            self.image_encoder = _fallback_encoder(img_feature_dim)
+            self.use_monai = False
+        self.rna_encoder = nn.Sequential(
+            nn.Linear(rna_dim, 1024), nn.BatchNorm1d(1024), nn.ReLU(), nn.Dropout(0.3),
+            nn.Linear(1024, 512), nn.BatchNorm1d(512), nn.ReLU(), nn.Dropout(0.3),
+            nn.Linear(512, rna_feature_dim), nn.ReLU())
+        self.missing_image_bias = nn.Parameter(torch.randn(img_feature_dim))
+        self.missing_rna_bias = nn.Parameter(torch.randn(rna_feature_dim))
+        self.fusion = nn.Sequential(
+            nn.Linear(img_feature_dim + rna_feature_dim, 256), nn.BatchNorm1d(256), nn.ReLU(), nn.Dropout(0.3),
+            nn.Linear(256, 128), nn.ReLU(), nn.Dropout(0.2), nn.Linear(128, 1))
+
+    def forward(self, image, rnaseq, mask):
+        B = image.size(0)
+        img_feat = self.image_encoder(image).view(B, -1)
+        rna_feat = self.rna_encoder(rnaseq)
+        img_mask, rna_mask = mask[:, 0:1], mask[:, 1:2]
+        img_feat = img_feat * img_mask + self.missing_image_bias.unsqueeze(0) * (1 - img_mask)      # :249
+        rna_feat = rna_feat * rna_mask + self.missing_rna_bias.unsqueeze(0) * (1 - rna_mask)        # :250
+        return self.fusion(torch.cat([img_feat, rna_feat], dim=1)).squeeze(1)
+
+
+class RNASeqSurvivalModel(nn.Module):
+    """train_rnaseq_only.py:126-151 -- MLP over RNA-seq only; returns (B, 1)."""
+
+    def __init__(self, input_dim=5005, hidden_dims=[1024, 512, 256]):
+        super().__init__()
+        layers, in_dim = [], input_dim
+        for h in hidden_dims:
+            layers.extend([nn.Linear(in_dim, h), nn.BatchNorm1d(h), nn.ReLU(), nn.Dropout(0.3)])
+            in_dim = h
+        layers.append(nn.Linear(in_dim, 1))
+        self.mlp = nn.Sequential(*layers)
+
+    def forward(self, rnaseq):
+        return self.mlp(rnaseq)

@@ -70,6 +70,7 @@ def harvest():
     # train_epoch/validate sit after the CSV read (:238-305): exec'd by line range into the same namespace
     _exec_lines(f"{REF}/final_multimodal.py", [(238, 305)], fm)
     rn = _exec_until_data(f"{REF}/train_rnaseq_only.py")
+    # train_rnaseq_only.py defines its model and train_epoch/validate before the data access: rn holds RNASeqSurvivalModel too
     base = {"torch": torch, "nn": nn, "np": np, "USE_MONAI": False, "USE_TORCHSURV": False}
     pm = _exec_lines(f"{REF}/partial_modality_training.py", [(165, 331)], dict(base))
     sf = _exec_lines(f"{REF}/simple_fusion.py", [(46, 73), (160, 236)], dict(base))
@@ -269,6 +270,88 @@ def gen_models(fm, pm, sf):
     print("g3_models done:", len(out), "arrays")
 
 
+def gen_extra_models(rn):
+    """g6: RNASeqSurvivalModel (train_rnaseq_only.py:126-151, harvested whole) and FlexibleMultimodalModel
+    (flexible_multimodal.py:157-256, class block exec'd by line range with USE_MONAI = False: SimpleITK is imported at :38,
+    before any class exists).  Dropout forced to 0; weights from torch.manual_seed construction; small variants store the
+    full state_dict and gradients, default-width variants only outputs and gradient norms."""
+    out = {}
+    fx = _exec_lines(f"{REF}/flexible_multimodal.py", [(157, 256)], {"torch": torch, "nn": nn, "np": np, "USE_MONAI": False})
+    for tag, seed, B, rna_dim, vol in (("small", 21, 6, 40, (16, 16, 8)), ("full", 22, 16, 5005, (32, 32, 16))):
+        rng = np.random.default_rng(300 + seed)
+        ct = rng.random((B, 1) + vol, dtype=np.float32)
+        rna = rng.normal(0, 1, (B, rna_dim)).astype(np.float32)
+        h0, e, t = surv_batch(rng, B, "mixed")
+        mask = (rng.random((B, 2)) < 0.6).astype(np.float32)
+        mask[0] = (1, 1); mask[1] = (0, 1); mask[2] = (1, 0); mask[3] = (0, 0)
+        out[f"{tag}_e"], out[f"{tag}_t"], out[f"{tag}_mask2"] = e, t, mask
+        if tag == "small":
+            out["small_ct"], out["small_rna"] = ct, rna
+        tct, trna, te, tt, tmask = torch.tensor(ct), torch.tensor(rna), torch.tensor(e), torch.tensor(t), torch.tensor(mask)
+        # ---- RNASeqSurvivalModel ----
+        torch.manual_seed(seed)
+        m = rn["RNASeqSurvivalModel"](input_dim=rna_dim) if tag == "full" else rn["RNASeqSurvivalModel"](input_dim=rna_dim, hidden_dims=[48, 32, 16])
+        _zero_dropout(m)
+        sd0 = {k: v.detach().numpy().copy() for k, v in m.state_dict().items()}
+        m.eval()
+        with torch.no_grad():
+            out[f"{tag}_rs_eval"] = m(trna).squeeze().numpy()
+        m.train()
+        hz = m(trna).squeeze()
+        loss = rn["neg_partial_log_likelihood"](hz, te.long(), tt)
+        loss.backward()
+        out[f"{tag}_rs_train"], out[f"{tag}_rs_loss"] = hz.detach().numpy(), np.float32(loss.item())
+        g = _grads(m)
+        for k in g:
+            out[f"{tag}_rs_gnorm/{k}"] = np.float64(np.linalg.norm(g[k].astype(np.float64)))
+        if tag == "small":
+            for k in sd0:
+                out[f"small_rs_sd/{k}"] = sd0[k]
+            for k in g:
+                out[f"small_rs_grad/{k}"] = g[k]
+        # ---- FlexibleMultimodalModel (fallback encoder branch) ----
+        torch.manual_seed(seed)
+        m = fx["FlexibleMultimodalModel"](rna_dim=rna_dim)
+        _zero_dropout(m)
+        sd0 = {k: v.detach().numpy().copy() for k, v in m.state_dict().items()}
+        m.eval()
+        with torch.no_grad():
+            out[f"{tag}_fx_eval"] = m(tct, trna, tmask).numpy()
+        m.train()
+        hz = m(tct, trna, tmask)
+        loss = rn["neg_partial_log_likelihood"](hz, te.long(), tt)
+        loss.backward()
+        out[f"{tag}_fx_train"], out[f"{tag}_fx_loss"] = hz.detach().numpy(), np.float32(loss.item())
+        g = _grads(m)
+        for k in g:
+            out[f"{tag}_fx_gnorm/{k}"] = np.float64(np.linalg.norm(g[k].astype(np.float64)))
+        if tag == "small":     # a few whole tensors (creation-order / RNG pin + element-wise gradients); the rest as norms above
+            keep = [k for k in sd0 if k.startswith("missing_") or k.startswith("fusion.7") or k.startswith("rna_encoder.8.bias")
+                    or k.startswith("image_encoder.0.")]
+            for k in keep:
+                out[f"small_fx_sd/{k}"] = sd0[k]
+                if k in g:
+                    out[f"small_fx_grad/{k}"] = g[k]
+    # one epoch of the reference's own train_epoch (train_rnaseq_only.py:157-176: no clipping, loss / len(loader))
+    rng = np.random.default_rng(77)
+    n, B, rna_dim = 40, 8, 24
+    rna = rng.normal(0, 1, (n, rna_dim)).astype(np.float32)
+    t = (rng.exponential(1000.0, n) + 1 + np.arange(n) * 1e-3).astype(np.float32)
+    e = (rng.random(n) < 0.6).astype(np.int64)
+    torch.manual_seed(5)
+    m = rn["RNASeqSurvivalModel"](input_dim=rna_dim, hidden_dims=[32, 16])
+    _zero_dropout(m)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-3)
+    loader = [dict(rnaseq=torch.tensor(rna[i:i + B]), time=torch.tensor(t[i:i + B]).view(-1, 1),
+                   event=torch.tensor(e[i:i + B]).view(-1, 1)) for i in range(0, n, B)]
+    losses = [rn["train_epoch"](m, loader, opt, torch.device("cpu")) for _ in range(3)]
+    vl, vc = rn["validate"](m, loader, torch.device("cpu"))
+    out["ep_rna"], out["ep_t"], out["ep_e"] = rna, t, e.astype(np.float32)
+    out["ep_losses"], out["ep_val"] = np.array(losses, np.float64), np.array([vl, vc], np.float64)
+    np.savez_compressed(f"{OUT}/g6_extra_models.npz", **out)
+    print("g6_extra_models done:", len(out), "arrays")
+
+
 def gen_epoch(fm):
     """G5: one epoch of the reference's own train_epoch/validate (final_multimodal.py:238-305) on a seeded
     synthetic 88-patient cohort, config-1 style (small volume so it runs in seconds; dropout ACTIVE, so the
@@ -301,7 +384,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     fm, rn, pm, sf = harvest()
     for name, ns, keys in (("final_multimodal", fm, ["MultiModalSurvivalNet", "cox_loss", "calculate_cindex", "train_epoch", "validate"]),
-                           ("train_rnaseq_only", rn, ["neg_partial_log_likelihood", "ConcordanceIndex"]),
+                           ("train_rnaseq_only", rn, ["neg_partial_log_likelihood", "ConcordanceIndex", "RNASeqSurvivalModel", "train_epoch", "validate"]),
                            ("partial_modality_training", pm, ["PartialModalityNet", "cox_loss", "gate_entropy_loss"]),
                            ("simple_fusion", sf, ["SimpleFusionModel", "neg_partial_log_likelihood", "ConcordanceIndex"])):
         missing = [k for k in keys if k not in ns]
@@ -309,4 +392,5 @@ if __name__ == "__main__":
     gen_cox(fm, rn, sf)
     gen_cindex(rn, sf)
     gen_models(fm, pm, sf)
+    gen_extra_models(rn)
     gen_epoch(fm)

@@ -190,3 +190,76 @@ def test_densenet121_3d_structure():
     assert sd["features.denseblock3.denselayer24.layers.norm1.weight"].shape == (992,)
     assert sd["features.transition1.conv.weight"].shape == (128, 256, 1, 1, 1)
     assert tuple(m(torch.rand(2, 1, 32, 32, 32)).shape) == (2, 128)
+
+
+@pytest.mark.parametrize("tag,B,rna_dim,vol,seed", [("small", 6, 40, (16, 16, 8), 21), ("full", 16, 5005, (32, 32, 16), 22)])
+def test_extra_models_match_reference(tag, B, rna_dim, vol, seed):
+    """RNASeqSurvivalModel (train_rnaseq_only.py) and FlexibleMultimodalModel (flexible_multimodal.py, fallback encoder)
+    against outputs of the reference's own classes (g6_extra_models.npz)."""
+    z = np.load(f"{G}/g6_extra_models.npz")
+    rng = np.random.default_rng(300 + seed)
+    ct = torch.tensor(rng.random((B, 1) + vol, dtype=np.float32))
+    rna = torch.tensor(rng.normal(0, 1, (B, rna_dim)).astype(np.float32))
+    if tag == "small":
+        np.testing.assert_array_equal(ct.numpy(), z["small_ct"]); np.testing.assert_array_equal(rna.numpy(), z["small_rna"])
+    e, t, mask = torch.tensor(z[f"{tag}_e"]), torch.tensor(z[f"{tag}_t"]), torch.tensor(z[f"{tag}_mask2"])
+
+    def check(m, pre, fwd):
+        refs = {k: float(z[f"{tag}_{pre}_gnorm/{k}"]) for k, _ in m.named_parameters()}
+        gmax = max(refs.values())
+        m.eval()
+        with torch.no_grad():
+            np.testing.assert_allclose(fwd(m).numpy(), z[f"{tag}_{pre}_eval"], rtol=1e-5, atol=1e-6)
+        m.train()
+        hz = fwd(m)
+        loss = OL.neg_partial_log_likelihood(hz, e.bool(), t)
+        loss.backward()
+        np.testing.assert_allclose(hz.detach().numpy(), z[f"{tag}_{pre}_train"], rtol=1e-5, atol=1e-6)
+        assert loss.item() == pytest.approx(float(z[f"{tag}_{pre}_loss"]), rel=1e-5)
+        for k, p in m.named_parameters():
+            got = float(np.linalg.norm(p.grad.numpy().astype(np.float64)))
+            if refs[k] < 1e-5 * gmax:
+                assert got < 1e-4 * gmax, (pre, k)
+            else:
+                assert got == pytest.approx(refs[k], rel=1e-4), (pre, k)
+        if tag == "small":
+            for key in [k for k in z.files if k.startswith(f"small_{pre}_grad/")]:
+                k = key.split("/", 1)[1]
+                ref = z[key]
+                if float(np.abs(ref).max()) >= 1e-5 * gmax:
+                    np.testing.assert_allclose(dict(m.named_parameters())[k].grad.numpy(), ref, rtol=2e-4, atol=1e-6 * gmax, err_msg=k)
+
+    torch.manual_seed(seed)
+    m = OM.RNASeqSurvivalModel(input_dim=rna_dim) if tag == "full" else OM.RNASeqSurvivalModel(input_dim=rna_dim, hidden_dims=[48, 32, 16])
+    _zero_dropout(m)
+    if tag == "small":
+        for k, v in m.state_dict().items():
+            np.testing.assert_array_equal(v.numpy(), z[f"small_rs_sd/{k}"], err_msg=k)
+    check(m, "rs", lambda mm: mm(rna).squeeze())
+
+    torch.manual_seed(seed)
+    m = OM.FlexibleMultimodalModel(rna_dim=rna_dim, use_monai=False)
+    _zero_dropout(m)
+    if tag == "small":      # creation order (encoder, rna_encoder, randn biases, fusion) reproduces the reference's draw
+        sd = m.state_dict()
+        for key in [k for k in z.files if k.startswith("small_fx_sd/")]:
+            np.testing.assert_array_equal(sd[key.split("/", 1)[1]].numpy(), z[key], err_msg=key)
+    check(m, "fx", lambda mm: mm(ct, rna, mask))
+
+
+def test_rnaseq_epoch_matches_reference():
+    """train_epoch / validate of train_rnaseq_only.py (no gradient clipping, loss / len(loader)): 3 epochs of the oracle loop."""
+    from oracle import loops as LO
+    z = np.load(f"{G}/g6_extra_models.npz")
+    rna, t, e = z["ep_rna"], z["ep_t"], z["ep_e"]
+    B = 8
+    torch.manual_seed(5)
+    m = OM.RNASeqSurvivalModel(input_dim=rna.shape[1], hidden_dims=[32, 16])
+    _zero_dropout(m)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-3)
+    loader = [dict(rnaseq=torch.tensor(rna[i:i + B]), time=torch.tensor(t[i:i + B]).view(-1, 1),
+                   event=torch.tensor(e[i:i + B]).long().view(-1, 1)) for i in range(0, len(t), B)]
+    losses = [LO.train_epoch_rnaseq(m, loader, opt) for _ in range(3)]
+    np.testing.assert_allclose(losses, z["ep_losses"], rtol=2e-5)
+    vl, vc = LO.validate_rnaseq(m, loader)
+    np.testing.assert_allclose([vl, vc], z["ep_val"], rtol=2e-5)
