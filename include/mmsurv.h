@@ -420,6 +420,14 @@ int mms_dn121_backward_mt(void* ws, int B, int D, int H, int W, const float* x, 
                           const float* dout, int lddout, void* const* grads, hipStream_t s, hipStream_t side,
                           hipEvent_t ev_fork, hipEvent_t ev_join);
 
+/* ---- preprocessing upstream of the path, on the GPU (replaces per-item numpy/scipy on the CPU) ----
+ * mms_ct_preprocess: (x - min) / (max - min + 1e-8) and scipy.ndimage.zoom(order=1) to the network grid
+ *   (R/scripts/training/partial_modality_training.py:94-109, simple_fusion.py:117-134); scratch >= 512 floats.
+ * mms_rna_log_zscore: log2(count + 1), then per-gene StandardScaler over the n samples
+ *   (R/scripts/preprocessing/preprocess_genomic.py:108-117). */
+int mms_ct_preprocess(const float* x, int inD, int inH, int inW, float* out, int oD, int oH, int oW, float* scratch, hipStream_t s);
+int mms_rna_log_zscore(const float* counts, float* out, int n, int g, hipStream_t s);
+
 /* =========================== fold groups =====================================================================
  * The reference trains its K fold models one after the other (R/scripts/training/final_multimodal.py:316-402,
  * partial_modality_training.py:482-560, simple_fusion.py:318-436); they are independent, so this library can advance

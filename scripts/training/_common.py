@@ -34,6 +34,18 @@ def save_json(path, obj):
         json.dump(obj, f, indent=2)
 
 
+def load_or_make_cohort(device, **make_kw):
+    """The reference reads data/processed/{full_matching_table.csv, rnaseq_normalized_mapped.csv} relative to the cwd.  If that
+    contract is present (e.g. written by cohort_io.write_cohort, or real data converted to .npy volumes) it is loaded ONCE
+    into an HBM-resident store with the volume preprocessing done on the GPU; otherwise a seeded synthetic cohort is built."""
+    from multimodal_survival_prediction_amd import cohort_io, data
+    root = os.environ.get("MMS_DATA_ROOT", ".")
+    if os.path.exists(os.path.join(root, cohort_io.TABLE)):
+        print(f"loading cohort from {os.path.join(root, cohort_io.TABLE)}", flush=True)
+        return cohort_io.load_cohort(root, device, target_size=make_kw.get("dims", (64, 64, 32)))
+    return data.cohort_to(data.make_cohort(**make_kw), device)
+
+
 def lockstep_enabled(n_local_folds):
     """Folds of this rank train in lock-step as one fold group (MMS_LOCKSTEP=0 restores fold-after-fold order)."""
     return env_int("MMS_LOCKSTEP", 1) != 0 and 2 <= n_local_folds <= 10

@@ -103,3 +103,23 @@ def test_no_cpu_fallback():
     src = "".join(open(os.path.join(os.path.dirname(pkg.__file__), f)).read()
                   for f in os.listdir(os.path.dirname(pkg.__file__)) if f.endswith(".py"))
     assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_cohort_contract_on_disk(tmp_path):
+    """write_cohort lays down the reference's data/processed contract (create_full_matching_table.py:124-134 columns;
+    patient-indexed rnaseq CSV); read_tables validates it.  Host side only (the volume preprocessing needs the GPU)."""
+    import numpy as np
+    from multimodal_survival_prediction_amd import cohort_io, data
+    c = data.make_cohort(n=9, dims=(32, 32, 32), rna_dim=12, seed=2, complete=False, counts=dict(n=9, imaging=5, rnaseq=6, clinical=8, survival=4))
+    cohort_io.write_cohort(str(tmp_path), c, native_dims=(10, 12, 9))
+    mt, rn = cohort_io.read_tables(str(tmp_path))
+    assert list(mt.columns) == cohort_io.COLUMNS and len(mt) == 9
+    assert int(mt["has_imaging"].sum()) == 5 and int(mt["has_rnaseq"].sum()) == 6 and int(mt["has_survival"].sum()) == 4
+    assert rn.shape == (6, 12) and set(rn.index) == set(mt.loc[mt["has_rnaseq"], "patient_id"])
+    for flag, path in zip(mt["has_imaging"], mt["nifti_path"]):
+        assert isinstance(path, str) == bool(flag)
+        if flag:
+            assert np.load(path).shape == (10, 12, 9)
+    assert mt.loc[~mt["has_survival"], "survival_time"].isna().all()
+    ages = mt.loc[mt["has_clinical"], "age"].to_numpy()
+    assert ((ages >= 30) & (ages <= 90)).all()
