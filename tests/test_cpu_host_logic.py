@@ -123,3 +123,21 @@ def test_cohort_contract_on_disk(tmp_path):
     assert mt.loc[~mt["has_survival"], "survival_time"].isna().all()
     ages = mt.loc[mt["has_clinical"], "age"].to_numpy()
     assert ((ages >= 30) & (ages <= 90)).all()
+
+
+def test_final_comparison_collects_and_tests(tmp_path):
+    """scripts/training/final_comparison.py: cv_results.json collection, best model, paired t-test, results.json schema."""
+    import importlib.util, json, os
+    spec = importlib.util.spec_from_file_location("final_comparison", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                   "scripts", "training", "final_comparison.py"))
+    fc = importlib.util.module_from_spec(spec); spec.loader.exec_module(fc)
+    vals = {"results/rnaseq_only": [0.70, 0.66, 0.72], "results/simple_fusion": [0.61, 0.60, 0.65], "results/final": [0.5, 0.6, 0.55, 0.58, 0.52]}
+    for d, v in vals.items():
+        os.makedirs(tmp_path / d)
+        json.dump({"c_index_mean": float(sum(v) / len(v)), "c_index_std": 0.02,
+                   "fold_results": [{"fold": i + 1, "best_c_index": x, "val_size": 10} for i, x in enumerate(v)]}, open(tmp_path / d / "cv_results.json", "w"))
+    out = fc.main(str(tmp_path))
+    assert out["best_model"]["name"] == "RNA-Only"
+    assert set(out["paired_t_tests"]) == {"Simple Fusion"}            # the 5-fold model has a different fold count: skipped (:74)
+    assert out["paired_t_tests"]["Simple Fusion"]["p"] < 0.05
+    assert json.load(open(tmp_path / "results" / "final_comparison" / "results.json"))["model_results"]["Final Multimodal"]["n_patients"] == 50
