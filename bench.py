@@ -262,6 +262,27 @@ def main():
             cv5(i)
         torch.cuda.synchronize(); D.barrier()
         dt5 = D.max_over_ranks(time.perf_counter() - t0, dev) / (5 * n5)
+    # validation (reported separately): eval-mode forwards of the same models, same grouping/concurrency
+    val_rate = None
+    if G > 1:
+        for e_ in engines:
+            e_.model.eval()
+        nv = max(args.steps // (F * G), 4)
+
+        def vrun(n):
+            for u in range(n):
+                f = u % F
+                with torch.cuda.stream(streams[f]):
+                    bs = [batch_of(f * G + g, u // F) for g in range(G)]
+                    groups[f].forward_eval([dict(ct=b["ct"], rna=b["rna"], clinical=b["clinical"]) for b in bs])
+        vrun(2 * F)
+        torch.cuda.synchronize(); D.barrier()
+        t0 = time.perf_counter()
+        vrun(nv)
+        torch.cuda.synchronize(); D.barrier()
+        val_rate = world * nv * G * B / D.max_over_ranks(time.perf_counter() - t0, dev)
+        for e_ in engines:
+            e_.model.train()
     stats = engines[0].epoch_stats()
 
     if rank == 0:
@@ -275,7 +296,8 @@ def main():
                        "global_batch": world * B, "parallelism": (f"ddp x{world} (flat gradient all-reduce per step, local BN + local Cox risk set)" if ddp else
                                        f"kfold-shard x{world} ranks x {F} concurrent groups x {G} lock-step fold models per GPU (one stream + step graph per group, no collective)"),
                        "concurrent_folds": F, "fold_group": G, "fold_models_in_flight": F * G,
-                       "one_cv_5_lockstep_patients_per_s": (world * B / dt5) if dt5 else None, "single_chain_patients_per_s": world * B / dt1, "single_chain_ms_per_step": dt1 * 1e3,
+                       "one_cv_5_lockstep_patients_per_s": (world * B / dt5) if dt5 else None,
+                       "validation_patients_per_s": val_rate, "single_chain_patients_per_s": world * B / dt1, "single_chain_ms_per_step": dt1 * 1e3,
                        "hip_graph": not args.no_graph, "mean_train_loss": stats["sum_loss"] / max(stats["n_batches"], 1)},
         }
         avg_t, avg_f = measure_dominant_kernel(B, dims, dev, G)
