@@ -53,7 +53,8 @@ def measure_dominant_kernel(B, dims, device, G=1, reps=20):
     for i, (layers, _) in enumerate(BLOCKS):
         gd = (D // 4 >> i, H // 4 >> i, W // 4 >> i)
         M = B * gd[0] * gd[1] * gd[2]
-        ms = (M + 511) // 512 if M > 1024 else max((M + 127) // 128, 1)        # dn_net.hip: ms3
+        rows, rows_s = (1024, 256) if G >= 4 else (512, 128)                     # dn_net.hip: ms3
+        ms = (M + rows - 1) // rows if M > 1024 else max((M + rows_s - 1) // rows_s, 1)
         coords = ops.init_coords(B, gd, device)
         keep, blocks = [], []
         for _ in range(G):

@@ -231,7 +231,7 @@ static int split_target(int ng) {     // measured: 864 for one model (27-way spl
 }
 static int conv3_nsplit(int M, int ng, long cap_rows) {
     const long tiles = (long)((M + 31) / 32) * ng;
-    if (tiles >= 256) return 1;
+    if (tiles >= 256 && tiles >= split_target(ng)) return 1;
     long ns = (split_target(ng) + tiles - 1) / tiles;
     if (ns > 27) ns = 27;
     if (ns < 1) ns = 1;
@@ -373,8 +373,11 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
             Conv1BwdP c1[MMS_MAX_GROUP];
             BnBwdApplyP ap[MMS_MAX_GROUP];
             const int ns3 = conv3_nsplit(M, ng, P.partial_rows);
-            static const int rows3 = getenv("MMS_MS3_ROWS") ? atoi(getenv("MMS_MS3_ROWS")) : 512;
-            int ms3 = M > 1024 ? (M + rows3 - 1) / rows3 : (M + 127) / 128; if (ms3 < 1) ms3 = 1;
+            // rows per weight-gradient workgroup: every chunk flushes 27 x 16 KB of fp32 atomics, so groups (which bring their own
+            // parallelism) take chunks twice as long -- half the fabric writes (PMC WRITE_SIZE) for the same FLOPs
+            const char* e3 = getenv("MMS_MS3_ROWS");
+            const int rows3 = e3 ? atoi(e3) : (ng >= 4 ? 1024 : 512), rows3s = e3 ? 128 : (ng >= 4 ? 256 : 128);
+            int ms3 = M > 1024 ? (M + rows3 - 1) / rows3 : (M + rows3s - 1) / rows3s; if (ms3 < 1) ms3 = 1;
             int ms1 = M > 1024 ? M / 256 : M / 128; if (ms1 < 1) ms1 = 1; if (ms1 > 32) ms1 = 32;
             { const char* e = getenv("MMS_MS1_DIV"); const int dv = e ? atoi(e) : 1; if (dv > 1 && ng > 1) { ms1 = ms1 / dv; if (ms1 < 1) ms1 = 1; } }
             FOR_G {

@@ -12,7 +12,8 @@ G = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 lib, S = _lib.load_library(), _lib.structs()
 gd = (D // 4 >> which, H // 4 >> which, W // 4 >> which)
 M = B * gd[0] * gd[1] * gd[2]
-ms = (M + 511) // 512 if M > 1024 else max((M + 127) // 128, 1)
+rows, rows_s = (1024, 256) if G >= 4 else (512, 128)            # dn_net.hip: ms3
+ms = (M + rows - 1) // rows if M > 1024 else max((M + rows_s - 1) // rows_s, 1)
 g, b = torch.ones(128, device=dev), torch.zeros(128, device=dev)
 coords = ops.init_coords(B, gd, dev)
 keep, blocks = [], []
