@@ -379,7 +379,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
             const int rows3 = e3 ? atoi(e3) : (ng >= 4 ? 1024 : 512), rows3s = e3 ? 128 : (ng >= 4 ? 256 : 128);
             int ms3 = M > 1024 ? (M + rows3 - 1) / rows3 : (M + rows3s - 1) / rows3s; if (ms3 < 1) ms3 = 1;
             int ms1 = M > 1024 ? M / 256 : M / 128; if (ms1 < 1) ms1 = 1; if (ms1 > 32) ms1 = 32;
-            { const char* e = getenv("MMS_MS1_DIV"); const int dv = e ? atoi(e) : 1; if (dv > 1 && ng > 1) { ms1 = ms1 / dv; if (ms1 < 1) ms1 = 1; } }
+            { const char* e = getenv("MMS_MS1_DIV"); const int dv = e ? atoi(e) : (ng >= 4 ? 2 : 1); if (dv > 1) { ms1 = ms1 / dv; if (ms1 < 1) ms1 = 1; } }   // groups: half the chunks (fewer atomic flushes)
             FOR_G {
                 const Ctx& c = cx[g];
                 float* slab = at<float>(c.ws, P.slab[b]);
