@@ -124,6 +124,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--timed-only", action="store_true", help="profiling aid: stop after the timed region (no extra legs, no JSON)")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="profiling aid: run only the roofline leg (the dominant kernel's isolated group launches), so that a "
+                         "rocprofv3 --stats summary of this command holds exactly the launches the live measurement times")
     ap.add_argument("--concurrent-folds", type=int, default=2,
                     help="fold groups trained concurrently per GPU, one HIP stream + step graph each (mode fold)")
     ap.add_argument("--fold-group", type=int, default=10,
@@ -150,6 +153,12 @@ def main():
     from multimodal_survival_prediction_amd.training import FusedOptimizer
 
     B, dims, rna_dim = args.batch, (64, 64, 32), 5005
+    if args.roofline_only:
+        Gr = max(1, min(args.fold_group, 10))
+        avg_t, avg_f = measure_dominant_kernel(B, dims, dev, Gr)
+        print(json.dumps({"kernel": "tile_gemm_kernel<Conv3BwdWOp>", "models_per_launch": Gr, "avg_launch_us": avg_t * 1e6,
+                          "avg_flops_per_launch": avg_f, "achieved_tflops": avg_f / avg_t / 1e12}), flush=True)
+        return
     cohort_cpu = data.make_cohort(n=109, dims=dims, rna_dim=rna_dim, seed=608, complete=True)
     cohort = data.cohort_to(cohort_cpu, dev)                      # resident in HBM before the timed region
     folds = data.kfold_indices(cohort["n"], 5, seed=42)

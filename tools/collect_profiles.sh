@@ -4,6 +4,22 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/prof_final; rm -rf $O; mkdir -
 # 1. kernel-trace summary of the default bench
 rm -rf /tmp/pf1; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf1 -- python3 $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
 cp $(ls /tmp/pf1/*/*_kernel_stats.csv | head -1) $O/kernel_stats.csv
+# 1b. the roofline leg alone: the dominant kernel's isolated group launches (what bench.py times live with HIP events)
+rm -rf /tmp/pf2; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf2 -- python3 $R/bench.py --roofline-only > $O/roofline_leg.json 2> /dev/null
+cp $(ls /tmp/pf2/*/*_kernel_stats.csv | head -1) $O/roofline_leg_kernel_stats.csv
+python3 - $(ls /tmp/pf2/*/*_kernel_trace.csv | head -1) >> $O/roofline_leg.json <<'PY'
+import csv, sys, collections, json
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if 'Conv3BwdWOp' in r['Kernel_Name']]
+by = collections.defaultdict(list)
+for r in rows:
+    by[int(r['Grid_Size_Z'])].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+shapes = sorted(by, reverse=True)                      # block 1..4 (grid z = 27 * msplit * models); blocks 3 and 4 share z = 270
+layers = dict(zip(shapes, (6, 12, 24, 16) if len(shapes) == 4 else (6, 12, 40)))
+avg = {z: sum(v[3:]) / len(v[3:]) / 1e3 for z, v in by.items()}          # skip the 3 warm-up launches per shape
+w = sum(avg[z] * layers[z] for z in shapes) / 58.0
+print(json.dumps({"rocprofv3_kernel_trace_of_this_command": {"per_shape_avg_us": {str(z): round(avg[z], 2) for z in shapes},
+                  "layer_weighted_avg_us": round(w, 2)}}))
+PY
 # 2. PMC passes (kernel-trace only) on the dominant kernel, group launches, per block shape
 for blk in 0 1 2 3; do
   for c in FETCH_SIZE WRITE_SIZE; do
