@@ -440,7 +440,6 @@ extern "C" int mms_conv3_fwd_group(const Conv3FwdP* pp, int ng, hipStream_t s) {
     if (!p.partial && conv3_mt_ok(p.M, ng, p.g)) {
         constexpr int smem_max = (C3M_TM + 2 * C3M_MAXHALO) * C3M_PITCH * (int)sizeof(float);
         int smem = (C3M_TM + 2 * (p.g.W + 1)) * C3M_PITCH * (int)sizeof(float);       // W = 8: 43 KB -> 3 workgroups per CU
-        if (getenv("MMS_C3M_PAD")) smem += atoi(getenv("MMS_C3M_PAD")) * 1024;
         static bool attr_set = false;
         if (!attr_set) {
             hipFuncSetAttribute((const void*)conv3_fwd_mt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem_max);
