@@ -256,13 +256,22 @@ def main():
             dt1 = timed(n1, 1) / n1
     else:
         dt1 = dt / args.steps
-    # one 5-fold cross-validation alone on the GPU: 5 models in lock-step, nothing else running (sub-group of group 0)
+    # one 5-fold cross-validation alone on the GPU: its 5 models and nothing else (members 0-4 of group 0, stepped as two
+    # concurrent lock-step sub-groups of 3 + 2)
     dt5 = None
     if G >= 5:
+        cv5_split = os.environ.get("MMS_CV5_SPLIT", "1") == "1" and F >= 2      # sub-groups (0,1,2) and (3,4) on two streams (+4.5 % over one group of 5)
+
         def cv5(i):
             idx = [orders[g][(i % (len(orders[g]) // B)) * B:][:B] for g in range(5)]
-            groups[0].train_step_indexed(cohort, torch.stack(idx), members=(0, 1, 2, 3, 4), skip_if_unusable=True,
-                                         use_graph=not args.no_graph)
+            if not cv5_split:
+                groups[0].train_step_indexed(cohort, torch.stack(idx), members=(0, 1, 2, 3, 4), skip_if_unusable=True,
+                                             use_graph=not args.no_graph)
+                return
+            for sidx, mem in ((0, (0, 1, 2)), (1 % F, (3, 4))):
+                with torch.cuda.stream(streams[sidx]):
+                    groups[0].train_step_indexed(cohort, torch.stack([idx[m] for m in mem]), members=mem, skip_if_unusable=True,
+                                                 use_graph=not args.no_graph)
         n5 = max(args.steps // (2 * F * G), 6)
         for i in range(3):
             cv5(i)
