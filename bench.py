@@ -132,6 +132,9 @@ def main():
     ap.add_argument("--fold-group", type=int, default=10,
                     help="fold models advanced in lock-step by ONE launch sequence (FoldGroupEngine, *_group entry points); "
                          "--concurrent-folds then counts concurrent groups")
+    ap.add_argument("--global-cox", action="store_true",
+                    help="mode ddp: Cox risk set over the whole global batch (all-gather of hazards/times/events, gradients "
+                         "summed) instead of rank-local risk sets")
     ap.add_argument("--mode", choices=["fold", "ddp"], default="fold",
                     help="N>1: 'fold' = K-fold units sharded over ranks, no collective (default); 'ddp' = one model, global "
                          "batch N*B, flat gradient all-reduce (RCCL) per step")
@@ -206,7 +209,7 @@ def main():
                                              skip_if_unusable=True, use_graph=not args.no_graph)
             else:
                 engines[f].train_step(skip_if_unusable=True, use_graph=not args.no_graph, ddp_world=world if ddp else 1,
-                                      **batch_of(f, k))
+                                      global_cox=bool(ddp and args.global_cox), **batch_of(f, k))
 
     def run(nsteps, nf):
         """exactly nsteps steps (one step = one batch of one fold model), dealt over nf groups of G lock-step models"""
@@ -312,7 +315,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "MultiModalSurvivalNet (DenseNet121-3D CT 64x64x32 + RNA-seq 5005 + clinical), "
                                    "109 synthetic complete patients, 5-fold split, batch 4, Adam lr 1e-4 wd 1e-4, clip 1.0",
-                       "global_batch": world * B, "parallelism": (f"ddp x{world} (flat gradient all-reduce per step, local BN + local Cox risk set)" if ddp else
+                       "global_batch": world * B, "parallelism": (f"ddp x{world} (flat gradient all-reduce per step, local BN + {'global' if args.global_cox else 'local'} Cox risk set)" if ddp else
                                        f"kfold-shard x{world} ranks x {F} concurrent groups x {G} lock-step fold models per GPU (one stream + step graph per group, no collective)"),
                        "concurrent_folds": F, "fold_group": G, "fold_models_in_flight": F * G,
                        "one_cv_5_lockstep_patients_per_s": (world * B / dt5) if dt5 else None,

@@ -5,8 +5,9 @@ Two ways the path shards:
     result records are gathered at the end (`gather_fold_results`).  Reproduces single-GPU results exactly.
   * patient/batch level (DDP): each rank steps on its shard of the global batch; the flat gradient buffer is
     all-reduced (SUM then /world) between backward and the clip+Adam kernels (`allreduce_mean_`), one collective of
-    56 MB instead of 364 small ones.  BatchNorm statistics and the Cox risk set stay rank-local in this round
-    (documented difference to a single-process batch of world*B).
+    56 MB instead of 364 small ones.  Cox risk set: rank-local (default), or GLOBAL over the world*B patients of the step
+    (`train_step(..., ddp_world=N, global_cox=True)`: all-gather of hazards/times/events, every rank evaluates the global
+    loss and back-propagates its own slice, gradients are SUMMED).  BatchNorm statistics stay rank-local.
 """
 import os
 
@@ -44,6 +45,33 @@ def gather_fold_results(local_results, world):
     out = [None] * world
     dist.all_gather_object(out, local_results)
     return sorted([r for part in out for r in part], key=lambda r: r["fold"])
+
+
+def allreduce_sum_(flat, world):
+    """In-place sum over ranks (gradients of a loss that is already global: each rank holds its samples' share)."""
+    if world > 1:
+        if flat.is_cuda and dist.get_backend() == "gloo":
+            h = flat.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            flat.copy_(h)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return flat
+
+
+def all_gather_into(out, local, world):
+    """out[r * n:(r + 1) * n] = rank r's `local` (n elements, same on every rank): the (hazard, time, event, valid) exchange
+    of the global Cox risk set -- 4 collectives of world * B floats."""
+    if world <= 1:
+        out.copy_(local.reshape(-1))
+        return out
+    if local.is_cuda and dist.get_backend() == "gloo":
+        parts = [torch.empty(local.numel()) for _ in range(world)]
+        dist.all_gather(parts, local.detach().reshape(-1).cpu())
+        out.copy_(torch.cat(parts))
+    else:
+        dist.all_gather_into_tensor(out, local.detach().reshape(-1).contiguous())
+    return out
 
 
 def allreduce_mean_(flat, world):

@@ -334,11 +334,32 @@ class SurvivalEngine:
                                              ctypes.c_void_p(self.ev_fork.cuda_event), ctypes.c_void_p(self.ev_join.cuda_event)),
                    "mms_dn121_backward_mt")
 
+    def _global_cox_buffers(self, P, world):
+        if getattr(P, "gcox", None) is None or P.gcox["world"] != world:
+            n, dev = world * P.B, self.device
+            G = dict(world=world, h=torch.zeros(n, device=dev), time=torch.zeros(n, device=dev), event=torch.zeros(n, device=dev),
+                     valid=torch.ones(n, device=dev), lse=torch.zeros(n, device=dev), dh=torch.zeros(n, device=dev), rank=0)
+            G["cox"] = _S()["CoxP"](G["h"].data_ptr(), 1, G["time"].data_ptr(), G["event"].data_ptr(), G["valid"].data_ptr(), n, 1.0,
+                                    G["lse"].data_ptr(), G["dh"].data_ptr(), 1, P.cox_out.data_ptr())
+            P.gcox = G
+        return P.gcox
+
     def _train_body(self, P, skip_if_unusable, part="all"):
         """zero-grad -> forward -> Cox -> backward [-> gradient all-reduce outside] -> clip -> Adam, epoch accumulators.
         part: "all" (single GPU / fold sharding), or "grad" / "update" = the two halves around the DDP all-reduce."""
         st = ops.stream()
         lib = self.lib
+        if part == "fwd":                      # DDP with the global risk set: first third
+            self.gflat.zero_()
+            self.sumsq.zero_()
+            self._forward(P, True)
+            return
+        if part == "coxbwd":                   # ... second third: loss over the gathered world*B hazards, own slice of dL/dh
+            G = P.gcox
+            _lib.check(lib.mms_cox_fwd_bwd(ctypes.byref(G["cox"]), st), "mms_cox_fwd_bwd")
+            P.dbuf["hz"][:, 0].copy_(G["dh"][G["rank"] * P.B:(G["rank"] + 1) * P.B])
+            self._backward_from_dhz(P)
+            return
         if part in ("all", "grad"):
             self.gflat.zero_()
             self.sumsq.zero_()
@@ -399,7 +420,7 @@ class SurvivalEngine:
         return G
 
     def train_step(self, ct=None, rna=None, clinical=None, mask=None, time=None, event=None, valid=None, skip_if_unusable=True,
-                   use_graph=True, ddp_world=1):
+                   use_graph=True, ddp_world=1, global_cox=False):
         """One optimisation step on one batch (inputs may live on host or device).  Returns nothing: losses are
         accumulated on the device (`epoch_stats()`), exactly one host sync per epoch instead of one per batch.
         ddp_world > 1: data-parallel step -- this rank's shard of the global batch; the flat gradient buffer is averaged
@@ -408,6 +429,45 @@ class SurvivalEngine:
         B = rna.shape[0]
         P = self.plan(B, tuple(ct.shape[-3:]) if ct is not None else None)
         self.load_batch(P, ct, rna, clinical, mask, time, event, valid)
+        if ddp_world > 1 and global_cox:
+            # Cox is batch-coupled: for parity with ONE process stepping on the world*B patients, the risk sets must span all
+            # ranks (SURVEY 8e ii).  [zero-grad, forward] | all-gather (h, time, event, valid) | [global Cox -> dL/dh of all
+            # world*B hazards, own slice -> backward] | all-reduce SUM of the flat gradients | [clip, Adam]
+            from . import distributed as D
+            import torch.distributed as dist
+            G = self._global_cox_buffers(P, ddp_world)
+            G["rank"] = dist.get_rank() if dist.is_initialized() else 0
+
+            def sequence(run):
+                run("fwd")
+                D.all_gather_into(G["h"], P.buf["hz"][:, 0], ddp_world)
+                D.all_gather_into(G["time"], P.time, ddp_world); D.all_gather_into(G["event"], P.event, ddp_world)
+                D.all_gather_into(G["valid"], P.valid, ddp_world)
+                run("coxbwd")
+                D.allreduce_sum_(self.gflat, ddp_world)
+                run("update")
+            if not use_graph:
+                sequence(lambda part: self._train_body(P, False, part))
+                return
+            if ("fwd", False) not in P.graphs or ("coxbwd", False) not in P.graphs:
+                # the parts depend on each other through the workspace (statistic accumulators are zeroed by "fwd" only), so
+                # they are warmed up as ONE eager step, rolled back, and then captured without being executed
+                state = [self.flat.clone(), self.m.clone(), self.v.clone(), self.step_count.clone(), self.rng.clone(),
+                         self.acc.clone(), [b.clone() for b in self.model.buffers()]]
+                sequence(lambda part: self._train_body(P, False, part))
+                torch.cuda.synchronize()
+                with torch.no_grad():
+                    self.flat.copy_(state[0]); self.m.copy_(state[1]); self.v.copy_(state[2])
+                    self.step_count.copy_(state[3]); self.rng.copy_(state[4]); self.acc.copy_(state[5])
+                    for b, b0 in zip(self.model.buffers(), state[6]):
+                        b.copy_(b0)
+                for part in ("fwd", "coxbwd", "update"):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self._train_body(P, False, part)
+                    P.graphs[(part, False)] = g
+            sequence(lambda part: P.graphs[(part, False)].replay())
+            return
         if ddp_world > 1:
             from . import distributed as D
             # a usable/unusable decision must be common to all ranks, otherwise Adam states diverge: DDP never skips

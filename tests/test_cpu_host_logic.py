@@ -51,6 +51,13 @@ g = torch.full((1000,), float(rank + 1))
 D.allreduce_mean_(g, world)
 assert torch.allclose(g, torch.full((1000,), 1.5))
 assert D.max_over_ranks(float(rank), "cpu") == 1.0
+# the exchange of the global Cox risk set: rank r's B values land at [r*B, (r+1)*B) on every rank; gradients are summed
+out = torch.zeros(2 * 3)
+D.all_gather_into(out, torch.arange(3.0) + 10 * rank, world)
+assert out.tolist() == [0, 1, 2, 10, 11, 12]
+s = torch.full((8,), float(rank + 1))
+D.allreduce_sum_(s, world)
+assert torch.allclose(s, torch.full((8,), 3.0))
 D.barrier()
 print("ok", rank)
 '''
