@@ -148,3 +148,21 @@ def test_final_comparison_collects_and_tests(tmp_path):
     assert set(out["paired_t_tests"]) == {"Simple Fusion"}            # the 5-fold model has a different fold count: skipped (:74)
     assert out["paired_t_tests"]["Simple Fusion"]["p"] < 0.05
     assert json.load(open(tmp_path / "results" / "final_comparison" / "results.json"))["model_results"]["Final Multimodal"]["n_patients"] == 50
+
+
+def test_lockstep_iteration_and_batch_rules():
+    """Host logic of the lock-step K-fold driver: folds drop out as their loaders run dry; per-style batch keyword rules."""
+    from multimodal_survival_prediction_amd import training as T
+    loaders = [["a0", "a1", "a2"], ["b0"], ["c0", "c1"]]
+    seen = list(T._lockstep(loaders, (4, 7, 9)))
+    assert seen == [{4: "a0", 7: "b0", 9: "c0"}, {4: "a1", 9: "c1"}, {4: "a2"}]
+    b = dict(image=torch.zeros(3, 1, 32, 32, 32), rnaseq=torch.zeros(3, 8), clinical=torch.zeros(3, 1), label=torch.ones(3, 2),
+             mask=torch.ones(3, 3), has_survival=[True, False, True], time=torch.ones(3, 1), event=torch.ones(3, 1, dtype=torch.long))
+    assert set(T._train_kwargs("final", b)) == {"ct", "rna", "clinical", "time", "event"}
+    kw = T._train_kwargs("partial", b)
+    assert kw["valid"].tolist() == [1.0, 0.0, 1.0] and kw["mask"].shape == (3, 3)
+    assert T._train_kwargs("flexible", b)["mask"].shape == (3, 2)
+    assert set(T._train_kwargs("rnaseq", b)) == {"rna", "time", "event"}
+    b["has_survival"] = [True, False, False]
+    assert T._train_kwargs("simple", b) is None and T._train_kwargs("flexible", b) is None     # < 2 labelled: skipped before the forward
+    assert T._SKIP_UNUSABLE == {"final": True, "partial": False, "simple": True, "flexible": True, "rnaseq": False}
