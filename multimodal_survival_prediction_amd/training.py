@@ -311,14 +311,18 @@ def _lockstep(loaders, members):
             yield out
 
 
-def train_epoch_lockstep(group, loaders, style, members=None):
+def train_epoch_lockstep(group, loaders, style, members=None, concurrent=1):
     """One epoch of the folds `members` (default: all) of a FoldGroupEngine, each on its own loader.
+    concurrent = 2: the members are split into two fixed halves that step as two lock-step sub-groups on two HIP streams
+    (one sub-group's latency-bound kernels overlap the other's; 5 folds as 3 + 2: +4.5 % over one group of 5).  Every member's
+    loader is iterated under its half's stream, so batch tensors are allocated and consumed on the same stream.
     -> per member, what train_epoch_<style> returns for that fold."""
     members = tuple(range(len(group))) if members is None else tuple(members)
     for g in members:
         group.engines[g].model.train()
         group.engines[g].reset_epoch_stats()
-    for pos in _lockstep(loaders, members):
+
+    def advance(pos):
         by_size = {}
         for g, batch in pos.items():
             kw = _train_kwargs(style, batch)
@@ -327,6 +331,33 @@ def train_epoch_lockstep(group, loaders, style, members=None):
         for items in by_size.values():           # a ragged last batch forms its own (sub-)group step
             group.train_step([kw for _, kw in items], members=tuple(g for g, _ in items),
                              skip_if_unusable=_SKIP_UNUSABLE[style])
+
+    if concurrent <= 1 or len(members) < 4:
+        for pos in _lockstep(loaders, members):
+            advance(pos)
+    else:
+        if not hasattr(group, "_side_streams"):
+            group._side_streams = [torch.cuda.Stream(device=group.device) for _ in range(2)]
+        cut = (len(members) + 1) // 2
+        halves = [(members[:cut], loaders[:cut]), (members[cut:], loaders[cut:])]
+        cur = torch.cuda.current_stream()
+        for s in group._side_streams:
+            s.wait_stream(cur)
+        its = [_lockstep(ld, mem) for mem, ld in halves]
+        live = [True, True]
+        while any(live):
+            for h in (0, 1):
+                if not live[h]:
+                    continue
+                with torch.cuda.stream(group._side_streams[h]):
+                    pos = next(its[h], None)         # the loaders gather their batches on this stream
+                    if pos is None:
+                        live[h] = False
+                    else:
+                        advance(pos)
+        for s in group._side_streams:
+            cur.wait_stream(s)
+        torch.cuda.synchronize()
     out = []
     for g in members:
         st = group.engines[g].epoch_stats()

@@ -71,7 +71,8 @@ def cv_lockstep(style, models, loaders, group_kw, num_epochs, patience, make_sch
         if not active:
             break
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        tr = train_epoch_lockstep(group, [loaders[g][0] for g in active], style, members=active)
+        tr = train_epoch_lockstep(group, [loaders[g][0] for g in active], style, members=active,
+                                  concurrent=env_int("MMS_LOCKSTEP_STREAMS", 2))
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         n_ep = sum(len(loaders[g][0].idx) for g in active)
         va = validate_lockstep(group, [loaders[g][1] for g in active], style, device, members=active)

@@ -229,3 +229,24 @@ def test_lockstep_epoch_matches_sequential(style, monkeypatch):
         assert np.allclose(a, b, rtol=8e-2, atol=5e-3), (f, a, b)        # one epoch of chaotic fp32 training: loose on the mean loss
         assert abs(seq[f][1][0] - va[f][0]) <= 5e-2 * max(1.0, abs(seq[f][1][0])), (f, seq[f][1], va[f])
         assert abs(seq[f][1][1] - va[f][1]) <= 0.15, (f, seq[f][1], va[f])   # C-index over <= 10 patients: one swapped pair = 0.02-0.1
+
+
+def test_lockstep_two_streams_matches_one(monkeypatch):
+    """concurrent=2 (two sub-groups on two streams) trains the same folds as concurrent=1."""
+    monkeypatch.setenv("MMS_SPLIT_WGS", "1000000"); monkeypatch.setenv("MMS_CONV1_KSPLIT", "0"); monkeypatch.setenv("MMS_CONV3_MT", "0"); monkeypatch.setenv("MMS_BIG_NG", "0"); monkeypatch.setenv("MMS_MS3_ROWS", "512"); monkeypatch.setenv("MMS_MS1_DIV", "1")
+    from multimodal_survival_prediction_amd import data, models as HM, training as T
+    from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
+    dims, rna_dim, K, B = (32, 32, 32), 48, 5, 4
+    cohort = data.cohort_to(data.make_cohort(n=45, dims=dims, rna_dim=rna_dim, seed=5, complete=True), DEV)
+    folds = data.kfold_indices(45, K, seed=1)
+    ld = lambda f: data.BatchLoader(cohort, folds[f][0], B, shuffle=True, seed=10 + f)
+    base = []
+    for f in range(K):
+        torch.manual_seed(f); base.append(HM.MultiModalSurvivalNet(rna_dim=rna_dim))
+    res = []
+    for conc in (1, 2):
+        ge = FoldGroupEngine([copy.deepcopy(b).to(DEV) for b in base], lr=1e-4, weight_decay=1e-4)
+        res.append((T.train_epoch_lockstep(ge, [ld(f) for f in range(K)], "final", concurrent=conc), ge.epoch_stats()))
+    for f in range(K):
+        assert res[0][1][f]["n_batches"] == res[1][1][f]["n_batches"] == 9
+        assert abs(res[0][0][f] - res[1][0][f]) <= 8e-2 * max(1.0, abs(res[0][0][f])), (f, res[0][0][f], res[1][0][f])
