@@ -63,13 +63,33 @@ def cohort_to(cohort, device):
     return {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in cohort.items()}
 
 
+def gather_view(cohort, with_valid):
+    """The dict the fused batch gather (FoldGroupEngine.train_step_indexed) reads: the cohort itself plus, when the style masks
+    unlabeled patients out of the loss, a float `valid` column = has_survival.  One object per (cohort, with_valid), so that all
+    folds' loaders share it and a group's batches are assembled by ONE gather launch."""
+    key = "_gather_view_%d" % int(with_valid)
+    if key not in cohort:
+        v = {k: t for k, t in cohort.items() if not k.startswith("_gather_view_") and k != "valid"}
+        if with_valid:
+            v["valid"] = cohort["has_survival"].to(torch.float32)
+        cohort[key] = v
+    return cohort[key]
+
+
 class BatchLoader:
     """Minimal DataLoader stand-in over a tensor-resident cohort: yields the reference's batch dicts.
-    shuffle uses its own seeded generator; drop_last=False like the reference's DataLoader calls."""
+    shuffle uses its own seeded generator; drop_last=False like the reference's DataLoader calls.
+    lazy=True (device-resident cohorts, lock-step training): a batch is only NAMED -- dict(index=[B] patient indices,
+    has_survival=[...], gather=<gather_view>) -- and assembled on the GPU by the consumer's single gather launch instead of
+    ~8 indexing kernels + copies per fold and batch here."""
 
-    def __init__(self, cohort, indices, batch_size, shuffle=False, seed=0, style="final"):
+    def __init__(self, cohort, indices, batch_size, shuffle=False, seed=0, style="final", lazy=False, with_valid=True):
         self.c, self.idx, self.bs, self.shuffle, self.style = cohort, torch.as_tensor(indices), batch_size, shuffle, style
         self.gen = torch.Generator().manual_seed(seed)
+        self.lazy = lazy
+        if lazy:
+            self.view = gather_view(cohort, with_valid)
+            self.hs_cpu = cohort["has_survival"].cpu().tolist()
 
     def __len__(self):
         return (len(self.idx) + self.bs - 1) // self.bs
@@ -78,6 +98,10 @@ class BatchLoader:
         idx = self.idx[torch.randperm(len(self.idx), generator=self.gen)] if self.shuffle else self.idx
         dev = self.c["image"].device
         for i in range(0, len(idx), self.bs):
+            if self.lazy:
+                jj = idx[i:i + self.bs]
+                yield dict(index=jj, has_survival=[self.hs_cpu[int(k)] for k in jj], gather=self.view)
+                continue
             j = idx[i:i + self.bs].to(dev)
             b = dict(image=self.c["image"][j], rnaseq=self.c["rnaseq"][j], clinical=self.c["clinical"][j],
                      label=self.c["label"][j], mask=self.c["mask"][j], has_survival=self.c["has_survival"][j].tolist())

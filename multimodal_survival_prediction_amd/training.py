@@ -323,6 +323,17 @@ def train_epoch_lockstep(group, loaders, style, members=None, concurrent=1):
         group.engines[g].reset_epoch_stats()
 
     def advance(pos):
+        lazy = [(g, b) for g, b in pos.items() if "gather" in b]
+        if lazy:        # batches named by index (data.BatchLoader(lazy=True)): one gather launch per (sub-)group step
+            by = {}
+            for g, b in lazy:
+                if style in ("simple", "flexible") and sum(bool(x) for x in b["has_survival"]) < 2:
+                    continue                          # skipped before the forward (simple_fusion.py:257-258)
+                by.setdefault((len(b["index"]), id(b["gather"])), []).append((g, b))
+            for items in by.values():
+                group.train_step_indexed(items[0][1]["gather"], torch.stack([torch.as_tensor(b["index"]) for _, b in items]),
+                                         members=tuple(g for g, _ in items), skip_if_unusable=_SKIP_UNUSABLE[style])
+            pos = {g: b for g, b in pos.items() if "gather" not in b}
         by_size = {}
         for g, batch in pos.items():
             kw = _train_kwargs(style, batch)

@@ -46,6 +46,11 @@ def load_or_make_cohort(device, **make_kw):
     return data.cohort_to(data.make_cohort(**make_kw), device)
 
 
+def data_mod():
+    from multimodal_survival_prediction_amd import data
+    return data
+
+
 def lockstep_enabled(n_local_folds):
     """Folds of this rank train in lock-step as one fold group (MMS_LOCKSTEP=0 restores fold-after-fold order)."""
     return env_int("MMS_LOCKSTEP", 1) != 0 and 2 <= n_local_folds <= 10
@@ -62,6 +67,11 @@ def cv_lockstep(style, models, loaders, group_kw, num_epochs, patience, make_sch
     from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
     from multimodal_survival_prediction_amd.training import FusedOptimizer, train_epoch_lockstep, validate_lockstep
     group = FoldGroupEngine(models, **group_kw)
+    for tl, _ in loaders:                      # device-resident cohort: name the training batches, let the group gather them
+        if env_int("MMS_LAZY_BATCHES", 1) and tl.c["image"].is_cuda:
+            tl.lazy = True
+            tl.view = data_mod().gather_view(tl.c, with_valid=(style != "final"))
+            tl.hs_cpu = tl.c["has_survival"].cpu().tolist()
     opts = [FusedOptimizer(m, lr=group_kw.get("lr", 1e-4), weight_decay=group_kw.get("weight_decay", 1e-4)) for m in models]
     scheds = [make_scheduler(o) for o in opts]
     takes_metric = [len(inspect.signature(s.step).parameters) > 0 for s in scheds]

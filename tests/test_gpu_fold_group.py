@@ -244,9 +244,11 @@ def test_lockstep_two_streams_matches_one(monkeypatch):
     for f in range(K):
         torch.manual_seed(f); base.append(HM.MultiModalSurvivalNet(rna_dim=rna_dim))
     res = []
-    for conc in (1, 2):
+    lazy = lambda f: data.BatchLoader(cohort, folds[f][0], B, shuffle=True, seed=10 + f, lazy=True, with_valid=False)
+    for conc, mk in ((1, ld), (2, ld), (2, lazy)):      # lazy: batches named by index, assembled by the group's one gather launch
         ge = FoldGroupEngine([copy.deepcopy(b).to(DEV) for b in base], lr=1e-4, weight_decay=1e-4)
-        res.append((T.train_epoch_lockstep(ge, [ld(f) for f in range(K)], "final", concurrent=conc), ge.epoch_stats()))
+        res.append((T.train_epoch_lockstep(ge, [mk(f) for f in range(K)], "final", concurrent=conc), ge.epoch_stats()))
     for f in range(K):
-        assert res[0][1][f]["n_batches"] == res[1][1][f]["n_batches"] == 9
-        assert abs(res[0][0][f] - res[1][0][f]) <= 8e-2 * max(1.0, abs(res[0][0][f])), (f, res[0][0][f], res[1][0][f])
+        assert res[0][1][f]["n_batches"] == res[1][1][f]["n_batches"] == res[2][1][f]["n_batches"] == 9
+        for other in (1, 2):
+            assert abs(res[0][0][f] - res[other][0][f]) <= 8e-2 * max(1.0, abs(res[0][0][f])), (f, other, res[0][0][f], res[other][0][f])
