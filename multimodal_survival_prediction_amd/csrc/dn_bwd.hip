@@ -34,7 +34,6 @@ template <bool SPLIT>
 struct Conv3BwdDataOp {
     typedef Conv3BwdDataP Params;
     static constexpr int WM = 1, WN = 4, WK = 1, AMODE = LD_K4, BMODE = LD_K4;
-    static constexpr bool SPEC = false;
     static constexpr int TM = 32, TN = 128;
     static constexpr int EXTRA = 4 * 128 + 32 + 2 * 2 * 128 * 2;   // bn consts, (unused), fp64 reduction scratch
     typedef float4 ARaw;
@@ -170,7 +169,6 @@ MMS_SINGLE(mms_conv3_bwd_data, Conv3BwdDataP)
 struct Conv3BwdWOp {
     typedef Conv3BwdWP Params;
     static constexpr int WM = 4, WN = 1, WK = 1, AMODE = LD_R4, BMODE = LD_R4;
-    static constexpr bool SPEC = false;
     static constexpr int TM = 128, TN = 32;
     static constexpr int EXTRA = 1024;       // tap-validity mask of every voxel of this workgroup's row chunk
     typedef float4 ARaw;
@@ -358,7 +356,6 @@ template <int WM_, int WN_, int WK_, bool POOL>
 struct Conv1BwdDataOp {
     typedef Conv1BwdP Params;
     static constexpr int WM = WM_, WN = WN_, WK = WK_, AMODE = LD_K4, BMODE = LD_R4;
-    static constexpr bool SPEC = false;
     __device__ void step(const Params&, int) {}
     static constexpr int TM = 32 * WM, TN = 32 * WN;
     // dy consts for all N (<=512 without bn_out, 128 with), bn_in consts for TN columns, srcbase[TM], fp64 scratch
@@ -482,7 +479,6 @@ template <bool POOL>
 struct Conv1BwdWOp {
     typedef Conv1BwdP Params;
     static constexpr int WM = 2, WN = 2, WK = 1, AMODE = LD_R4, BMODE = LD_R4;
-    static constexpr bool SPEC = false;
     __device__ void step(const Params&, int) {}
     static constexpr int TM = 64, TN = 64;
     static constexpr int EXTRA = 5 * 64 + 3 * 64;
@@ -835,7 +831,6 @@ MMS_SINGLE(mms_pool_bwd, PoolBwdP)
 struct Conv0BwdWOp {
     typedef Conv0BwdWP Params;
     static constexpr int WM = 2, WN = 2, WK = 1, AMODE = LD_K1, BMODE = LD_R4;
-    static constexpr bool SPEC = false;
     __device__ void step(const Params&, int) {}
     static constexpr int TM = 64, TN = 64;
     static constexpr int EXTRA = 5 * 64;

@@ -41,7 +41,6 @@ template <int WM_, int WN_, int WK_, bool POOL, bool KSPLIT = false>
 struct Conv1FwdOp {
     typedef Conv1FwdP Params;
     static constexpr int WM = WM_, WN = WN_, WK = WK_, AMODE = LD_K4, BMODE = LD_K4;
-    static constexpr bool SPEC = false;
     __device__ void step(const Params&, int) {}
     static constexpr int TM = 32 * WM, TN = 32 * WN;
     static constexpr int EXTRA = 3 * 1024 + TM;
@@ -176,7 +175,6 @@ template <bool SPLIT>
 struct Conv3FwdOp {
     typedef Conv3FwdP Params;
     static constexpr int WM = 1, WN = 1, WK = 4, AMODE = LD_K4, BMODE = LD_K4;
-    static constexpr bool SPEC = false;
     static constexpr int TM = 32, TN = 32;
     static constexpr int EXTRA = 4;
     typedef float4 ARaw;
@@ -471,7 +469,6 @@ MMS_SINGLE(mms_conv3_fwd, Conv3FwdP)
 struct Conv0FwdOp {
     typedef Conv0FwdP Params;
     static constexpr int WM = 2, WN = 2, WK = 1, AMODE = LD_K1, BMODE = LD_K1;
-    static constexpr bool SPEC = false;
     __device__ void step(const Params&, int) {}
     static constexpr int TM = 64, TN = 64;
     static constexpr int EXTRA = 4 * 64;

@@ -29,7 +29,8 @@
 //   (same for b_ld / b_tx with n instead of m).  The core issues every *_ld of tile t+1 BEFORE the MFMAs of
 //   tile t and runs *_tx after them, at LDS-store time, so HBM/L2 latency hides under the matrix phase.
 //   __device__ void epilogue(const Params&, int m0, int n0, int z, const float* Cs /*[TM][TN+1]*/, int tid, bool active);
-//   (active = false for the producer half in SPEC mode: take part in barriers only)
+//   (active is always true; a wave-specialised 512-thread variant of this core -- producer waves loading, consumer waves
+//   issuing MFMAs -- was measured on the conv3 forward and gave nothing over the register-prefetch pipeline, and was removed)
 #pragma once
 #include "common.h"
 
@@ -58,13 +59,8 @@ struct TileGemmCfg {
 template <class Op, class = void> struct has_zremap { static constexpr bool value = false; };
 template <class Op> struct has_zremap<Op, decltype((void)&Op::zremap)> { static constexpr bool value = true; };
 
-// Op::SPEC = true: wave-specialised variant, 512 threads.  Waves 0-3 ("consumers") only read LDS and issue MFMAs;
-// waves 4-7 ("producers") only run the loaders, transforms and LDS stores.  Each SIMD then hosts one consumer and
-// one producer wave, so the dependent-MFMA issue gaps (64 cycles each) are filled by the other wave's VALU/VMEM work
-// instead of idling -- measured on the conv3 forward: MFMA-chain stalls, loader issue and memory waits each took
-// about a third of a one-wave-per-SIMD kernel's time, serialised.
 template <class Op>
-__global__ __launch_bounds__(Op::SPEC ? 512 : 256) void tile_gemm_kernel(const Grp<typename Op::Params> grp) {
+__global__ __launch_bounds__(256) void tile_gemm_kernel(const Grp<typename Op::Params> grp) {
     int gi, z;                                             // model of the fold group, the op's own z index
     if constexpr (has_zremap<Op>::value) Op::zremap((int)blockIdx.z, grp.zdim, (int)gridDim.z, gi, z);
     else { gi = blockIdx.z / grp.zdim; z = blockIdx.z - gi * grp.zdim; }
@@ -80,8 +76,7 @@ __global__ __launch_bounds__(Op::SPEC ? 512 : 256) void tile_gemm_kernel(const G
     float* extra = smem + Cfg::main_floats();
 
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
-    const bool producer = Op::SPEC ? threadIdx.x >= 256 : true;
-    const bool consumer = Op::SPEC ? threadIdx.x < 256 : true;
+    constexpr bool consumer = true;
     const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
     // XCD-aware tile order (cdna_hip_programming.md T1): workgroups are dealt round-robin over the 8 XCDs, so give the
     // blocks that share an XCD (equal blockIdx.x % 8) a CONTIGUOUS range of M tiles -- neighbouring tiles share halo rows /
@@ -211,32 +206,7 @@ __global__ __launch_bounds__(Op::SPEC ? 512 : 256) void tile_gemm_kernel(const G
     };
 
     if (kb < ke) {
-        if constexpr (Op::SPEC) {
-            // producers run two tiles ahead: the loads of tile t+2 are in flight while tile t+1 is transformed and
-            // stored (vmcnt retires in order, so waiting for the older register set leaves the newer loads pending)
-            if (producer) {
-                gload(R0, kb);
-                if (kb + TK < ke) gload(R1, kb + TK);
-                sstore(R0, 0);
-            }
-            __syncthreads();
-            int buf = 0;
-            for (int k0 = kb; k0 + TK < ke; k0 += 2 * TK) {
-                // tile k0 is in LDS[buf]; R1 holds tile k0+TK
-                if (producer) { if (k0 + 2 * TK < ke) gload(R0, k0 + 2 * TK); sstore(R1, buf ^ 1); }
-                else mma(buf);
-                __syncthreads();
-                buf ^= 1;
-                if (k0 + 2 * TK >= ke) break;
-                // tile k0+TK is in LDS[buf]; R0 holds tile k0+2TK
-                if (producer) { if (k0 + 3 * TK < ke) gload(R1, k0 + 3 * TK); sstore(R0, buf ^ 1); }
-                else mma(buf);
-                __syncthreads();
-                buf ^= 1;
-            }
-            if (consumer) mma(buf);
-            __syncthreads();
-        } else {
+        {
             // two register sets: the global loads of tile t+2 are issued before the MFMAs of tile t and consumed (transform
             // + LDS store) one step later, so L2/MALL latency has a full step to hide (vmcnt retires in order)
             gload(R0, kb);
@@ -276,7 +246,6 @@ __global__ __launch_bounds__(Op::SPEC ? 512 : 256) void tile_gemm_kernel(const G
         }
         __syncthreads();
     }
-    // epilogues are written for 256 threads (tid 0..255); in SPEC mode the producer half only joins their barriers
     op.epilogue(p, m0, n0, z, Cs, tid, consumer);
 }
 
@@ -292,6 +261,6 @@ static inline int launch_tile_gemm(const typename Op::Params* pp, int ng, dim3 g
     Grp<typename Op::Params> a;
     if (!grp_fill(a, pp, ng, (int)grid.z)) return MMS_ERR_ARG;
     grid.z *= ng;
-    MMS_LAUNCH(tile_gemm_kernel<Op>, grid, dim3(Op::SPEC ? 512 : 256), smem, s, a);
+    MMS_LAUNCH(tile_gemm_kernel<Op>, grid, dim3(256), smem, s, a);
     return mms_check_launch();
 }

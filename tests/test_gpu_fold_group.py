@@ -228,7 +228,8 @@ def test_lockstep_epoch_matches_sequential(style, monkeypatch):
         a, b = np.atleast_1d(np.asarray(seq[f][0], dtype=float)), np.atleast_1d(np.asarray(tr[f], dtype=float))
         assert np.allclose(a, b, rtol=8e-2, atol=5e-3), (f, a, b)        # one epoch of chaotic fp32 training: loose on the mean loss
         assert abs(seq[f][1][0] - va[f][0]) <= 5e-2 * max(1.0, abs(seq[f][1][0])), (f, seq[f][1], va[f])
-        assert abs(seq[f][1][1] - va[f][1]) <= 0.15, (f, seq[f][1], va[f])   # C-index over <= 10 patients: one swapped pair = 0.02-0.1
+        # C-index over <= 10 patients: one swapped pair = 0.02-0.1; the partial cohort's folds hold only 3-6 permissible pairs
+        assert abs(seq[f][1][1] - va[f][1]) <= (0.34 if style == "partial" else 0.15), (f, seq[f][1], va[f])
 
 
 def test_lockstep_two_streams_matches_one(monkeypatch):
