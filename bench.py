@@ -120,7 +120,7 @@ def main():
     ap.add_argument("--steps", type=int, default=240)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--timed-only", action="store_true", help="profiling aid: stop after the timed region (no extra legs, no JSON)")
