@@ -325,6 +325,29 @@ typedef struct AdamP {
     int* rng;                       // [2] dropout (seed, step counter): counter += 1 after the step's kernels have used it
 } AdamP;
 
+/* Large-batch Linear (rows M > 32: BASELINE config 5, RNA-seq-only B = 2048; R/scripts/training/train_rnaseq_only.py:126-151).
+ * y = P(x) W^T + bias [-> ReLU], P = Dropout(ReLU(BatchNorm1d(x))) of the PRECEDING nn.Sequential entries (has_bn = 0: P = identity
+ * or dropout only).  fp32 MFMA GEMMs on the tile core; BatchNorm1d batch statistics travel like the BatchNorm3d ones: the
+ * producing launch accumulates (sum, sumsq) of its output in fp64 (osum/osumsq), the consuming launch normalises in its
+ * operand prologue (bn: sum/sumsq over the M rows).  Backward of one layer: mms_linear_big_bwd_w (dW, db), mms_linear_big_bwd_x
+ * (gradient wrt P's output, through dropout/ReLU -> dbn + the two BN-backward column sums), mms_bn1d_bwd_apply (dx, dgamma, dbeta). */
+typedef struct LinBigP {
+    const float* x; int ldx; int M; int K;
+    const float* w; const float* bias; int N;      // torch Linear: weight [N][K], bias [N]
+    float* y; int ldy; int out_relu;
+    int has_bn; BnSrc bn;                            // BatchNorm1d over the K input columns (train: batch sums of x; eval: running)
+    float* rmean; float* rvar; long long* nbt; float momentum;   // running statistics, updated by the forward in train mode (nullable)
+    float drop_p; const float* drop_mask; const uint32_t* rng; uint32_t stream_id; int train;
+    double* osum; double* osumsq;                   // [N] statistics of y (nullable)
+    /* backward */
+    const float* dy; int lddy;                      // gradient wrt y (after out_relu)
+    float* dw; float* dbias; int msplit;            // accumulated (atomics); rows split over msplit workgroups
+    float* dbn; int lddbn;                          // [M][K] gradient wrt BN output (has_bn) or wrt x (no BN)
+    double* s1; double* s2;                         // [K] sum dbn, sum dbn * xhat (has_bn)
+    float* dx; int lddx;                            // mms_bn1d_bwd_apply output
+    float* dgamma; float* dbeta;
+} LinBigP;
+
 /* Learnable missing-modality bias (R/scripts/training/flexible_multimodal.py:205-206,243-250): per feature segment s
  * (image 128 | RNA 256 columns of the fused vector)   feats[m][j] = feats[m][j]*mask[m][s] + bias_s[j]*(1 - mask[m][s]),
  * in place; backward: dbias_s[j] += sum_m dfeats[m][j]*(1 - mask[m][s]);  dfeats[m][j] *= mask[m][s]. */
@@ -395,6 +418,10 @@ int mms_linear_bwd(const LinearBwdP* p, hipStream_t s);
 int mms_gate_fwd(const GateP* p, hipStream_t s);
 int mms_gate_bwd(const GateP* p, hipStream_t s);
 int mms_gate_entropy(const float* gate, int M, float scale, float* loss, float* dgate, hipStream_t s);  /* gate_entropy_loss value (+= into *loss) and gradient */
+int mms_linear_big_fwd(const LinBigP* p, hipStream_t s);
+int mms_linear_big_bwd_w(const LinBigP* p, hipStream_t s);
+int mms_linear_big_bwd_x(const LinBigP* p, hipStream_t s);
+int mms_bn1d_bwd_apply(const LinBigP* p, hipStream_t s);
 int mms_missing_mix_fwd(const MixP* p, hipStream_t s);        /* R/scripts/training/flexible_multimodal.py:243-250 */
 int mms_missing_mix_bwd(const MixP* p, hipStream_t s);
 int mms_cox_fwd_bwd(const CoxP* p, hipStream_t s);

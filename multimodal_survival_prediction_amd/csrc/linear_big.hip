@@ -1,0 +1,314 @@
+// Large-batch Linear layers (rows M > 32) on the fp32-MFMA tile core: BASELINE config 5 (RNA-seq-only model at batch 2048,
+// R/scripts/training/train_rnaseq_only.py:126-176).  The small-batch kernels of heads.hip keep all rows of a column in one
+// lane (M <= 32); here the layers are ordinary GEMMs -- [M x K] x [K x N] with K up to 5005 -- and the neighbouring
+// BatchNorm1d / ReLU / Dropout are fused the way the DenseNet ops fuse BatchNorm3d: batch statistics of a layer's output are
+// accumulated by its epilogue (fp64 sum / sumsq), the next layer normalises in its operand prologue.
+#include "dn_ops.h"
+#include "tile_gemm.h"
+
+namespace {
+
+// prologue constants of the K input columns in LDS (K <= 1024 whenever a BatchNorm1d precedes: 1024 / 512 / 256 / 128)
+struct Prolog {
+    const float *mean, *sc, *beta;
+    bool has_bn, drop;
+    uint32_t seed, stream;
+    float dp;
+    const float* mask; int K;
+    __device__ void init(const LinBigP& p, float* lds, int tid) {
+        mean = lds; sc = lds + 1024; beta = lds + 2048;
+        has_bn = p.has_bn != 0;
+        if (has_bn) bn_consts_to_lds<4>(p.bn, p.K, tid, lds, lds + 1024, lds + 2048);
+        drop = p.train && (p.drop_mask != nullptr || p.drop_p > 0.f);
+        mask = p.drop_mask; dp = p.drop_p; K = p.K; stream = p.stream_id;
+        seed = (drop && !mask) ? p.rng[0] + 0x9E3779B9u * p.rng[1] : 0u;
+    }
+    __device__ __forceinline__ float scale(int m, int k) const {
+        if (!drop) return 1.f;
+        return mask ? mask[(size_t)m * K + k] : dropout_scale(seed, stream, (uint32_t)(m * K + k), dp);
+    }
+    // value of P(x)[m][k]
+    __device__ __forceinline__ float act(float v, int m, int k) const {
+        if (has_bn) v = fmaxf(bn_apply(v, mean[k], sc[k], beta[k]), 0.f);
+        return v * scale(m, k);
+    }
+};
+
+// zero the lanes of a float4 that lie beyond column K (pad columns of a padded row carry no data)
+__device__ __forceinline__ float4 tail4(float4 v, int k, int K) {
+    if (k + 3 < K) return v;
+    return make_float4(v.x, k + 1 < K ? v.y : 0.f, k + 2 < K ? v.z : 0.f, 0.f);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward:  y[m][n] = sum_k P(x)[m][k] * W[n][k] + bias[n]
+// ---------------------------------------------------------------------------------------------------------------------
+// XA: rows of x are 16-B aligned and padded to a multiple of 4 floats (ldx >= roundup4(K), pad columns readable) -> float4
+// loads; WA: K % 4 == 0 -> float4 loads of the weight rows.  Otherwise scalar (still coalesced along k) loads: the
+// 5005-wide first layer reads its [N][5005] weight that way.
+template <bool XA, bool WA>
+struct LinBigFwdOp {
+    typedef LinBigP Params;
+    static constexpr int WM = 2, WN = 2, WK = 1, AMODE = XA ? LD_K4 : LD_K1, BMODE = WA ? LD_K4 : LD_K1;
+    static constexpr int TM = 64, TN = 64;
+    static constexpr int EXTRA = 3 * 1024;
+    typedef typename std::conditional<XA, float4, float>::type ARaw;
+    typedef typename std::conditional<WA, float4, float>::type BRaw;
+    Prolog pr;
+    __device__ void step(const Params&, int) {}
+    __device__ void setup(const Params& p, int m0, int n0, int, float* extra, int tid) {
+        pr.init(p, extra, tid);
+        // running statistics of the BatchNorm1d in front of this layer (torch: momentum update with the unbiased variance)
+        if (p.has_bn && p.train && p.rmean && m0 == 0 && n0 == 0) {
+            for (int k = tid; k < p.K; k += 256) {
+                const double cnt = 1.0 / (double)p.bn.inv_count;
+                const double m = rep_sum(p.bn.sum, k, p.bn.nrep, p.bn.rep_stride) / cnt;
+                double v = rep_sum(p.bn.sumsq, k, p.bn.nrep, p.bn.rep_stride) / cnt - m * m;
+                if (v < 0) v = 0;
+                const double unb = cnt > 1.0 ? v * cnt / (cnt - 1.0) : v;
+                p.rmean[k] = (1.f - p.momentum) * p.rmean[k] + p.momentum * (float)m;
+                p.rvar[k] = (1.f - p.momentum) * p.rvar[k] + p.momentum * (float)unb;
+            }
+            if (tid == 0 && p.nbt) *p.nbt += 1;
+        }
+    }
+    __device__ void krange(const Params& p, int, int& kb, int& ke) { kb = 0; ke = p.K; }
+    __device__ ARaw a_ld(const Params& p, int, int m, int k, bool& ok) const {
+        ok = m < p.M && k < p.K;
+        if constexpr (XA) return ok ? *(const float4*)(p.x + (size_t)m * p.ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        else return ok ? p.x[(size_t)m * p.ldx + k] : 0.f;
+    }
+    __device__ ARaw a_tx(const Params& p, int, const ARaw& v, int m, int k, bool ok) const {
+        if constexpr (XA) {
+            if (!ok) return v;
+            return tail4(make_float4(pr.act(v.x, m, k), pr.act(v.y, m, k + 1), pr.act(v.z, m, k + 2), pr.act(v.w, m, k + 3)), k, p.K);
+        } else {
+            return ok ? pr.act(v, m, k) : 0.f;
+        }
+    }
+    __device__ BRaw b_ld(const Params& p, int, int n, int k, bool& ok) const {
+        ok = n < p.N && k < p.K;
+        if constexpr (WA) return ok ? *(const float4*)(p.w + (size_t)n * p.K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        else return ok ? p.w[(size_t)n * p.K + k] : 0.f;
+    }
+    __device__ BRaw b_tx(const Params&, int, const BRaw& v, int, int, bool) const { return v; }
+    __device__ void epilogue(const Params& p, int m0, int n0, int, const float* Cs, int tid, bool) {
+        float* C = const_cast<float*>(Cs);
+        for (int idx = tid; idx < TM * TN; idx += 256) {
+            const int r = idx / TN, c = idx % TN, m = m0 + r, n = n0 + c;
+            if (m < p.M && n < p.N) {
+                float v = C[r * (TN + 1) + c] + (p.bias ? p.bias[n] : 0.f);
+                if (p.out_relu) v = fmaxf(v, 0.f);
+                C[r * (TN + 1) + c] = v;
+                p.y[(size_t)m * p.ldy + n] = v;
+            }
+        }
+        __syncthreads();
+        if (p.osum && tid < TN && n0 + tid < p.N) {
+            double s = 0, q = 0;
+            const int rows = p.M - m0 < TM ? p.M - m0 : TM;
+            for (int r = 0; r < rows; ++r) { const double v = C[r * (TN + 1) + tid]; s += v; q += v * v; }
+            atomicAdd(&p.osum[n0 + tid], s);
+            atomicAdd(&p.osumsq[n0 + tid], q);
+        }
+    }
+};
+
+// gradient wrt the pre-activation output: dy masked by the output ReLU
+__device__ __forceinline__ float dpre_of(const LinBigP& p, float dy, float y) { return (p.out_relu && !(y > 0.f)) ? 0.f : dy; }
+
+struct DpreRaw { float4 g, y; };
+// dpre[m][n..n+3] (zero beyond column N); the 1-wide Cox head and unaligned rows take the scalar branch
+__device__ __forceinline__ DpreRaw dpre_ld(const LinBigP& p, int m, int n) {
+    DpreRaw r; r.g = make_float4(0.f, 0.f, 0.f, 0.f); r.y = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (n + 3 < p.N && ((p.lddy | p.ldy) & 3) == 0 && ((((uintptr_t)p.dy) | ((uintptr_t)p.y)) & 15) == 0) {
+        r.g = *(const float4*)(p.dy + (size_t)m * p.lddy + n);
+        if (p.out_relu) r.y = *(const float4*)(p.y + (size_t)m * p.ldy + n);
+    } else {
+        float g[4] = {0.f, 0.f, 0.f, 0.f}, y[4] = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (n + j < p.N) { g[j] = p.dy[(size_t)m * p.lddy + n + j]; if (p.out_relu) y[j] = p.y[(size_t)m * p.ldy + n + j]; }
+        r.g = make_float4(g[0], g[1], g[2], g[3]); r.y = make_float4(y[0], y[1], y[2], y[3]);
+    }
+    return r;
+}
+__device__ __forceinline__ float4 dpre_tx(const LinBigP& p, const DpreRaw& r) {
+    return make_float4(dpre_of(p, r.g.x, r.y.x), dpre_of(p, r.g.y, r.y.y), dpre_of(p, r.g.z, r.y.z), dpre_of(p, r.g.w, r.y.w));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward-weight:  dW[n][k] += sum_m dpre[m][n] * P(x)[m][k];  dbias[n] += sum_m dpre[m][n]
+// tile rows = n, cols = k, reduction over the rows m (split over grid.z, fp32 atomics)
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool XA>
+struct LinBigBwdWOp {
+    typedef LinBigP Params;
+    static constexpr int WM = 2, WN = 2, WK = 1, AMODE = LD_R4, BMODE = XA ? LD_R4 : LD_K1;
+    static constexpr int TM = 64, TN = 64;
+    static constexpr int EXTRA = 3 * 1024;
+    typedef DpreRaw ARaw;
+    typedef typename std::conditional<XA, float4, float>::type BRaw;
+    Prolog pr;
+    int mb, me;
+    __device__ void step(const Params&, int) {}
+    __device__ void setup(const Params& p, int, int, int z, float* extra, int tid) {
+        pr.init(p, extra, tid);
+        int mc = (p.M + p.msplit - 1) / p.msplit;
+        mc = (mc + 31) & ~31;
+        mb = z * mc;
+        me = mb + mc < p.M ? mb + mc : p.M;
+    }
+    __device__ void krange(const Params&, int, int& kb, int& ke) { kb = mb; ke = me; }
+    __device__ ARaw a_ld(const Params& p, int, int n, int m, bool& ok) const {        // A(rows n..n+3, m) = dpre[m][n..n+3]
+        ok = m < me && n < p.N;
+        if (!ok) { ARaw r; r.g = make_float4(0.f, 0.f, 0.f, 0.f); r.y = r.g; return r; }
+        return dpre_ld(p, m, n);
+    }
+    __device__ float4 a_tx(const Params& p, int, const ARaw& r, int, int, bool ok) const { return ok ? dpre_tx(p, r) : r.g; }
+    __device__ BRaw b_ld(const Params& p, int, int k, int m, bool& ok) const {        // B(cols k.., m) = P(x)[m][k..]
+        ok = m < me && k < p.K;
+        if constexpr (XA) return ok ? *(const float4*)(p.x + (size_t)m * p.ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        else return ok ? p.x[(size_t)m * p.ldx + k] : 0.f;
+    }
+    __device__ BRaw b_tx(const Params& p, int, const BRaw& v, int k, int m, bool ok) const {
+        if constexpr (XA) {
+            if (!ok) return v;
+            return tail4(make_float4(pr.act(v.x, m, k), pr.act(v.y, m, k + 1), pr.act(v.z, m, k + 2), pr.act(v.w, m, k + 3)), k, p.K);
+        } else {
+            return ok ? pr.act(v, m, k) : 0.f;
+        }
+    }
+    __device__ void epilogue(const Params& p, int n0r, int k0c, int, const float* Cs, int tid, bool) {
+        __shared__ float red[4][64];
+        if (mb >= me) return;
+        for (int idx = tid; idx < TM * TN; idx += 256) {
+            const int r = idx / TN, c = idx % TN, n = n0r + r, k = k0c + c;
+            if (n < p.N && k < p.K) atomicAdd(&p.dw[(size_t)n * p.K + k], Cs[r * (TN + 1) + c]);
+        }
+        if (k0c != 0 || !p.dbias) return;            // bias gradient: the workgroups of column tile 0 sum their rows of dpre
+        const int c = tid & 63, rg = tid >> 6, n = n0r + c;
+        float s = 0.f;
+        if (n < p.N)
+            for (int m = mb + rg; m < me; m += 4) s += dpre_of(p, p.dy[(size_t)m * p.lddy + n], p.out_relu ? p.y[(size_t)m * p.ldy + n] : 1.f);
+        red[rg][c] = s;
+        __syncthreads();
+        if (rg == 0 && n < p.N) atomicAdd(&p.dbias[n], red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward-data:  dP[m][k] = sum_n dpre[m][n] * W[n][k]  ->  through dropout and ReLU:  dbn[m][k], plus the BatchNorm-backward
+// column sums s1 = sum_m dbn, s2 = sum_m dbn * (x - mean)      (K % 4 == 0: every hidden width)
+// ---------------------------------------------------------------------------------------------------------------------
+struct LinBigBwdXOp {
+    typedef LinBigP Params;
+    static constexpr int WM = 2, WN = 2, WK = 1, AMODE = LD_K4, BMODE = LD_R4;
+    static constexpr int TM = 64, TN = 64;
+    static constexpr int EXTRA = 3 * 1024;
+    typedef DpreRaw ARaw;
+    typedef float4 BRaw;
+    Prolog pr;
+    __device__ void step(const Params&, int) {}
+    __device__ void setup(const Params& p, int, int, int, float* extra, int tid) { pr.init(p, extra, tid); }
+    __device__ void krange(const Params& p, int, int& kb, int& ke) { kb = 0; ke = p.N; }
+    __device__ ARaw a_ld(const Params& p, int, int m, int n, bool& ok) const {        // A(m, n..n+3) = dpre[m][n..n+3]
+        ok = m < p.M && n < p.N;
+        if (!ok) { ARaw r; r.g = make_float4(0.f, 0.f, 0.f, 0.f); r.y = r.g; return r; }
+        return dpre_ld(p, m, n);
+    }
+    __device__ float4 a_tx(const Params& p, int, const ARaw& r, int, int, bool ok) const { return ok ? dpre_tx(p, r) : r.g; }
+    __device__ float4 b_ld(const Params& p, int, int k, int n, bool& ok) const {      // B(cols k..k+3, n) = W[n][k..k+3]
+        ok = n < p.N && k < p.K;
+        return ok ? *(const float4*)(p.w + (size_t)n * p.K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __device__ float4 b_tx(const Params&, int, const float4& v, int, int, bool) const { return v; }
+    __device__ void epilogue(const Params& p, int m0, int k0, int, const float* Cs, int tid, bool) {
+        __shared__ double red[2][4][64];
+        const int c = tid & 63, rg = tid >> 6, k = k0 + c;
+        double s1 = 0, s2 = 0;
+        if (k < p.K) {
+            const int rows = p.M - m0 < TM ? p.M - m0 : TM;
+            for (int r = rg; r < rows; r += 4) {
+                const int m = m0 + r;
+                float g = Cs[r * (TN + 1) + c] * pr.scale(m, k);
+                if (pr.has_bn) {
+                    const float xc = p.x[(size_t)m * p.ldx + k] - pr.mean[k];
+                    g = fmaf(xc, pr.sc[k], pr.beta[k]) > 0.f ? g : 0.f;
+                    s1 += g; s2 += (double)g * xc;
+                }
+                p.dbn[(size_t)m * p.lddbn + k] = g;
+            }
+        }
+        if (!pr.has_bn) return;
+        red[0][rg][c] = s1; red[1][rg][c] = s2;
+        __syncthreads();
+        if (rg == 0 && k < p.K) {
+            atomicAdd(&p.s1[k], red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+            atomicAdd(&p.s2[k], red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+        }
+    }
+};
+
+// BatchNorm1d backward (training mode):  dx = gamma * rstd * (dbn - mean_m(dbn) - xhat * mean_m(dbn * xhat));
+// dgamma += sum_m dbn * xhat, dbeta += sum_m dbn          (s2 holds sum_m dbn * (x - mean): xhat's rstd is applied here)
+__global__ __launch_bounds__(256) void bn1d_bwd_apply_kernel(const LinBigP p) {
+    const int k = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    if (k >= p.K) return;
+    float mu, rstd;
+    bn_mean_rstd(p.bn, k, mu, rstd);
+    const float ga = p.bn.gamma[k];
+    const float t2 = (float)(p.s2[k] * (double)rstd);
+    const float m1 = (float)(p.s1[k] * (double)p.bn.inv_count), m2 = t2 * p.bn.inv_count;
+    if (blockIdx.y == 0 && rg == 0) {
+        if (p.dgamma) p.dgamma[k] += t2;
+        if (p.dbeta) p.dbeta[k] += (float)p.s1[k];
+    }
+    const int r0 = blockIdx.y * 64;
+    for (int r = r0 + rg; r < r0 + 64 && r < p.M; r += 4) {
+        const float xh = (p.x[(size_t)r * p.ldx + k] - mu) * rstd;
+        p.dx[(size_t)r * p.lddx + k] = ga * rstd * (p.dbn[(size_t)r * p.lddbn + k] - m1 - xh * m2);
+    }
+}
+
+bool args_ok(const LinBigP& p) {
+    return p.x && p.w && p.y && p.M > 0 && p.K > 0 && p.N > 0 && p.ldx >= p.K && p.ldy >= p.N &&
+           (!p.has_bn || (p.K <= 1024 && p.bn.gamma && p.bn.beta && (p.bn.train ? (p.bn.sum && p.bn.sumsq) : (p.bn.rmean && p.bn.rvar))));
+}
+// float4 loads of the rows of x: 16-B aligned, row pitch a multiple of 4 floats that covers roundup4(K)
+bool x_aligned(const LinBigP& p) { return (p.ldx & 3) == 0 && p.ldx >= ((p.K + 3) & ~3) && ((uintptr_t)p.x & 15) == 0; }
+bool w_aligned(const LinBigP& p) { return (p.K & 3) == 0 && ((uintptr_t)p.w & 15) == 0; }
+
+}  // namespace
+
+extern "C" int mms_linear_big_fwd(const LinBigP* pp, hipStream_t s) {
+    if (!pp || !args_ok(*pp)) return MMS_ERR_ARG;
+    const LinBigP& p = *pp;
+    const dim3 g((p.M + 63) / 64, (p.N + 63) / 64, 1);
+    const bool xa = x_aligned(p), wa = w_aligned(p);
+    if (xa && wa) return launch_tile_gemm<LinBigFwdOp<true, true>>(pp, 1, g, s);
+    if (xa) return launch_tile_gemm<LinBigFwdOp<true, false>>(pp, 1, g, s);
+    if (wa) return launch_tile_gemm<LinBigFwdOp<false, true>>(pp, 1, g, s);
+    return launch_tile_gemm<LinBigFwdOp<false, false>>(pp, 1, g, s);
+}
+
+extern "C" int mms_linear_big_bwd_w(const LinBigP* pp, hipStream_t s) {
+    if (!pp || !args_ok(*pp) || !pp->dy || !pp->dw || pp->msplit <= 0 || pp->lddy < pp->N) return MMS_ERR_ARG;
+    const LinBigP& p = *pp;
+    const dim3 g((p.N + 63) / 64, (p.K + 63) / 64, p.msplit);
+    return x_aligned(p) ? launch_tile_gemm<LinBigBwdWOp<true>>(pp, 1, g, s) : launch_tile_gemm<LinBigBwdWOp<false>>(pp, 1, g, s);
+}
+
+extern "C" int mms_linear_big_bwd_x(const LinBigP* pp, hipStream_t s) {
+    if (!pp || !args_ok(*pp) || !pp->dy || !pp->dbn || pp->lddy < pp->N || pp->lddbn < pp->K) return MMS_ERR_ARG;
+    const LinBigP& p = *pp;
+    if (!w_aligned(p) || (p.has_bn && (!p.s1 || !p.s2))) return MMS_ERR_ARG;
+    return launch_tile_gemm<LinBigBwdXOp>(pp, 1, dim3((p.M + 63) / 64, (p.K + 63) / 64, 1), s);
+}
+
+extern "C" int mms_bn1d_bwd_apply(const LinBigP* pp, hipStream_t s) {
+    if (!pp || !pp->has_bn || !pp->bn.train || !pp->dbn || !pp->dx || !pp->s1 || !pp->s2 || !pp->x || pp->M <= 0 || pp->K <= 0) return MMS_ERR_ARG;
+    const LinBigP& p = *pp;
+    MMS_LAUNCH(bn1d_bwd_apply_kernel, dim3((p.K + 63) / 64, (p.M + 63) / 64), dim3(256), 0, s, p);
+    return mms_check_launch();
+}

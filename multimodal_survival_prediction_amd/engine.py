@@ -187,7 +187,13 @@ class SurvivalEngine:
         P.has_enc = prog["encoder"] is not None
         D, H, W = dims if P.has_enc else (1, 1, 1)
         P.ct = torch.zeros(B, 1, D, H, W, device=dev)
-        P.buf = {k: torch.zeros(B, w, device=dev) for k, w in prog["bufs"].items()}
+        P.big = B > 32                 # rows beyond the one-lane-per-column head kernels: MFMA GEMM path (mms_linear_big_*)
+        if P.big and (P.has_enc or prog["gate"] is not None or prog.get("mix") is not None):
+            raise RuntimeError("batches of more than 32 rows are supported for the encoder-less RNASeqSurvivalModel only "
+                               "(the reference trains the imaging models at batch 4-16)")
+        # row pitch padded to a multiple of 4 floats so that the 5005-wide RNA rows are 16-B aligned (float4 operand loads)
+        P.buf = {k: torch.zeros(B, (w + 3) & ~3, device=dev)[:, :w] if P.big and w > 1 else torch.zeros(B, w, device=dev)
+                 for k, w in prog["bufs"].items()}
         P.dbuf = {k: torch.zeros(B, w, device=dev) for k, w in prog["bufs"].items() if k not in ("rna", "clin")}
         P.mask = torch.ones(B, 3, device=dev)
         P.time = torch.zeros(B, device=dev)
@@ -218,7 +224,9 @@ class SurvivalEngine:
         # head launches (train / eval variants)
         P.lin_fwd = {True: [], False: []}
         P.lin_bwd = []
-        for i, L in enumerate(prog["lins"]):
+        if P.big:
+            self._plan_big(P, gmap)
+        for i, L in enumerate(() if P.big else prog["lins"]):
             xs, xo = L.src
             ys, yo = L.dst
             x = P.buf[xs][:, xo:]
@@ -273,6 +281,62 @@ class SurvivalEngine:
         self.plans[key] = P
         return P
 
+    def _plan_big(self, P, gmap):
+        """LinBigP blocks (include/mmsurv.h) of the large-batch Linear chain.  BatchNorm1d statistics of a buffer live in one
+        fp64 array per plan: [sum | sumsq | s1 | s2] x columns, zeroed once per training step."""
+        prog, B, dev = self.prog, P.B, self.device
+        S, ptr = _S()["LinBigP"], ops.ptr
+        widths = {L.src[0]: L.lin.in_features for L in prog["lins"] if L.pro_bn is not None}
+        off, o = {}, 0
+        for name, k in widths.items():
+            off[name] = o
+            o += 4 * k
+        P.big_stats = torch.zeros(max(o, 1), dtype=torch.float64, device=dev)
+        P.big_dbn = torch.zeros(B, max(list(widths.values()) + [4]), device=dev)
+        st = lambda name, j: P.big_stats[off[name] + j * widths[name]:]
+        P.big_lin = {True: [], False: []}
+        for i, L in enumerate(prog["lins"]):
+            (xs, xo), (ys, yo) = L.src, L.dst
+            if xo or yo:
+                raise RuntimeError("large-batch path: column-offset buffers are not supported")
+            x, y = P.buf[xs], P.buf[ys]
+            K, N = L.lin.in_features, L.lin.out_features
+            for train in (True, False):
+                q = S()
+                q.x, q.ldx, q.M, q.K = x.data_ptr(), x.stride(0), B, K
+                q.w, q.bias, q.N = L.lin.weight.data_ptr(), L.lin.bias.data_ptr(), N
+                q.y, q.ldy, q.out_relu = y.data_ptr(), y.stride(0), 1 if L.out_relu else 0
+                q.train = 1 if train else 0
+                q.drop_p = float(L.pro_drop.p) if L.pro_drop is not None else 0.0
+                q.drop_mask, q.rng, q.stream_id = ptr(self.dropout_masks.get(i)), self.rng.data_ptr(), i + 1
+                bn = L.pro_bn
+                if bn is not None:
+                    q.has_bn = 1
+                    q.bn.sum, q.bn.sumsq = st(xs, 0).data_ptr(), st(xs, 1).data_ptr()
+                    q.bn.rmean, q.bn.rvar = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                    q.bn.gamma, q.bn.beta = bn.weight.data_ptr(), bn.bias.data_ptr()
+                    q.bn.inv_count, q.bn.eps, q.bn.train, q.bn.nrep, q.bn.rep_stride = 1.0 / B, float(bn.eps), q.train, 1, 0
+                    q.rmean, q.rvar, q.nbt = bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr()
+                    q.momentum = float(bn.momentum)
+                if train and ys in widths:           # a BatchNorm1d follows: the forward accumulates its batch statistics
+                    q.osum, q.osumsq = st(ys, 0).data_ptr(), st(ys, 1).data_ptr()
+                if train:
+                    dy = P.dbuf[ys]
+                    q.dy, q.lddy = dy.data_ptr(), dy.stride(0)
+                    q.dw, q.dbias = gmap[id(L.lin.weight)].data_ptr(), gmap[id(L.lin.bias)].data_ptr()
+                    tiles = ((N + 63) // 64) * ((K + 63) // 64)
+                    q.msplit = max(1, min((512 + tiles - 1) // tiles, (B + 63) // 64))
+                    if L.need_dx:
+                        dx = P.dbuf[xs]
+                        if bn is not None:
+                            q.dbn, q.lddbn = P.big_dbn.data_ptr(), P.big_dbn.stride(0)
+                            q.s1, q.s2 = st(xs, 2).data_ptr(), st(xs, 3).data_ptr()
+                            q.dx, q.lddx = dx.data_ptr(), dx.stride(0)
+                            q.dgamma, q.dbeta = gmap[id(bn.weight)].data_ptr(), gmap[id(bn.bias)].data_ptr()
+                        else:
+                            q.dbn, q.lddbn = dx.data_ptr(), dx.stride(0)
+                P.big_lin[train].append(q)
+
     def _prolog(self, L, idx, train):
         p = float(L.pro_drop.p) if (L.pro_drop is not None) else 0.0
         mask = self.dropout_masks.get(idx)
@@ -289,6 +353,12 @@ class SurvivalEngine:
             fwd = lib.mms_fb_forward if P.fallback else lib.mms_dn121_forward
             _lib.check(fwd(P.ws.data_ptr(), B, D, H, W, P.ct.data_ptr(), P.ptab, P.btab, out.data_ptr(),
                            feats.stride(0), 1 if train else 0, st), "encoder forward")
+        if P.big:
+            if train:
+                P.big_stats.zero_()
+            for q in P.big_lin[train]:
+                _lib.check(lib.mms_linear_big_fwd(ctypes.byref(q), st), "mms_linear_big_fwd")
+            return
         lf = P.lin_fwd[train]
         n_pre = prog["n_pre"]
         for i in range(n_pre):
@@ -307,6 +377,14 @@ class SurvivalEngine:
         lib, prog = self.lib, self.prog
         B, (D, H, W) = P.B, (P.dims if P.has_enc else (1, 1, 1))
         n_pre = prog["n_pre"]
+        if P.big:
+            for L, q in zip(reversed(prog["lins"]), reversed(P.big_lin[True])):
+                _lib.check(lib.mms_linear_big_bwd_w(ctypes.byref(q), st), "mms_linear_big_bwd_w")
+                if L.need_dx:
+                    _lib.check(lib.mms_linear_big_bwd_x(ctypes.byref(q), st), "mms_linear_big_bwd_x")
+                    if L.pro_bn is not None:
+                        _lib.check(lib.mms_bn1d_bwd_apply(ctypes.byref(q), st), "mms_bn1d_bwd_apply")
+            return
         for i in range(len(P.lin_bwd) - 1, n_pre - 1, -1):
             _lib.check(lib.mms_linear_bwd(ctypes.byref(P.lin_bwd[i]), st), "mms_linear_bwd")
         if P.gate is not None:

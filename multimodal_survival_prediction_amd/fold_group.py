@@ -73,6 +73,9 @@ class FoldGroupEngine:
         key = (B,) + (tuple(dims) if dims is not None else ()) + (members,)
         if key in self.plans:
             return self.plans[key]
+        if B > 32:
+            raise RuntimeError("fold groups batch the small-batch head kernels (<= 32 rows per model); train large-batch "
+                               "RNA-seq-only folds one engine at a time (SurvivalEngine.train_step)")
         eng = [self.engines[i] for i in members]
         Ps = [e.plan(B, dims) for e in eng]
         if any(P.fallback and P.has_enc for P in Ps):

@@ -1,0 +1,195 @@
+"""Large-batch Linear path (mms_linear_big_* in include/mmsurv.h; BASELINE config 5: RNA-seq-only model, batch 2048,
+train_rnaseq_only.py:126-176): the MFMA GEMM layers with fused BatchNorm1d / ReLU / Dropout against a plain torch fp32
+restatement of the same ops (op level) and against the CPU oracle's RNASeqSurvivalModel (model level).
+Tolerance: 1e-4 relative (north_star)."""
+import copy
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import DEV, assert_close
+from test_gpu_extra_models import _pair, _surv
+from test_gpu_models import _grad_stats
+
+
+def _block(M, K, N, ldx, has_bn, drop, out_relu, seed, train=True):
+    """One layer through the C ABI; -> dict of device results and the torch reference of each."""
+    from multimodal_survival_prediction_amd import _lib, ops
+    lib, S = _lib.load_library(), _lib.structs()
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(M, K, generator=g) * 1.5 + 0.3
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g) * 0.1
+    gamma, beta = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.1
+    rmean, rvar = torch.randn(K, generator=g) * 0.1, torch.rand(K, generator=g) + 0.5
+    mask = ((torch.rand(M, K, generator=g) > 0.3).float() / 0.7) if drop else None
+    dy = torch.randn(M, N, generator=g)
+    # ---- torch reference ----
+    xr, wr, br, gr, ber = [t.clone().requires_grad_(True) for t in (x, w, b, gamma, beta)]
+    h = xr
+    rm_ref, rv_ref = rmean.clone(), rvar.clone()
+    if has_bn:
+        h = torch.relu(torch.nn.functional.batch_norm(h, rm_ref, rv_ref, gr, ber, training=train, momentum=0.1, eps=1e-5))
+    if drop and train:
+        h = h * mask
+    y = h @ wr.t() + br
+    if out_relu:
+        y = torch.relu(y)
+    if train:
+        y.backward(dy)
+    # ---- device ----
+    xd = torch.zeros(M, ldx, device=DEV); xd[:, :K] = x.to(DEV)
+    d = dict(w=w, b=b, gamma=gamma, beta=beta, rmean=rmean, rvar=rvar, dy=dy)
+    d = {k: v.to(DEV).contiguous() for k, v in d.items()}
+    yd = torch.zeros(M, N, device=DEV)
+    stats = torch.zeros(4, K, dtype=torch.float64, device=DEV)
+    ostats = torch.zeros(2, N, dtype=torch.float64, device=DEV)
+    if has_bn:
+        stats[0] = xd[:, :K].double().sum(0); stats[1] = (xd[:, :K].double() ** 2).sum(0)
+    nbt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    dw, db = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+    dbn, dx = torch.zeros(M, K, device=DEV), torch.zeros(M, K, device=DEV)
+    dga, dbe = torch.zeros(K, device=DEV), torch.zeros(K, device=DEV)
+    maskd = mask.to(DEV).contiguous() if mask is not None else None
+    rng = torch.tensor([1, 0], dtype=torch.int32, device=DEV)
+    q = S["LinBigP"]()
+    q.x, q.ldx, q.M, q.K = xd.data_ptr(), ldx, M, K
+    q.w, q.bias, q.N = d["w"].data_ptr(), d["b"].data_ptr(), N
+    q.y, q.ldy, q.out_relu = yd.data_ptr(), N, int(out_relu)
+    q.has_bn = int(has_bn)
+    if has_bn:
+        q.bn.sum, q.bn.sumsq, q.bn.rmean, q.bn.rvar = stats[0].data_ptr(), stats[1].data_ptr(), d["rmean"].data_ptr(), d["rvar"].data_ptr()
+        q.bn.gamma, q.bn.beta, q.bn.inv_count, q.bn.eps, q.bn.train, q.bn.nrep = d["gamma"].data_ptr(), d["beta"].data_ptr(), 1.0 / M, 1e-5, int(train), 1
+        q.rmean, q.rvar, q.nbt, q.momentum = d["rmean"].data_ptr(), d["rvar"].data_ptr(), nbt.data_ptr(), 0.1
+    q.drop_p, q.drop_mask, q.rng, q.stream_id, q.train = (0.3 if drop else 0.0), ops.ptr(maskd), rng.data_ptr(), 1, int(train)
+    q.osum, q.osumsq = ostats[0].data_ptr(), ostats[1].data_ptr()
+    q.dy, q.lddy, q.dw, q.dbias, q.msplit = d["dy"].data_ptr(), N, dw.data_ptr(), db.data_ptr(), 3
+    q.dbn, q.lddbn, q.s1, q.s2 = dbn.data_ptr(), K, stats[2].data_ptr(), stats[3].data_ptr()
+    q.dx, q.lddx, q.dgamma, q.dbeta = dx.data_ptr(), K, dga.data_ptr(), dbe.data_ptr()
+    st = ops.stream()
+    _lib.check(lib.mms_linear_big_fwd(ctypes.byref(q), st), "fwd")
+    if train:
+        _lib.check(lib.mms_linear_big_bwd_w(ctypes.byref(q), st), "bwd_w")
+        if K % 4 == 0:
+            _lib.check(lib.mms_linear_big_bwd_x(ctypes.byref(q), st), "bwd_x")
+            if has_bn:
+                _lib.check(lib.mms_bn1d_bwd_apply(ctypes.byref(q), st), "bn1d_bwd_apply")
+    torch.cuda.synchronize()
+    assert_close(yd, y, 1e-4, "y")
+    yv = y.detach().double()
+    assert_close(ostats[0], yv.sum(0), 1e-5, "osum"); assert_close(ostats[1], (yv ** 2).sum(0), 1e-5, "osumsq")
+    if has_bn and train:
+        assert_close(d["rmean"], rm_ref, 1e-5, "running mean"); assert_close(d["rvar"], rv_ref, 1e-5, "running var")
+        assert int(nbt) == 1
+    if not train:
+        return
+    assert_close(dw, wr.grad, 1e-4, "dW"); assert_close(db, br.grad, 1e-4, "dbias")
+    if K % 4 == 0:
+        assert_close(dx if has_bn else dbn, xr.grad, 1e-4, "dx")
+        if has_bn:
+            assert_close(dga, gr.grad, 1e-4, "dgamma"); assert_close(dbe, ber.grad, 1e-4, "dbeta")
+
+
+@pytest.mark.parametrize("M,K,N,ldx,has_bn,drop,out_relu", [
+    (2048, 256, 128, 256, True, True, False),     # hidden layer of the RNA-seq MLP: BN + ReLU + dropout prologue
+    (300, 512, 256, 512, True, False, True),      # ragged rows (300 = 4*64 + 44), output ReLU
+    (129, 256, 1, 256, True, True, False),        # the 1-wide Cox head
+    (200, 5005, 192, 5008, False, False, False),  # first layer: padded 16-B aligned rows of x, unaligned weight rows
+    (200, 5005, 64, 5005, False, False, False),   # unpadded x: scalar loaders on both operands
+    (77, 37, 70, 40, False, False, True),         # tiny K (one partial tile), N not a multiple of 4
+    (640, 128, 64, 128, False, True, False),      # dropout-only prologue (simple_fusion.py fusion tail), dx written directly
+])
+def test_linear_big_ops_vs_torch(M, K, N, ldx, has_bn, drop, out_relu):
+    _block(M, K, N, ldx, has_bn, drop, out_relu, seed=M + K + N)
+
+
+def test_linear_big_eval_mode_uses_running_stats():
+    _block(300, 256, 64, 256, True, True, False, seed=5, train=False)
+
+
+def test_linear_big_rejects_bad_arguments():
+    from multimodal_survival_prediction_amd import _lib, ops
+    lib, S = _lib.load_library(), _lib.structs()
+    q = S["LinBigP"]()
+    assert lib.mms_linear_big_fwd(ctypes.byref(q), ops.stream()) == -1
+    assert lib.mms_linear_big_bwd_w(ctypes.byref(q), ops.stream()) == -1
+    assert lib.mms_linear_big_bwd_x(ctypes.byref(q), ops.stream()) == -1
+    assert lib.mms_bn1d_bwd_apply(ctypes.byref(q), ops.stream()) == -1
+
+
+@pytest.mark.parametrize("B", [2048, 300, 33])
+def test_rnaseq_model_large_batch_parity_and_fused_step(B):
+    """BASELINE config 5 at full size (B = 2048, 5005 genes) and two ragged sizes against the CPU oracle."""
+    from oracle import losses as OL
+    from multimodal_survival_prediction_amd import losses as HL
+    from multimodal_survival_prediction_amd.training import FusedOptimizer
+    ref, net = _pair("RNASeqSurvivalModel", 3, input_dim=5005)
+    rng = np.random.default_rng(B)
+    rna = torch.tensor(rng.normal(0, 1, (B, 5005)).astype(np.float32))
+    t, e = _surv(B, 9)
+    ref.eval(); net.eval()
+    with torch.no_grad():
+        assert_close(net(rna.to(DEV)), ref(rna), 1e-4, "eval log-hazard")
+    ref.train(); net.train()
+    hz = ref(rna).squeeze(); loss = OL.neg_partial_log_likelihood(hz, e.bool(), t); loss.backward()
+    hz2 = net(rna.to(DEV)).squeeze(); loss2 = HL.neg_partial_log_likelihood(hz2, e.to(DEV).bool(), t.to(DEV)); loss2.backward()
+    torch.cuda.synchronize()
+    assert_close(hz2, hz, 1e-4, "train log-hazard"); assert abs(loss2.item() - loss.item()) <= 1e-4 * max(1, abs(loss.item()))
+    p10, mx, l2, hmax = _grad_stats(ref, net)
+    assert hmax <= 1e-4 and l2 <= 1e-4, (hmax, l2)
+    for (k, a), (_, b) in zip(ref.named_buffers(), net.named_buffers()):
+        assert_close(b.float(), a.float(), 1e-5, k)          # running statistics, num_batches_tracked
+    # fused step == reference loop body (zero_grad, backward, AdamW step; no clipping), captured as one HIP graph
+    ref, net = _pair("RNASeqSurvivalModel", 4, input_dim=5005)
+    ref0 = copy.deepcopy(ref)
+    opt = torch.optim.AdamW(ref.parameters(), lr=1e-4, weight_decay=1e-3)
+    fo = FusedOptimizer(net, lr=1e-4, weight_decay=1e-3, adamw=True, max_norm=0.0)
+    ref.train(); net.train()
+    for it in range(2):
+        rna = torch.tensor(np.random.default_rng(40 + it).normal(0, 1, (B, 5005)).astype(np.float32))
+        t, e = _surv(B, 50 + it)
+        opt.zero_grad(); OL.neg_partial_log_likelihood(ref(rna).squeeze(), e.bool(), t).backward(); opt.step()
+        fo.engine.train_step(None, rna, time=t, event=e, skip_if_unusable=False)
+    torch.cuda.synchronize()
+    st = fo.engine.epoch_stats()
+    assert st["n_batches"] == 2 and st["n_usable"] == 2
+    # Adam's first steps move every weight by ~lr * sign(g): compare the updates where the gradient is not rounding noise
+    worst = 0.0
+    for (k, p), (_, q), (_, p0) in zip(ref.named_parameters(), net.named_parameters(), ref0.named_parameters()):
+        worst = max(worst, float(((p.detach() - p0.detach()) - (q.detach().cpu() - p0.detach())).abs().max()))
+    assert worst <= 4.2e-4, worst
+
+
+def test_large_batch_dropout_uses_hash_rng_and_varies_per_step():
+    """Hash dropout on the large-batch path: rate ~ p, a new mask every step (the rng step counter advances in the update)."""
+    from multimodal_survival_prediction_amd import models as HM
+    from multimodal_survival_prediction_amd.training import FusedOptimizer
+    torch.manual_seed(0)
+    net = HM.RNASeqSurvivalModel(input_dim=64, hidden_dims=[128, 64]).to(DEV).train()
+    fo = FusedOptimizer(net, lr=0.0, weight_decay=0.0, adamw=True, max_norm=0.0)
+    B = 512
+    rna = torch.randn(B, 64)
+    t, e = _surv(B, 1)
+    hz = []
+    for _ in range(2):
+        fo.engine.train_step(None, rna, time=t, event=e, skip_if_unusable=False)
+        torch.cuda.synchronize()
+        hz.append(fo.engine.plans[(B,)].buf["hz"][:, 0].clone())
+    assert not torch.allclose(hz[0], hz[1])                       # lr = 0: only the dropout mask changed
+    net.eval()
+    with torch.no_grad():
+        a, b = net(rna.to(DEV)), net(rna.to(DEV))
+    assert torch.equal(a, b)
+
+
+def test_fold_group_rejects_large_batches():
+    from multimodal_survival_prediction_amd import models as HM
+    from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
+    nets = [HM.RNASeqSurvivalModel(input_dim=64, hidden_dims=[32]).to(DEV) for _ in range(2)]
+    grp = FoldGroupEngine(nets, lr=1e-4, weight_decay=1e-3)
+    with pytest.raises(RuntimeError):
+        grp.plan(64, None)
