@@ -39,8 +39,9 @@ BLOCKS = ((6, 64), (12, 128), (24, 256), (16, 512))     # (layers, first-layer i
 
 
 def measure_dominant_kernel(B, dims, device, G=1, reps=20):
-    """Average launch duration of the dominant kernel -- tile_gemm_kernel<Conv3BwdWOp>, the weight gradient of the
-    dense-layer 3x3x3 conv (58 launches per group step, the largest share of GPU time in profiles/r01_*) -- timed live
+    """Average launch duration of the dominant kernel -- the weight gradient of the dense-layer 3x3x3 conv
+    (mms_conv3_bwd_weight_group: conv3_bwdw_mt_kernel for the block-1 launches of groups, tile_gemm_kernel<Conv3BwdWOp>
+    otherwise; 58 launches per group step, the largest share of GPU time in profiles/r01_*) -- timed live
     with HIP events on the launch stream (torch's current stream), launched exactly as the timed region launches it:
     one launch carries the G models of a fold group (mms_conv3_bwd_weight_group), shape by shape with the driver's own
     split factors, weighted by the launch counts.  Algorithmic FLOPs per launch = G * 2 * M * 27 * 128 * 32."""
@@ -54,6 +55,8 @@ def measure_dominant_kernel(B, dims, device, G=1, reps=20):
         gd = (D // 4 >> i, H // 4 >> i, W // 4 >> i)
         M = B * gd[0] * gd[1] * gd[2]
         rows, rows_s = (1024, 256) if G >= 4 else (512, 128)                     # dn_net.hip: ms3
+        if G >= 4 and M > 1024 and -(-M // 1024) * G * 9 < 512 <= -(-M // 512) * G * 9:
+            rows = 512                                                           # ... 4-7 models: multi-tap kernel on 512-row chunks
         ms = (M + rows - 1) // rows if M > 1024 else max((M + rows_s - 1) // rows_s, 1)
         coords = ops.init_coords(B, gd, device)
         keep, blocks = [], []

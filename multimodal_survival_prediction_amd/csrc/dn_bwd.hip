@@ -239,6 +239,9 @@ struct Conv3BwdWOp {
     }
     __device__ void epilogue(const Params& p, int, int, int, const float* Cs, int tid, bool active) {
         if (mb >= me || !active) return;
+#ifdef MMS_ABLATE_FLUSH
+        if (p.M > 0) return;
+#endif
         for (int idx = tid; idx < TM * TN; idx += 256) {
             const int cin = idx & 127, co = idx >> 7;
             const size_t dst = p.dw_tapmajor ? ((size_t)tap * 32 + co) * 128 + cin : ((size_t)co * 128 + cin) * 27 + tap;
@@ -309,6 +312,159 @@ extern "C" int mms_unpack_conv3_grads(const void* table_host, int nlayers, hipSt
     return mms_check_launch();
 }
 
+// ------------------------------------------------------------------------------------------------------
+// conv3 backward-weight, multi-tap form (launches with enough row chunks to fill the chip with a third of the workgroups):
+// a workgroup owns one (model, row chunk, kd, kh) and produces the gradients of its THREE kw taps at once.  Their a2 operands
+// are the same rows shifted by one voxel, so per 32-row step the a2 rows [r0-1, r0+33) + off(kd,kh) are normalised and staged
+// ONCE (34 x 128, k-major) and every fragment read from LDS feeds three MFMAs (three independent accumulators per wave,
+// wave w = input channels 32w..32w+31); the tap validity (zero padding) rides on the small operand: dz[r] * valid(r, tap),
+// applied in registers from the chunk's 9-bit masks.  Versus the one-tap GEMM form: a third of the a2 loads / BN transforms /
+// LDS stores per MFMA and 81 instead of 96 LDS fragment reads per 48 MFMAs.
+// ------------------------------------------------------------------------------------------------------
+#define C3W_AP 132                      // a2 image pitch (floats): [34][132]
+#define C3W_BP 36                       // dz image pitch: [32][36]
+#define C3W_STAGE (34 * C3W_AP + 32 * C3W_BP)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void conv3_bwdw_mt_kernel(const Grp<Conv3BwdWP> grp) {
+    // blockIdx.z = flat over (model, chunk, kd*3+kh); the 9 workgroups of a (model, chunk) pair share their rows: one XCD per pair
+    int gi, z;
+    {
+        const int flat = blockIdx.z, nflat = gridDim.z, zdim = grp.zdim, pairs = nflat / 9, ms = zdim / 9;
+        if ((pairs & 7) == 0) {
+            const int x = flat & 7, slot = flat >> 3, pair = (slot / 9) * 8 + x;
+            gi = pair / ms;
+            z = (pair - gi * ms) * 9 + slot % 9;
+        } else { gi = flat / zdim; z = flat - gi * zdim; }
+    }
+    const Conv3BwdWP& p = grp.p[gi];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned* vm = (unsigned*)(smem + 2 * C3W_STAGE);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
+    const int kdh = z % 9, chunk = z / 9, kd = kdh / 3, kh = kdh - 3 * kd;
+    const int offdh = ((kd - 1) * p.g.H + (kh - 1)) * p.g.W;
+    int mc = (p.M + p.msplit - 1) / p.msplit;
+    mc = (mc + 31) & ~31;
+    const int mb = chunk * mc, me = mb + mc < p.M ? mb + mc : p.M;
+    if (mb >= me) return;
+    const int c0 = (tid & 31) * 4;
+    float mean[4], sc[4], beta[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float mu, rstd;
+        bn_mean_rstd(p.bn, c0 + j, mu, rstd);
+        mean[j] = mu; sc[j] = p.bn.gamma[c0 + j] * rstd; beta[j] = p.bn.beta[c0 + j];
+    }
+    for (int j = tid; j < mc; j += 256) vm[j] = (mb + j < me) ? tap_mask9(p.coords[mb + j], p.g, false) : 0u;
+    const unsigned selb = (1u << kd) | (8u << kh), sel0 = selb | 64u, sel1 = selb | 128u, sel2 = selb | 256u;
+
+    float4 ra[5], rb;
+    unsigned oka = 0;
+    auto gload = [&](int r0) __attribute__((always_inline)) {
+        oka = 0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int j = (tid >> 5) + 8 * i, src = r0 + j - 1 + offdh;
+            const bool ok = j < 34 && src >= 0 && src < p.M;
+            oka |= (ok ? 1u : 0u) << i;
+            ra[i] = ok ? *(const float4*)(p.y1 + (size_t)src * 128 + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const int m = r0 + (tid >> 3);
+        rb = m < me ? *(const float4*)(p.dz + (size_t)m * p.lddz + (tid & 7) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto sstore = [&](float* st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int j = (tid >> 5) + 8 * i;
+            if (j < 34) {
+                const float zf = (oka >> i) & 1u ? 1.f : 0.f;
+                *(float4*)&st[j * C3W_AP + c0] =
+                    make_float4(zf * fmaxf(bn_apply(ra[i].x, mean[0], sc[0], beta[0]), 0.f), zf * fmaxf(bn_apply(ra[i].y, mean[1], sc[1], beta[1]), 0.f),
+                                zf * fmaxf(bn_apply(ra[i].z, mean[2], sc[2], beta[2]), 0.f), zf * fmaxf(bn_apply(ra[i].w, mean[3], sc[3], beta[3]), 0.f));
+            }
+        }
+        *(float4*)&st[34 * C3W_AP + (tid >> 3) * C3W_BP + (tid & 7) * 4] = rb;
+    };
+    f32x16 acc0, acc1, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
+    auto mma = [&](const float* st, int t) __attribute__((always_inline)) {
+        const float* at = st + h * C3W_AP + 32 * wave + li;          // lane (i = li, k-parity h): a2 image rows j + h
+        const float* bt = st + 34 * C3W_AP + h * C3W_BP + li;         // dz rows k + h, column cout = li
+        const unsigned* vt = vm + 32 * t + h;
+        float a[33];
+#ifdef C3W_NO_READ
+#pragma unroll
+        for (int j = 0; j < 33; ++j) a[j] = (float)(j + t);
+#else
+#pragma unroll
+        for (int j = 0; j < 33; ++j) a[j] = at[j * C3W_AP];
+#endif
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int kk = 2 * q;
+#ifdef C3W_NO_READ
+            const float b = (float)(q + t);
+            const unsigned mk = sel0 | sel1 | (unsigned)(t & 1) << 8;
+#else
+            const float b = bt[kk * C3W_BP];
+            const unsigned mk = vt[kk];
+#endif
+#ifdef C3W_NO_MFMA
+            acc0[q] += a[kk] * ((mk & sel0) == sel0 ? b : 0.f);
+            acc1[q] += a[kk + 1] * ((mk & sel1) == sel1 ? b : 0.f);
+            acc2[q] += a[kk + 2] * ((mk & sel2) == sel2 ? b : 0.f);
+#else
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], (mk & sel0) == sel0 ? b : 0.f, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk + 1], (mk & sel1) == sel1 ? b : 0.f, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk + 2], (mk & sel2) == sel2 ? b : 0.f, acc2, 0, 0, 0);
+#endif
+        }
+    };
+    const int T = (me - mb + 31) / 32;
+    gload(mb);
+    sstore(smem);
+    __syncthreads();                                                   // also publishes vm
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        float* cur = smem + (t & 1) * C3W_STAGE;
+        float* nxt = smem + ((t + 1) & 1) * C3W_STAGE;
+#ifndef C3W_NO_LOAD
+        if (t + 1 < T) gload(mb + 32 * (t + 1));                     // in flight during the matrix phase
+#endif
+        mma(cur, t);
+#ifndef C3W_NO_LOAD
+        if (t + 1 < T) sstore(nxt);                                   // the other buffer: last read before the previous barrier
+#endif
+#ifndef C3W_NO_BARRIER
+        __syncthreads();
+#endif
+    }
+    // ---- flush: one tap at a time through LDS so that the atomics run along cin (contiguous in the tap-major scratch)
+    float* Cs = smem;                                                  // [128][33]
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const f32x16& acc = kw == 0 ? acc0 : (kw == 1 ? acc1 : acc2);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Cs[(32 * wave + 4 * h + (r & 3) + 8 * (r >> 2)) * 33 + li] = acc[r];
+        __syncthreads();
+        const int tap = kdh * 3 + kw;
+        for (int idx = tid; idx < 128 * 32; idx += 256) {
+            const int cin = idx & 127, co = idx >> 7;
+            const size_t dst = p.dw_tapmajor ? ((size_t)tap * 32 + co) * 128 + cin : ((size_t)co * 128 + cin) * 27 + tap;
+            atomicAdd(&p.dw[dst], Cs[cin * 33 + co]);
+        }
+        __syncthreads();
+    }
+}
+// MMS_CONV3W_MT: 0 = never, 2 = always (tests); default: chunks of >= 512 rows (16 steps to amortise the three-tap flush) whose
+// 9-per-chunk grid still fills the chip (measured, 10 models x 8192 rows: 250 -> 227 us; 5 models, 512-row chunks: 139 -> 123 us;
+// 1024-row blocks and single models are faster on the one-tap form, see tools/run_mt.sh)
+static inline bool conv3w_mt_ok(int rows_per_chunk, int msplit, int ng) {
+    const char* e = getenv("MMS_CONV3W_MT");
+    if (e && e[0] == '0') return false;
+    if (e && e[0] == '2') return true;
+    return rows_per_chunk >= 512 && (long)msplit * ng * 9 >= 512;
+}
+
 extern "C" int mms_conv3_bwd_weight_group(const Conv3BwdWP* pp, int ng, hipStream_t s) {
     if (!pp || ng < 1 || ng > MMS_MAX_GROUP) return MMS_ERR_ARG;
     const Conv3BwdWP& p = *pp;
@@ -318,6 +474,13 @@ extern "C" int mms_conv3_bwd_weight_group(const Conv3BwdWP* pp, int ng, hipStrea
         const Conv3BwdWP& q = pp[g];
         if (q.M != p.M || q.msplit != p.msplit || q.lddz % 4 != 0 || q.g.D != p.g.D || q.g.H != p.g.H || q.g.W != p.g.W ||
             q.dw_tapmajor != p.dw_tapmajor) return MMS_ERR_ARG;
+    }
+    if (conv3w_mt_ok(((p.M + p.msplit - 1) / p.msplit + 31) & ~31, p.msplit, ng)) {
+        constexpr int smem = (2 * C3W_STAGE + 1024) * (int)sizeof(float);            // 49.2 KB: 3 workgroups per CU
+        Grp<Conv3BwdWP> a;
+        if (!grp_fill(a, pp, ng, 9 * p.msplit)) return MMS_ERR_ARG;
+        MMS_LAUNCH(conv3_bwdw_mt_kernel, dim3(1, 1, 9 * p.msplit * ng), dim3(256), smem, s, a);
+        return mms_check_launch();
     }
     return launch_tile_gemm<Conv3BwdWOp>(pp, ng, dim3(1, 1, 27 * p.msplit), s);
 }

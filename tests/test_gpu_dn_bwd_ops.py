@@ -25,7 +25,7 @@ def _d(t):
                                               # shapes that take the multi-tap forward kernel in the layer's forward: ragged last tile, W = 16
                                               (3, (7, 7, 8), 64, 256, 4), (2, (8, 16, 16), 96, 256, 8)])
 @pytest.mark.parametrize("split", [0, 27, 3])
-def test_dense_layer_backward(ops, B, dims, C, Ctot, ms, split):
+def test_dense_layer_backward(ops, B, dims, C, Ctot, ms, split, monkeypatch):
     """One _DenseLayer: norm1-relu-conv1-norm2-relu-conv2 + cat; gradient w.r.t. every parameter and the input slab."""
     torch.manual_seed(0)
     M = B * dims[0] * dims[1] * dims[2]
@@ -61,7 +61,13 @@ def test_dense_layer_backward(ops, B, dims, C, Ctot, ms, split):
     part = torch.empty(27 * M * 128, device=DEV) if split else None
     ops.conv3_bwd_data(dslab[:, C:C + 32], coords, dims, wpb, y1d, bn2, dbn_mid, a1, a2, part, split or 27)
     dw2 = torch.zeros_like(w2)
+    monkeypatch.setenv("MMS_CONV3W_MT", "0")            # one-tap GEMM form
     ops.conv3_bwd_weight(y1d, coords, dims, bn2, dslab[:, C:C + 32], dw2, ms)
+    monkeypatch.setenv("MMS_CONV3W_MT", "2")            # multi-tap form (three kw taps per workgroup), both gradient layouts
+    dw2m, dw2t = torch.zeros_like(w2), torch.zeros(27, 32, 128, device=DEV)
+    ops.conv3_bwd_weight(y1d, coords, dims, bn2, dslab[:, C:C + 32], dw2m, ms)
+    ops.conv3_bwd_weight(y1d, coords, dims, bn2, dslab[:, C:C + 32], dw2t, ms, tapmajor=True)
+    monkeypatch.delenv("MMS_CONV3W_MT")
     dw1 = torch.zeros_like(w1)
     dg2, db2, dg1, db1 = (torch.zeros(128, device=DEV), torch.zeros(128, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV))
     dbn_in = torch.empty(M, Ctot, device=DEV)
@@ -73,6 +79,8 @@ def test_dense_layer_backward(ops, B, dims, C, Ctot, ms, split):
     ops.bn_bwd_apply(dbn_in, slab, dslab, M, C, bn1, ops.bnbwd(e1, e2), True, dg1, db1)
     torch.cuda.synchronize()
     assert_close(dw2, c2.weight.grad, 1e-4, "dW conv2")
+    assert_close(dw2m, c2.weight.grad, 1e-4, "dW conv2 (multi-tap kernel)")
+    assert_close(dw2t.permute(1, 2, 0).reshape(32, 128, 3, 3, 3), c2.weight.grad, 1e-4, "dW conv2 (multi-tap kernel, tap-major scratch)")
     assert_close(dg2, n2.weight.grad, 1e-4, "dgamma2")
     assert_close(db2, n2.bias.grad, 1e-4, "dbeta2")
     assert_close(dw1, c1.weight.grad.view(128, C), 1e-4, "dW conv1")

@@ -13,6 +13,10 @@ lib, S = _lib.load_library(), _lib.structs()
 gd = (D // 4 >> which, H // 4 >> which, W // 4 >> which)
 M = B * gd[0] * gd[1] * gd[2]
 rows, rows_s = (1024, 256) if G >= 4 else (512, 128)            # dn_net.hip: ms3
+if G >= 4 and M > 1024 and -(-M // 1024) * G * 9 < 512 <= -(-M // 512) * G * 9:
+    rows = 512
+if len(sys.argv) > 4:
+    rows = rows_s = int(sys.argv[4])
 ms = (M + rows - 1) // rows if M > 1024 else max((M + rows_s - 1) // rows_s, 1)
 g, b = torch.ones(128, device=dev), torch.zeros(128, device=dev)
 coords = ops.init_coords(B, gd, dev)
@@ -27,7 +31,13 @@ for _ in range(G):
     keep.append((y1, s, q, dslab, dwp))
     blocks.append(S["Conv3BwdWP"](y1.data_ptr(), coords.data_ptr(), ops.dims3(gd), M, bn, dz.data_ptr(), dz.stride(0), dwp.data_ptr(), ms, 1))
 arr = (S["Conv3BwdWP"] * G)(*blocks)
+for _ in range(3):
+    _lib.check(lib.mms_conv3_bwd_weight_group(arr, G, ops.stream()), "conv3_bwd_weight_group")
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
 for _ in range(reps):
     _lib.check(lib.mms_conv3_bwd_weight_group(arr, G, ops.stream()), "conv3_bwd_weight_group")
+e1.record()
 torch.cuda.synchronize()
+print("us per launch %.1f" % (e0.elapsed_time(e1) * 1e3 / reps))
 print("block", which, "M", M, "msplit", ms, "G", G, "algorithmic bytes per launch", G * (M * 128 * 4 + M * 32 * 4 + 27 * 32 * 128 * 4))
