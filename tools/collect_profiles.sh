@@ -8,16 +8,18 @@ cp $(ls /tmp/pf1/*/*_kernel_stats.csv | head -1) $O/kernel_stats.csv
 rm -rf /tmp/pf2; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf2 -- python3 $R/bench.py --roofline-only > $O/roofline_leg.json 2> /dev/null
 cp $(ls /tmp/pf2/*/*_kernel_stats.csv | head -1) $O/roofline_leg_kernel_stats.csv
 python3 - $(ls /tmp/pf2/*/*_kernel_trace.csv | head -1) >> $O/roofline_leg.json <<'PY'
-import csv, sys, collections, json
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if 'Conv3BwdWOp' in r['Kernel_Name']]
-by = collections.defaultdict(list)
-for r in rows:
-    by[int(r['Grid_Size_Z'])].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
-shapes = sorted(by, reverse=True)                      # block 1..4 (grid z = 27 * msplit * models); blocks 3 and 4 share z = 270
-layers = dict(zip(shapes, (6, 12, 24, 16) if len(shapes) == 4 else (6, 12, 40)))
-avg = {z: sum(v[3:]) / len(v[3:]) / 1e3 for z, v in by.items()}          # skip the 3 warm-up launches per shape
-w = sum(avg[z] * layers[z] for z in shapes) / 58.0
-print(json.dumps({"rocprofv3_kernel_trace_of_this_command": {"per_shape_avg_us": {str(z): round(avg[z], 2) for z in shapes},
+import csv, sys, json
+# the leg launches the weight-gradient kernel block by block: 3 warm-up + 20 timed launches per block shape, in order
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if 'Conv3BwdWOp' in r['Kernel_Name'] or 'conv3_bwdw_mt' in r['Kernel_Name']]
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+assert len(rows) == 4 * 23, len(rows)
+layers, avg, names = (6, 12, 24, 16), [], []
+for b in range(4):
+    seg = rows[23 * b + 3:23 * (b + 1)]
+    avg.append(sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in seg) / len(seg) / 1e3)
+    names.append(seg[0]['Kernel_Name'].split('(')[0][-40:] + ' z=' + seg[0]['Grid_Size_Z'])
+w = sum(a * l for a, l in zip(avg, layers)) / 58.0
+print(json.dumps({"rocprofv3_kernel_trace_of_this_command": {"per_block_avg_us": [round(a, 2) for a in avg], "kernels": names,
                   "layer_weighted_avg_us": round(w, 2)}}))
 PY
 # 2. PMC passes (kernel-trace only) on the dominant kernel, group launches, per block shape
@@ -27,7 +29,7 @@ for blk in 0 1 2 3; do
     f=$(ls /tmp/pm/*/*_counter_collection.csv | head -1)
     python3 - "$f" $blk $c >> $O/pmc_conv3bwdw.txt <<'PY'
 import csv,sys
-rows=[r for r in csv.DictReader(open(sys.argv[1])) if 'Conv3BwdWOp' in r['Kernel_Name'] and r['Counter_Name']==sys.argv[3]]
+rows=[r for r in csv.DictReader(open(sys.argv[1])) if ('Conv3BwdWOp' in r['Kernel_Name'] or 'conv3_bwdw_mt' in r['Kernel_Name']) and r['Counter_Name']==sys.argv[3]]
 v=[float(r['Counter_Value']) for r in rows]
 print('block',sys.argv[2],sys.argv[3],'dispatches',len(v),'mean',sum(v)/max(len(v),1))
 PY
