@@ -55,8 +55,9 @@ def measure_dominant_kernel(B, dims, device, G=1, reps=20):
         gd = (D // 4 >> i, H // 4 >> i, W // 4 >> i)
         M = B * gd[0] * gd[1] * gd[2]
         rows, rows_s = (1024, 256) if G >= 4 else (512, 128)                     # dn_net.hip: ms3
-        if G >= 4 and M > 1024 and -(-M // 1024) * G * 9 < 512 <= -(-M // 512) * G * 9:
-            rows = 512                                                           # ... 4-7 models: multi-tap kernel on 512-row chunks
+        fills = lambda w: w * 10 >= -(-w // 768) * 768 * 9                     # dn_ops.h: mms_conv3w_mt_fills
+        if G >= 4 and M > 1024 and not fills(-(-M // 1024) * G * 9) and fills(-(-M // 512) * G * 9):
+            rows = 512                                                           # ... e.g. 5 models: multi-tap kernel on 512-row chunks
         ms = (M + rows - 1) // rows if M > 1024 else max((M + rows_s - 1) // rows_s, 1)
         coords = ops.init_coords(B, gd, device)
         keep, blocks = [], []

@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     }
     const Conv3BwdWP& p = grp.p[gi];
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    unsigned* vm = (unsigned*)(smem + 2 * C3W_STAGE);
+    float2* vf = (float2*)(smem + 2 * C3W_STAGE);                      // per chunk row: 1/0 for "kw = 0 valid", "kw = 2 valid"
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
     const int kdh = z % 9, chunk = z / 9, kd = kdh / 3, kh = kdh - 3 * kd;
     const int offdh = ((kd - 1) * p.g.H + (kh - 1)) * p.g.W;
@@ -353,11 +353,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         bn_mean_rstd(p.bn, c0 + j, mu, rstd);
         mean[j] = mu; sc[j] = p.bn.gamma[c0 + j] * rstd; beta[j] = p.bn.beta[c0 + j];
     }
-    for (int j = tid; j < mc; j += 256) vm[j] = (mb + j < me) ? tap_mask9(p.coords[mb + j], p.g, false) : 0u;
-    const unsigned selb = (1u << kd) | (8u << kh), sel0 = selb | 64u, sel1 = selb | 128u, sel2 = selb | 256u;
+    // zero padding: the (kd, kh) part of a row's tap validity is common to the three taps and is folded into the staged dz
+    // row; the kw part (kw = 1 is always valid) is a per-row factor pair read next to the dz fragment
+    for (int j = tid; j < mc; j += 256) {
+        const unsigned mk = (mb + j < me) ? tap_mask9(p.coords[mb + j], p.g, false) : 0u;
+        vf[j] = make_float2(mk & 64u ? 1.f : 0.f, mk & 256u ? 1.f : 0.f);
+    }
+    const unsigned selb = (1u << kd) | (8u << kh);
 
     float4 ra[5], rb;
     unsigned oka = 0;
+    bool okb = false;
     auto gload = [&](int r0) __attribute__((always_inline)) {
         oka = 0;
 #pragma unroll
@@ -369,6 +375,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         }
         const int m = r0 + (tid >> 3);
         rb = m < me ? *(const float4*)(p.dz + (size_t)m * p.lddz + (tid & 7) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        okb = m < me && (tap_mask9(p.coords[m], p.g, false) & selb) == selb;
     };
     auto sstore = [&](float* st) __attribute__((always_inline)) {
 #pragma unroll
@@ -381,7 +388,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
                                 zf * fmaxf(bn_apply(ra[i].z, mean[2], sc[2], beta[2]), 0.f), zf * fmaxf(bn_apply(ra[i].w, mean[3], sc[3], beta[3]), 0.f));
             }
         }
-        *(float4*)&st[34 * C3W_AP + (tid >> 3) * C3W_BP + (tid & 7) * 4] = rb;
+        const float zb = okb ? 1.f : 0.f;
+        *(float4*)&st[34 * C3W_AP + (tid >> 3) * C3W_BP + (tid & 7) * 4] = make_float4(zb * rb.x, zb * rb.y, zb * rb.z, zb * rb.w);
     };
     f32x16 acc0, acc1, acc2;
 #pragma unroll
@@ -389,7 +397,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     auto mma = [&](const float* st, int t) __attribute__((always_inline)) {
         const float* at = st + h * C3W_AP + 32 * wave + li;          // lane (i = li, k-parity h): a2 image rows j + h
         const float* bt = st + 34 * C3W_AP + h * C3W_BP + li;         // dz rows k + h, column cout = li
-        const unsigned* vt = vm + 32 * t + h;
+        const float2* vt = vf + 32 * t + h;
         float a[33];
 #ifdef C3W_NO_READ
 #pragma unroll
@@ -403,26 +411,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
             const int kk = 2 * q;
 #ifdef C3W_NO_READ
             const float b = (float)(q + t);
-            const unsigned mk = sel0 | sel1 | (unsigned)(t & 1) << 8;
+            const float2 f = make_float2((float)(t & 1), 1.f);
 #else
             const float b = bt[kk * C3W_BP];
-            const unsigned mk = vt[kk];
+            const float2 f = vt[kk];
 #endif
 #ifdef C3W_NO_MFMA
-            acc0[q] += a[kk] * ((mk & sel0) == sel0 ? b : 0.f);
-            acc1[q] += a[kk + 1] * ((mk & sel1) == sel1 ? b : 0.f);
-            acc2[q] += a[kk + 2] * ((mk & sel2) == sel2 ? b : 0.f);
+            acc0[q] += a[kk] * (b * f.x);
+            acc1[q] += a[kk + 1] * b;
+            acc2[q] += a[kk + 2] * (b * f.y);
 #else
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], (mk & sel0) == sel0 ? b : 0.f, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk + 1], (mk & sel1) == sel1 ? b : 0.f, acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk + 2], (mk & sel2) == sel2 ? b : 0.f, acc2, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b * f.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk + 1], b, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk + 2], b * f.y, acc2, 0, 0, 0);
 #endif
         }
     };
     const int T = (me - mb + 31) / 32;
     gload(mb);
     sstore(smem);
-    __syncthreads();                                                   // also publishes vm
+    __syncthreads();                                                   // also publishes vf
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
         float* cur = smem + (t & 1) * C3W_STAGE;
@@ -456,13 +464,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     }
 }
 // MMS_CONV3W_MT: 0 = never, 2 = always (tests); default: chunks of >= 512 rows (16 steps to amortise the three-tap flush) whose
-// 9-per-chunk grid still fills the chip (measured, 10 models x 8192 rows: 250 -> 227 us; 5 models, 512-row chunks: 139 -> 123 us;
-// 1024-row blocks and single models are faster on the one-tap form, see tools/run_mt.sh)
+// 9-per-chunk grid fills >= 90 % of a whole number of rounds of the chip (3 workgroups x 256 CUs).  Measured per launch,
+// block 1 of a fold group (tools/run_mt.sh): 10 models x 8192 rows, 720 workgroups: 247 -> 216 us; 5 models on 512-row chunks,
+// 720: 135 -> 119 us; but 8 models (576 workgroups = 0.75 round): 199 -> 210 us, 4 models on 512-row chunks (576): 108 -> 116 us.
 static inline bool conv3w_mt_ok(int rows_per_chunk, int msplit, int ng) {
     const char* e = getenv("MMS_CONV3W_MT");
     if (e && e[0] == '0') return false;
     if (e && e[0] == '2') return true;
-    return rows_per_chunk >= 512 && (long)msplit * ng * 9 >= 512;
+    return rows_per_chunk >= 512 && mms_conv3w_mt_fills((long)msplit * ng * 9);
 }
 
 extern "C" int mms_conv3_bwd_weight_group(const Conv3BwdWP* pp, int ng, hipStream_t s) {
@@ -476,7 +485,7 @@ extern "C" int mms_conv3_bwd_weight_group(const Conv3BwdWP* pp, int ng, hipStrea
             q.dw_tapmajor != p.dw_tapmajor) return MMS_ERR_ARG;
     }
     if (conv3w_mt_ok(((p.M + p.msplit - 1) / p.msplit + 31) & ~31, p.msplit, ng)) {
-        constexpr int smem = (2 * C3W_STAGE + 1024) * (int)sizeof(float);            // 49.2 KB: 3 workgroups per CU
+        constexpr int smem = (2 * C3W_STAGE + 2 * 1024) * (int)sizeof(float);        // 53.3 KB: 3 workgroups per CU
         Grp<Conv3BwdWP> a;
         if (!grp_fill(a, pp, ng, 9 * p.msplit)) return MMS_ERR_ARG;
         MMS_LAUNCH(conv3_bwdw_mt_kernel, dim3(1, 1, 9 * p.msplit * ng), dim3(256), smem, s, a);

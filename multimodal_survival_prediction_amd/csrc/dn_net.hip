@@ -378,8 +378,8 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
             const char* e3 = getenv("MMS_MS3_ROWS");
             int rows3 = e3 ? atoi(e3) : (ng >= 4 ? 1024 : 512);
             const int rows3s = e3 ? 128 : (ng >= 4 ? 256 : 128);
-            // groups of 4-7 models: 512-row chunks put the launch on the multi-tap kernel (needs >= 512 workgroups at 9 per chunk)
-            if (!e3 && ng >= 4 && M > 1024 && (long)((M + 1023) / 1024) * ng * 9 < 512 && (long)((M + 511) / 512) * ng * 9 >= 512) rows3 = 512;
+            // 512-row chunks when that (and not the default) puts the launch on the multi-tap kernel with a well-filled grid (5-model groups)
+            if (!e3 && ng >= 4 && M > 1024 && !mms_conv3w_mt_fills((long)((M + 1023) / 1024) * ng * 9) && mms_conv3w_mt_fills((long)((M + 511) / 512) * ng * 9)) rows3 = 512;
             int ms3 = M > 1024 ? (M + rows3 - 1) / rows3 : (M + rows3s - 1) / rows3s; if (ms3 < 1) ms3 = 1;
             int ms1 = M > 1024 ? M / 256 : M / 128; if (ms1 < 1) ms1 = 1; if (ms1 > 32) ms1 = 32;
             { const char* e = getenv("MMS_MS1_DIV"); const int dv = e ? atoi(e) : (ng >= 4 ? 2 : 1); if (dv > 1) { ms1 = ms1 / dv; if (ms1 < 1) ms1 = 1; } }   // groups: half the chunks (fewer atomic flushes)

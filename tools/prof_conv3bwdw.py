@@ -13,7 +13,8 @@ lib, S = _lib.load_library(), _lib.structs()
 gd = (D // 4 >> which, H // 4 >> which, W // 4 >> which)
 M = B * gd[0] * gd[1] * gd[2]
 rows, rows_s = (1024, 256) if G >= 4 else (512, 128)            # dn_net.hip: ms3
-if G >= 4 and M > 1024 and -(-M // 1024) * G * 9 < 512 <= -(-M // 512) * G * 9:
+fills = lambda w: w * 10 >= -(-w // 768) * 768 * 9                     # dn_ops.h: mms_conv3w_mt_fills
+if G >= 4 and M > 1024 and not fills(-(-M // 1024) * G * 9) and fills(-(-M // 512) * G * 9):
     rows = 512
 if len(sys.argv) > 4:
     rows = rows_s = int(sys.argv[4])
