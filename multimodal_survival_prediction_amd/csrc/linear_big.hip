@@ -34,6 +34,18 @@ struct Prolog {
     }
 };
 
+// 16-byte load from a 4-byte aligned address (rows of a [N][5005] weight): one global_load_dwordx4, the hardware splits it
+typedef float f4u_t __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ float4 ld4u(const float* p) {
+    const f4u_t v = *(const f4u_t*)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+// elements k..k+3 of a K-long row (zero beyond the row end; the last partial quad is read element-wise: no over-read)
+__device__ __forceinline__ float4 ld4_row(const float* row, int k, int K) {
+    if (k + 3 < K) return ld4u(row + k);
+    return make_float4(row[k], k + 1 < K ? row[k + 1] : 0.f, k + 2 < K ? row[k + 2] : 0.f, 0.f);
+}
+
 // zero the lanes of a float4 that lie beyond column K (pad columns of a padded row carry no data)
 __device__ __forceinline__ float4 tail4(float4 v, int k, int K) {
     if (k + 3 < K) return v;
@@ -44,8 +56,8 @@ __device__ __forceinline__ float4 tail4(float4 v, int k, int K) {
 // forward:  y[m][n] = sum_k P(x)[m][k] * W[n][k] + bias[n]
 // ---------------------------------------------------------------------------------------------------------------------
 // XA: rows of x are 16-B aligned and padded to a multiple of 4 floats (ldx >= roundup4(K), pad columns readable) -> float4
-// loads; WA: K % 4 == 0 -> float4 loads of the weight rows.  Otherwise scalar (still coalesced along k) loads: the
-// 5005-wide first layer reads its [N][5005] weight that way.
+// loads; WA: 16-byte loads of the weight rows from 4-byte aligned addresses (the [N][5005] weight of the first layer has
+// unaligned rows; the hardware splits such a load, still one instruction per 4 elements instead of four).
 template <bool XA, bool WA>
 struct LinBigFwdOp {
     typedef LinBigP Params;
@@ -88,7 +100,7 @@ struct LinBigFwdOp {
     }
     __device__ BRaw b_ld(const Params& p, int, int n, int k, bool& ok) const {
         ok = n < p.N && k < p.K;
-        if constexpr (WA) return ok ? *(const float4*)(p.w + (size_t)n * p.K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (WA) return ok ? ld4_row(p.w + (size_t)n * p.K, k, p.K) : make_float4(0.f, 0.f, 0.f, 0.f);
         else return ok ? p.w[(size_t)n * p.K + k] : 0.f;
     }
     __device__ BRaw b_tx(const Params&, int, const BRaw& v, int, int, bool) const { return v; }
@@ -182,6 +194,7 @@ struct LinBigBwdWOp {
     __device__ void epilogue(const Params& p, int n0r, int k0c, int, const float* Cs, int tid, bool) {
         __shared__ float red[4][64];
         if (mb >= me) return;
+        // (a plain read-modify-write for msplit == 1 -- one writer per element -- measured slower than the fire-and-forget atomic)
         for (int idx = tid; idx < TM * TN; idx += 256) {
             const int r = idx / TN, c = idx % TN, n = n0r + r, k = k0c + c;
             if (n < p.N && k < p.K) atomicAdd(&p.dw[(size_t)n * p.K + k], Cs[r * (TN + 1) + c]);
@@ -277,7 +290,8 @@ bool args_ok(const LinBigP& p) {
 }
 // float4 loads of the rows of x: 16-B aligned, row pitch a multiple of 4 floats that covers roundup4(K)
 bool x_aligned(const LinBigP& p) { return (p.ldx & 3) == 0 && p.ldx >= ((p.K + 3) & ~3) && ((uintptr_t)p.x & 15) == 0; }
-bool w_aligned(const LinBigP& p) { return (p.K & 3) == 0 && ((uintptr_t)p.w & 15) == 0; }
+bool w_aligned(const LinBigP& p) { return (p.K & 3) == 0 && ((uintptr_t)p.w & 15) == 0; }      // backward-data: float4 along k from k-major images
+bool w_vec(const LinBigP& p) { return ((uintptr_t)p.w & 3) == 0; }                                 // forward: 4-byte aligned 16-byte loads
 
 }  // namespace
 
@@ -285,7 +299,7 @@ extern "C" int mms_linear_big_fwd(const LinBigP* pp, hipStream_t s) {
     if (!pp || !args_ok(*pp)) return MMS_ERR_ARG;
     const LinBigP& p = *pp;
     const dim3 g((p.M + 63) / 64, (p.N + 63) / 64, 1);
-    const bool xa = x_aligned(p), wa = w_aligned(p);
+    const bool xa = x_aligned(p), wa = w_vec(p);
     if (xa && wa) return launch_tile_gemm<LinBigFwdOp<true, true>>(pp, 1, g, s);
     if (xa) return launch_tile_gemm<LinBigFwdOp<true, false>>(pp, 1, g, s);
     if (wa) return launch_tile_gemm<LinBigFwdOp<false, true>>(pp, 1, g, s);
