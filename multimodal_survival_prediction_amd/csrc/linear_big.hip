@@ -211,6 +211,103 @@ struct LinBigBwdWOp {
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
+// backward-weight of a layer WITHOUT input prologue (the first layer: x is the raw input), large shapes: 128 x 128 output tiles.
+// Both operands are row-contiguous (dpre[m][n..], x[m][k..]), so their LDS images are m-major.  Instead of one ds_read_b32 per
+// MFMA operand, a lane reads FOUR consecutive n of one row with a single ds_read_b128 and feeds them to four MFMAs whose
+// 32 output rows are the interleaved sets {4i + e}: a wave owns all 128 n of the tile x 32 k columns (4 accumulators), the
+// x fragment (one ds_read_b32) is shared by the four.  Per 64 MFMAs: 16 b128 + 16 b32 LDS reads (the GEMM-core form: 128 b32)
+// and half the global loads.  Rows are split over grid.z (fp32 atomics, 128-byte runs along k).
+// ---------------------------------------------------------------------------------------------------------------------
+#define LBW_P 132
+#define LBW_STAGE (2 * 32 * LBW_P)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void lin_bwdw_wide_kernel(const LinBigP p, const int msplit) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+    int mc = (p.M + msplit - 1) / msplit;
+    mc = (mc + 31) & ~31;
+    const int mb = blockIdx.z * mc, me = mb + mc < p.M ? mb + mc : p.M;
+    if (mb >= me) return;
+    const int c4 = (tid & 31) * 4, r8 = tid >> 5;
+    const bool nok = n0 + c4 < p.N, kok = k0 + c4 + 3 < p.ldx;
+    DpreRaw ra[4];
+    float4 rb[4];
+    auto gload = [&](int r0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = r0 + r8 + 8 * i;
+            const bool ok = m < me;
+            if (ok && nok) ra[i] = dpre_ld(p, m, n0 + c4);
+            else { ra[i].g = make_float4(0.f, 0.f, 0.f, 0.f); ra[i].y = ra[i].g; }
+            rb[i] = ok && kok ? *(const float4*)(p.x + (size_t)m * p.ldx + k0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto sstore = [&](float* st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *(float4*)&st[(r8 + 8 * i) * LBW_P + c4] = dpre_tx(p, ra[i]);
+            *(float4*)&st[32 * LBW_P + (r8 + 8 * i) * LBW_P + c4] = tail4(rb[i], k0 + c4, p.K);
+        }
+    };
+    f32x16 acc0, acc1, acc2, acc3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; }
+    const bool do_bias = blockIdx.y == 0 && p.dbias != nullptr;
+    float bsum = 0.f;
+    const int T = (me - mb + 31) / 32;
+    gload(mb);
+    sstore(smem);
+    __syncthreads();
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        const float* cur = smem + (t & 1) * LBW_STAGE;
+        float* nxt = smem + ((t + 1) & 1) * LBW_STAGE;
+        if (t + 1 < T) gload(mb + 32 * (t + 1));
+        const float* at = cur + h * LBW_P + 4 * li;
+        const float* bt = cur + 32 * LBW_P + h * LBW_P + 32 * wave + li;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float4 a = *(const float4*)(at + 2 * q * LBW_P);
+            const float b = bt[2 * q * LBW_P];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b, acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b, acc3, 0, 0, 0);
+        }
+        if (do_bias && tid < 128) {
+#pragma unroll 8
+            for (int mm = 0; mm < 32; ++mm) bsum += cur[mm * LBW_P + tid];
+        }
+        if (t + 1 < T) sstore(nxt);
+        __syncthreads();
+    }
+    const int k = k0 + 32 * wave + li;
+    if (k < p.K) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x16& acc = e == 0 ? acc0 : (e == 1 ? acc1 : (e == 2 ? acc2 : acc3));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + 4 * ((r & 3) + 8 * (r >> 2) + 4 * h) + e;
+                if (n < p.N) atomicAdd(&p.dw[(size_t)n * p.K + k], acc[r]);
+            }
+        }
+    }
+    if (do_bias && tid < 128 && n0 + tid < p.N) atomicAdd(&p.dbias[n0 + tid], bsum);
+}
+// rows split of the wide kernel: the smallest split whose grid fills >= 90 % of a whole number of rounds (2 workgroups x 256 CUs)
+static int lbw_msplit(const LinBigP& p) {
+    const long tiles = (long)((p.N + 127) / 128) * ((p.K + 127) / 128);
+    int best = 1;
+    for (int ms = 1; ms <= 8 && p.M / ms >= 256; ++ms) {
+        const long w = tiles * ms, rounds = (w + 511) / 512;
+        best = ms;
+        if (w * 10 >= rounds * 512 * 9) break;
+    }
+    return best;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // backward-data:  dP[m][k] = sum_n dpre[m][n] * W[n][k]  ->  through dropout and ReLU:  dbn[m][k], plus the BatchNorm-backward
 // column sums s1 = sum_m dbn, s2 = sum_m dbn * (x - mean)      (K % 4 == 0: every hidden width)
 // ---------------------------------------------------------------------------------------------------------------------
@@ -309,6 +406,19 @@ extern "C" int mms_linear_big_fwd(const LinBigP* pp, hipStream_t s) {
 extern "C" int mms_linear_big_bwd_w(const LinBigP* pp, hipStream_t s) {
     if (!pp || !args_ok(*pp) || !pp->dy || !pp->dw || pp->msplit <= 0 || pp->lddy < pp->N) return MMS_ERR_ARG;
     const LinBigP& p = *pp;
+    const bool plain = !p.has_bn && !(p.train && (p.drop_mask || p.drop_p > 0.f));
+    const char* e = getenv("MMS_LINBIG_WIDE");           // 0: GEMM-core form only (A/B measurements, tests)
+    if (plain && x_aligned(p) && p.N >= 128 && p.K >= 128 && p.M >= 256 && !(e && e[0] == '0')) {
+        constexpr int smem = 2 * LBW_STAGE * (int)sizeof(float);             // 67.6 KB: 2 workgroups per CU
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute((const void*)lin_bwdw_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            attr_set = true;
+        }
+        const int ms = lbw_msplit(p);
+        MMS_LAUNCH(lin_bwdw_wide_kernel, dim3((p.N + 127) / 128, (p.K + 127) / 128, ms), dim3(256), smem, s, p, ms);
+        return mms_check_launch();
+    }
     const dim3 g((p.N + 63) / 64, (p.K + 63) / 64, p.msplit);
     return x_aligned(p) ? launch_tile_gemm<LinBigBwdWOp<true>>(pp, 1, g, s) : launch_tile_gemm<LinBigBwdWOp<false>>(pp, 1, g, s);
 }

@@ -102,6 +102,8 @@ def _block(M, K, N, ldx, has_bn, drop, out_relu, seed, train=True):
     (200, 5005, 64, 5005, False, False, False),   # unpadded x: scalar loaders on both operands
     (77, 37, 70, 40, False, False, True),         # tiny K (one partial tile), N not a multiple of 4
     (640, 128, 64, 128, False, True, False),      # dropout-only prologue (simple_fusion.py fusion tail), dx written directly
+    (300, 5005, 192, 5008, False, False, False),  # no prologue, M >= 256: the 128x128 wide weight-gradient kernel, partial n and k tiles
+    (1000, 1000, 256, 1000, False, False, True),  # wide kernel with the output-ReLU mask and a rows split
 ])
 def test_linear_big_ops_vs_torch(M, K, N, ldx, has_bn, drop, out_relu):
     _block(M, K, N, ldx, has_bn, drop, out_relu, seed=M + K + N)
