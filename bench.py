@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--steps", type=int, default=240)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--volume", type=int, nargs=3, default=(64, 64, 32), metavar=("D", "H", "W"),
+                    help="CT volume (default: the headline 64 64 32; BASELINE config 4 uses 128 128 64)")
     ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -159,7 +161,7 @@ def main():
     from multimodal_survival_prediction_amd import data, models
     from multimodal_survival_prediction_amd.training import FusedOptimizer
 
-    B, dims, rna_dim = args.batch, (64, 64, 32), 5005
+    B, dims, rna_dim = args.batch, tuple(args.volume), 5005
     if args.roofline_only:
         Gr = max(1, min(args.fold_group, 10))
         avg_t, avg_f = measure_dominant_kernel(B, dims, dev, Gr)
@@ -317,8 +319,8 @@ def main():
             "value": world * args.steps * B / dt, "unit": "patients/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "MultiModalSurvivalNet (DenseNet121-3D CT 64x64x32 + RNA-seq 5005 + clinical), "
-                                   "109 synthetic complete patients, 5-fold split, batch 4, Adam lr 1e-4 wd 1e-4, clip 1.0",
+            "config": {"workload": "MultiModalSurvivalNet (DenseNet121-3D CT %dx%dx%d + RNA-seq 5005 + clinical), "
+                                   "109 synthetic complete patients, 5-fold split, batch %d, Adam lr 1e-4 wd 1e-4, clip 1.0" % (dims + (B,)),
                        "global_batch": world * B, "parallelism": (f"ddp x{world} (flat gradient all-reduce per step, local BN + {'global' if args.global_cox else 'local'} Cox risk set)" if ddp else
                                        f"kfold-shard x{world} ranks x {F} concurrent groups x {G} lock-step fold models per GPU (one stream + step graph per group, no collective)"),
                        "concurrent_folds": F, "fold_group": G, "fold_models_in_flight": F * G,
