@@ -126,6 +126,133 @@ struct LinBigFwdOp {
     }
 };
 
+// ---------------------------------------------------------------------------------------------------------------------
+// forward of a layer WITHOUT input prologue (the first layer), large shapes: 128 x 128 output tiles, split-K.  A wave owns
+// all 128 rows of the tile x 32 columns (4 accumulators); per 16 MFMAs it reads 4 x-fragments + 1 weight fragment
+// (ds_read_b128) and the workgroup loads half the operand bytes per MFMA of the 64 x 64 form.  2048 x 1024 outputs are only
+// 128 such tiles, so K is split over grid.z and the partial products are added into a zeroed y with fp32 atomics (128-byte
+// runs; split 0 adds the bias); output ReLU and the BatchNorm column statistics of y follow in lin_colstats_kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+#define LFW_P 36
+#define LFW_STAGE (2 * 128 * LFW_P)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void lin_fwd_wide_kernel(const LinBigP p, const int kc) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
+    const int kb = blockIdx.z * kc, ke = kb + kc < p.K ? kb + kc : p.K;
+    if (kb >= ke) return;
+    const int k4 = (tid & 7) * 4, r32 = tid >> 3;
+    float4 ra[4], rb[4];
+    auto gload = [&](int k0) __attribute__((always_inline)) {
+        const int k = k0 + k4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + r32 + 32 * i, n = n0 + r32 + 32 * i;
+            ra[i] = (m < p.M && k + 3 < p.ldx) ? tail4(*(const float4*)(p.x + (size_t)m * p.ldx + k), k, p.K) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[i] = (n < p.N && k < p.K) ? ld4_row(p.w + (size_t)n * p.K, k, p.K) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto sstore = [&](float* st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *(float4*)&st[(r32 + 32 * i) * LFW_P + k4] = ra[i];
+            *(float4*)&st[128 * LFW_P + (r32 + 32 * i) * LFW_P + k4] = rb[i];
+        }
+    };
+    f32x16 acc0, acc1, acc2, acc3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; }
+    const int T = (ke - kb + 31) / 32;
+    gload(kb);
+    sstore(smem);
+    __syncthreads();
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        const float* cur = smem + (t & 1) * LFW_STAGE;
+        float* nxt = smem + ((t + 1) & 1) * LFW_STAGE;
+        if (t + 1 < T) gload(kb + 32 * (t + 1));
+        const float* at = cur + li * LFW_P + 4 * h;
+        const float* bt = cur + 128 * LFW_P + (32 * wave + li) * LFW_P + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 b = *(const float4*)(bt + 8 * q);
+            const float4 a0 = *(const float4*)(at + 8 * q), a1 = *(const float4*)(at + 32 * LFW_P + 8 * q);
+            const float4 a2 = *(const float4*)(at + 64 * LFW_P + 8 * q), a3 = *(const float4*)(at + 96 * LFW_P + 8 * q);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b.x, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, b.x, acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3.x, b.x, acc3, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b.y, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, b.y, acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3.y, b.y, acc3, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b.z, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.z, b.z, acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3.z, b.z, acc3, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b.w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b.w, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.w, b.w, acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3.w, b.w, acc3, 0, 0, 0);
+        }
+        if (t + 1 < T) sstore(nxt);
+        __syncthreads();
+    }
+    const int n = n0 + 32 * wave + li;
+    if (n < p.N) {
+        const float bv = (blockIdx.z == 0 && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x16& acc = e == 0 ? acc0 : (e == 1 ? acc1 : (e == 2 ? acc2 : acc3));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 32 * e + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < p.M) atomicAdd(&p.y[(size_t)m * p.ldy + n], acc[r] + bv);
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void lin_zero_y_kernel(const LinBigP p) {
+    const int n4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, r0 = blockIdx.y * 64 + (threadIdx.x >> 6);
+    if (n4 >= p.N) return;
+    for (int m = r0; m < blockIdx.y * 64 + 64 && m < p.M; m += 4) {
+        float* d = p.y + (size_t)m * p.ldy + n4;
+        if (n4 + 3 < p.N && (p.ldy & 3) == 0 && ((uintptr_t)p.y & 15) == 0) *(float4*)d = make_float4(0.f, 0.f, 0.f, 0.f);
+        else for (int j = 0; j < 4 && n4 + j < p.N; ++j) d[j] = 0.f;
+    }
+}
+// output ReLU (in place) and the BatchNorm column statistics of y, after all K splits have landed
+__global__ __launch_bounds__(256) void lin_colstats_kernel(const LinBigP p) {
+    __shared__ double red[2][4][64];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6, n = blockIdx.x * 64 + c, r0 = blockIdx.y * 64;
+    double s = 0, q = 0;
+    if (n < p.N)
+        for (int m = r0 + rg; m < r0 + 64 && m < p.M; m += 4) {
+            float v = p.y[(size_t)m * p.ldy + n];
+            if (p.out_relu) { v = fmaxf(v, 0.f); p.y[(size_t)m * p.ldy + n] = v; }
+            s += v; q += (double)v * v;
+        }
+    if (!p.osum) return;
+    red[0][rg][c] = s; red[1][rg][c] = q;
+    __syncthreads();
+    if (rg == 0 && n < p.N) {
+        atomicAdd(&p.osum[n], red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+        atomicAdd(&p.osumsq[n], red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    }
+}
+// K split of the wide forward: smallest split whose grid fills >= 90 % of a whole number of rounds (2 workgroups x 256 CUs)
+static int lfw_kc(const LinBigP& p, int& ks_out) {
+    const long tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    int best = 1;
+    for (int ks = 1; ks <= 8 && p.K / ks >= 256; ++ks) {
+        const long w = tiles * ks, rounds = (w + 511) / 512;
+        best = ks;
+        if (w * 10 >= rounds * 512 * 9) break;
+    }
+    ks_out = best;
+    return (((p.K + best - 1) / best) + 31) & ~31;
+}
+
 // gradient wrt the pre-activation output: dy masked by the output ReLU
 __device__ __forceinline__ float dpre_of(const LinBigP& p, float dy, float y) { return (p.out_relu && !(y > 0.f)) ? 0.f : dy; }
 
@@ -395,8 +522,24 @@ bool w_vec(const LinBigP& p) { return ((uintptr_t)p.w & 3) == 0; }              
 extern "C" int mms_linear_big_fwd(const LinBigP* pp, hipStream_t s) {
     if (!pp || !args_ok(*pp)) return MMS_ERR_ARG;
     const LinBigP& p = *pp;
-    const dim3 g((p.M + 63) / 64, (p.N + 63) / 64, 1);
     const bool xa = x_aligned(p), wa = w_vec(p);
+    const bool plain = !p.has_bn && !(p.train && (p.drop_mask || p.drop_p > 0.f));
+    const char* e = getenv("MMS_LINBIG_WIDE");           // 0: GEMM-core form only (A/B measurements, tests)
+    if (plain && xa && wa && p.M >= 256 && p.N >= 128 && p.K >= 512 && !(e && e[0] == '0')) {
+        constexpr int smem = 2 * LFW_STAGE * (int)sizeof(float);             // 73.7 KB: 2 workgroups per CU
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute((const void*)lin_fwd_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            attr_set = true;
+        }
+        int ks = 1;
+        const int kc = lfw_kc(p, ks);
+        MMS_LAUNCH(lin_zero_y_kernel, dim3((p.N + 255) / 256, (p.M + 63) / 64), dim3(256), 0, s, p);
+        MMS_LAUNCH(lin_fwd_wide_kernel, dim3((p.M + 127) / 128, (p.N + 127) / 128, ks), dim3(256), smem, s, p, kc);
+        if (p.osum || p.out_relu) MMS_LAUNCH(lin_colstats_kernel, dim3((p.N + 63) / 64, (p.M + 63) / 64), dim3(256), 0, s, p);
+        return mms_check_launch();
+    }
+    const dim3 g((p.M + 63) / 64, (p.N + 63) / 64, 1);
     if (xa && wa) return launch_tile_gemm<LinBigFwdOp<true, true>>(pp, 1, g, s);
     if (xa) return launch_tile_gemm<LinBigFwdOp<true, false>>(pp, 1, g, s);
     if (wa) return launch_tile_gemm<LinBigFwdOp<false, true>>(pp, 1, g, s);
