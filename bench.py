@@ -118,6 +118,76 @@ def cpu_baseline(cohort, train_idx, steps, B):
                 sample=f"{steps} training steps (batch {B}) of the torch-fp32 CPU oracle after 1 warm-up step, {dt:.1f} s")
 
 
+def run_config5(args, dev):
+    """BASELINE config 5 (`--workload c5`, single GPU): RNA-seq-only model 5005 -> 1024 -> 512 -> 256 -> 1 at batch 2048, one full
+    training step per replay (zero-grad, forward, O(B^2) Cox partial likelihood, backward, AdamW; train_rnaseq_only.py:153-176)
+    as a captured HIP graph.  roofline: the first-layer forward GEMM (2 * B * 5005 * 1024 FLOP per launch; the launch sequence
+    timed live with HIP events includes its 13 us of output zeroing + column statistics); cpu_baseline: the oracle's loop body."""
+    import ctypes
+    import numpy as np
+    from multimodal_survival_prediction_amd import _lib, models
+    from multimodal_survival_prediction_amd.training import FusedOptimizer
+    B = 2048 if args.batch == 4 else args.batch
+    torch.manual_seed(0)
+    net = models.RNASeqSurvivalModel(input_dim=5005).to(dev).train()
+    fo = FusedOptimizer(net, lr=1e-4, weight_decay=1e-3, adamw=True, max_norm=0.0)
+    rng = np.random.default_rng(0)
+    rna = torch.tensor(rng.normal(0, 1, (B, 5005)).astype(np.float32), device=dev)
+    t = torch.tensor((rng.exponential(1000, B) + 1 + np.arange(B) * 1e-3).astype(np.float32), device=dev)
+    e = torch.tensor((rng.random(B) < 0.6).astype(np.float32), device=dev)
+
+    def step():
+        fo.engine.train_step(None, rna, time=t, event=e, skip_if_unusable=False, use_graph=not args.no_graph)
+    for _ in range(max(args.warmup, 3)):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    if args.timed_only:
+        print(f"timed-only (config 5): {B / dt:.1f} patients/s, {dt * 1e3:.3f} ms/step", flush=True)
+        return
+    out = {"metric": "patients/sec per epoch (training: fwd + Cox + bwd + AdamW)", "value": B / dt, "unit": "patients/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"BASELINE config 5: RNASeqSurvivalModel (5005-1024-512-256-1), batch {B}, Cox over the {B}-patient risk set, "
+                                  "AdamW lr 1e-4 wd 1e-3", "global_batch": B, "parallelism": "single GPU, one step graph",
+                      "hip_graph": not args.no_graph, "mean_train_loss": fo.engine.epoch_stats()["sum_loss"] / (args.steps + max(args.warmup, 3))}}
+    P = fo.engine.plans[(B,)]
+    q, lib = P.big_lin[True][0], _lib.load_library()
+    P.big_stats.zero_()
+    reps = 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    from multimodal_survival_prediction_amd import ops
+    for i in range(3 + reps):
+        if i == 3:
+            e0.record()
+        _lib.check(lib.mms_linear_big_fwd(ctypes.byref(q), ops.stream()), "mms_linear_big_fwd")
+    e1.record()
+    torch.cuda.synchronize()
+    avg_t, flops = e0.elapsed_time(e1) * 1e-3 / reps, 2.0 * B * 5005 * 1024
+    out["roofline"] = {"bound": "mfma", "kernel": "mms_linear_big_fwd of the first layer = lin_zero_y_kernel + lin_fwd_wide_kernel + lin_colstats_kernel",
+                       "achieved": flops / avg_t / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                       "frac": flops / avg_t / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "avg_launch_us": avg_t * 1e6,
+                       "avg_flops_per_launch": flops}
+    if not args.no_cpu_baseline:
+        from oracle import losses as OL
+        from oracle import models as OM
+        ref = OM.RNASeqSurvivalModel(input_dim=5005).train()
+        opt = torch.optim.AdamW(ref.parameters(), lr=1e-4, weight_decay=1e-3)
+        x, tc, ec = rna.cpu(), t.cpu(), e.cpu().bool()
+        for i in range(args.cpu_steps + 1):
+            if i == 1:
+                c0 = time.perf_counter()
+            opt.zero_grad(); OL.neg_partial_log_likelihood(ref(x).squeeze(), ec, tc).backward(); opt.step()
+        cdt = time.perf_counter() - c0
+        out["cpu_baseline"] = dict(value=args.cpu_steps * B / cdt, unit="patients/s", cores=torch.get_num_threads(), kind="port",
+                                   sample=f"{args.cpu_steps} training steps (batch {B}) of the torch-fp32 CPU oracle after 1 warm-up step, {cdt:.1f} s")
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,6 +196,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--volume", type=int, nargs=3, default=(64, 64, 32), metavar=("D", "H", "W"),
                     help="CT volume (default: the headline 64 64 32; BASELINE config 4 uses 128 128 64)")
+    ap.add_argument("--workload", choices=["c2", "c5"], default="c2",
+                    help="c2 (default): BASELINE configs[1], the headline; c5: BASELINE config 5 (RNA-seq-only model, batch 2048, single GPU)")
     ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -158,6 +230,13 @@ def main():
     from multimodal_survival_prediction_amd import _build, _lib
     if not os.path.exists(_lib.lib_path()):
         _build.build()
+    if args.workload == "c5":
+        if world > 1:
+            raise SystemExit("--workload c5 is a single-GPU run")
+        if args.steps == 240 and args.warmup == 20:
+            args.steps, args.warmup = 200, 10
+        run_config5(args, dev)
+        return
     from multimodal_survival_prediction_amd import data, models
     from multimodal_survival_prediction_amd.training import FusedOptimizer
 

@@ -1,6 +1,6 @@
 """BASELINE config 5: RNA-seq-only model (5005 -> 1024 -> 512 -> 256 -> 1), batch 2048, one full training step per replay
-(zero-grad, forward, O(B^2) Cox partial likelihood, backward, AdamW) as a captured HIP graph.  Prints one JSON line;
---cpu-steps N also times the CPU oracle's loop body (train_rnaseq_only.py:153-176) on the host cores."""
+(zero-grad, forward, O(B^2) Cox partial likelihood, backward, AdamW) as a captured HIP graph.  Profiling aid (tools/prof_c5.sh):
+prints one JSON line with the GPU rate only; the judged line with roofline and cpu_baseline is `python bench.py --workload c5`."""
 import argparse
 import json
 import os
@@ -18,7 +18,6 @@ def main():
     ap.add_argument("--batch", type=int, default=2048)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--cpu-steps", type=int, default=0)
     a = ap.parse_args()
     from multimodal_survival_prediction_amd import models
     from multimodal_survival_prediction_amd.training import FusedOptimizer
@@ -42,17 +41,6 @@ def main():
     flops = 3 * 2 * B * (5005 * 1024 + 1024 * 512 + 512 * 256 + 256) - 2 * B * 5005 * 1024      # no dX for the first layer
     out = dict(workload="C5 rnaseq-only B=%d" % B, ms_per_step=dt * 1e3, patients_per_s=B / dt, gemm_tflops=flops / dt / 1e12,
                loss=fo.engine.epoch_stats()["sum_loss"] / (a.steps + a.warmup))
-    if a.cpu_steps:
-        from oracle import losses as OL, models as OM
-        ref = OM.RNASeqSurvivalModel(input_dim=5005).train()
-        opt = torch.optim.AdamW(ref.parameters(), lr=1e-4, weight_decay=1e-3)
-        x, tc, ec = rna.cpu(), t.cpu(), e.cpu().bool()
-        for i in range(a.cpu_steps + 1):
-            if i == 1:
-                c0 = time.perf_counter()
-            opt.zero_grad(); OL.neg_partial_log_likelihood(ref(x).squeeze(), ec, tc).backward(); opt.step()
-        cdt = (time.perf_counter() - c0) / a.cpu_steps
-        out["cpu_patients_per_s"], out["cpu_threads"] = B / cdt, torch.get_num_threads()
     print(json.dumps(out))
 
 

@@ -1,11 +1,10 @@
 """BASELINE config 5: large risk-set Cox stress -- n = 2048 log-hazards, O(n^2) risk-set kernel pair (value + gradient),
-checked against the fp64 numpy oracle and timed with HIP events."""
+timed with HIP events.  (Parity of the same sizes against the fp64 oracle: tests/test_gpu_heads.py.)"""
 import os, sys
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multimodal_survival_prediction_amd import ops
-from oracle.losses import cox_npll_grad_np, cox_npll_np
 dev = "cuda:0"
 for n in (4, 64, 2048, 8192):
     rng = np.random.default_rng(n)
@@ -15,9 +14,6 @@ for n in (4, 64, 2048, 8192):
     hd, td, ed = (torch.tensor(a).to(dev) for a in (h, t, e))
     out, dh = ops.cox_fwd_bwd(hd, td, ed)
     torch.cuda.synchronize()
-    ref_l, ref_g = cox_npll_np(h, e, t), cox_npll_grad_np(h, e, t)
-    err_l = abs(out[0].item() - ref_l) / max(1, abs(ref_l))
-    err_g = float(np.abs(dh.cpu().numpy() - ref_g).max() / np.abs(ref_g).max())
     for _ in range(5):
         ops.cox_fwd_bwd(hd, td, ed)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -25,5 +21,5 @@ for n in (4, 64, 2048, 8192):
     for _ in range(50):
         ops.cox_fwd_bwd(hd, td, ed)
     e1.record(); torch.cuda.synchronize()
-    print(f"n={n:5d}: loss rel err {err_l:.1e}, grad rel err {err_g:.1e}, {e0.elapsed_time(e1) * 1e3 / 50:.1f} us per loss+grad "
+    print(f"n={n:5d}: loss {out[0].item():.6f}, {e0.elapsed_time(e1) * 1e3 / 50:.1f} us per loss+grad "
           f"(2 launches + 3 small allocations, {2 * n * n / 1e6:.2f} M exp/compare pair-ops)")
