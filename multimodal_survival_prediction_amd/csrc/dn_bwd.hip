@@ -740,35 +740,44 @@ MMS_SINGLE(mms_conv1_bwd_weight, Conv1BwdP)
 // ------------------------------------------------------------------------------------------------------
 // BN backward apply into the gradient slab: dx[:, 0:C] (+)= g*rstd*(dbn - s1/M - xhat*s2/M)
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const Grp<BnBwdApplyP> grp) {
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const Grp<BnBwdApplyP> grp, const int rows) {
     const BnBwdApplyP& p = grp.p[blockIdx.z];
-    // workgroup = 32 rows x one 256-channel chunk; each thread owns 4 channels and keeps their constants in registers
-    const int tid = threadIdx.x, c = blockIdx.y * 256 + (tid & 63) * 4, rg = tid >> 6;
-    if (c >= p.C) return;
-    float mu[4], rs[4], gr[4], m1[4], m2[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        bn_mean_rstd(p.bn, c + j, mu[j], rs[j]);
-        gr[j] = p.bn.gamma[c + j] * rs[j];
-        const double t1 = rep_sum(p.bb.s1, c + j, p.bb.nrep, p.bb.rep_stride), t2 = rep_sum(p.bb.s2, c + j, p.bb.nrep, p.bb.rep_stride);
-        m1[j] = (float)(t1 * (double)p.bn.inv_count);
-        m2[j] = (float)(t2 * (double)p.bn.inv_count);
-        if (blockIdx.x == 0 && rg == 0 && p.dgamma) {
-            p.dgamma[c + j] += (float)t2;
-            p.dbeta[c + j] += (float)t1;
+    // workgroup = `rows` rows x one chunk of <= 256 channels.  The per-channel constants (fp64 replica sums of four
+    // accumulators) are computed ONCE per workgroup, one channel per thread, and shared through LDS; the threads then map
+    // densely onto (channel quad, row): a 64-channel layer keeps all 256 lanes busy (16 quads x 16 rows).
+    __shared__ float cm[4][256];            // mean | gamma*rstd | m1 | rstd*m2
+    const int tid = threadIdx.x, c0 = blockIdx.y * 256;
+    const int nc = p.C - c0 < 256 ? p.C - c0 : 256;          // channels of this chunk (multiple of 4)
+    if (tid < nc) {
+        const int c = c0 + tid;
+        float mu, rs;
+        bn_mean_rstd(p.bn, c, mu, rs);
+        const double t1 = rep_sum(p.bb.s1, c, p.bb.nrep, p.bb.rep_stride), t2 = rep_sum(p.bb.s2, c, p.bb.nrep, p.bb.rep_stride);
+        cm[0][tid] = mu; cm[1][tid] = p.bn.gamma[c] * rs;
+        cm[2][tid] = (float)(t1 * (double)p.bn.inv_count);
+        cm[3][tid] = rs * (float)(t2 * (double)p.bn.inv_count);
+        if (blockIdx.x == 0 && p.dgamma) {
+            p.dgamma[c] += (float)t2;
+            p.dbeta[c] += (float)t1;
         }
     }
-    const int r0 = blockIdx.x * 32, rows = p.M - r0 < 32 ? p.M - r0 : 32;
-    for (int r = rg; r < rows; r += 4) {
-        const size_t m = r0 + r;
-        const float4 g = *(const float4*)(p.dbn + m * p.lddbn + c);
-        const float4 x = *(const float4*)(p.x + m * p.ldx + c);
-        float4* dst = (float4*)(p.dx + m * p.lddx + c);
+    __syncthreads();
+    const int nq = nc >> 2, rpar = 256 / nq;                  // row lanes per pass
+    const int q = tid % nq, rl = tid / nq;
+    if (rl >= rpar) return;
+    const int c = 4 * q;
+    const float4 mu = *(const float4*)&cm[0][c], gr = *(const float4*)&cm[1][c], m1 = *(const float4*)&cm[2][c], m2 = *(const float4*)&cm[3][c];
+    const int r0 = blockIdx.x * rows, rend = r0 + rows < p.M ? r0 + rows : p.M;
+    for (int r = r0 + rl; r < rend; r += rpar) {
+        const size_t m = r;
+        const float4 g = *(const float4*)(p.dbn + m * p.lddbn + c0 + c);
+        const float4 x = *(const float4*)(p.x + m * p.ldx + c0 + c);
+        float4* dst = (float4*)(p.dx + m * p.lddx + c0 + c);
         float4 o = p.accumulate ? *dst : make_float4(0, 0, 0, 0);
-        o.x += gr[0] * (g.x - m1[0] - (x.x - mu[0]) * rs[0] * m2[0]);
-        o.y += gr[1] * (g.y - m1[1] - (x.y - mu[1]) * rs[1] * m2[1]);
-        o.z += gr[2] * (g.z - m1[2] - (x.z - mu[2]) * rs[2] * m2[2]);
-        o.w += gr[3] * (g.w - m1[3] - (x.w - mu[3]) * rs[3] * m2[3]);
+        o.x += gr.x * (g.x - m1.x - (x.x - mu.x) * m2.x);
+        o.y += gr.y * (g.y - m1.y - (x.y - mu.y) * m2.y);
+        o.z += gr.z * (g.z - m1.z - (x.z - mu.z) * m2.z);
+        o.w += gr.w * (g.w - m1.w - (x.w - mu.w) * m2.w);
         *dst = o;
     }
 }
@@ -777,12 +786,13 @@ extern "C" int mms_bn_bwd_apply_group(const BnBwdApplyP* pp, int ng, hipStream_t
     Grp<BnBwdApplyP> a;
     if (!grp_fill(a, pp, ng, 1)) return MMS_ERR_ARG;
     const BnBwdApplyP& p = *pp;
-    if (p.M <= 0 || p.C % 4 != 0 || p.lddbn % 4 || p.ldx % 4 || p.lddx % 4) return MMS_ERR_ARG;
+    if (p.M <= 0 || p.C <= 0 || p.C % 4 != 0 || p.lddbn % 4 || p.ldx % 4 || p.lddx % 4) return MMS_ERR_ARG;
     for (int g = 1; g < ng; ++g) {
         const BnBwdApplyP& q = pp[g];
         if (q.M != p.M || q.C != p.C || q.lddbn % 4 || q.ldx % 4 || q.lddx % 4 || q.accumulate != p.accumulate) return MMS_ERR_ARG;
     }
-    MMS_LAUNCH(bn_bwd_apply_kernel, dim3((p.M + 31) / 32, (p.C + 255) / 256, ng), dim3(256), 0, s, a);
+    const int rows = (long)p.M * ng >= 16384 ? 128 : 32;     // big launches amortise the constants over more rows; small ones keep their workgroup count
+    MMS_LAUNCH(bn_bwd_apply_kernel, dim3((p.M + rows - 1) / rows, (p.C + 255) / 256, ng), dim3(256), 0, s, a, rows);
     return mms_check_launch();
 }
 MMS_SINGLE(mms_bn_bwd_apply, BnBwdApplyP)
