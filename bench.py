@@ -1,30 +1,36 @@
 #!/usr/bin/env python3
 """Headline benchmark: patients/sec of the multimodal survival training hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): full MultiModalSurvivalNet (DenseNet121-3D CT 64x64x32 + RNA-seq 5005 +
-clinical), 109 synthetic complete-modality patients, batch 4, 5-fold split, Adam(lr 1e-4, wd 1e-4),
-clip_grad_norm_(1.0).  A "step" is one pass of the hot path over one batch of 4 patients of one fold's model:
-zero-grad, forward, Cox partial likelihood, backward, clip, Adam -- all inside one replayed HIP graph.  The cohort is
-resident in HBM before the timed region; per step the batch is gathered device-to-device into the graph's static buffers.
+Default workload `c3` = the configuration BASELINE.json's metric is quoted on, N = 1 leg (BASELINE configs[2]):
+  608-patient synthetic cohort with modality masks (142 CT / 427 RNA-seq / 587 clinical / 348 labelled), PartialModalityNet
+  (DenseNet121-3D CT 64x64x32 + RNA-seq 5005 + clinical, softmax gate, gate-entropy term), 5-fold cross-validation over the
+  348 labelled patients with all 260 unlabelled patients added to every training split
+  (R/scripts/training/partial_modality_training.py:496-532), batch 4, Adam(lr 1e-4, wd 1e-4), clip_grad_norm_(1.0).
+  The K = 5 fold models are advanced in lock-step by `training.train_epoch_lockstep` (what scripts/training/
+  partial_modality_training.py runs): ONE launch sequence per lock-step step carries all fold models of a sub-group.
+  A "step" is one lock-step step: every fold model that still has a batch takes one optimisation step on it (zero-grad,
+  forward, Cox partial likelihood on the labelled patients + gate entropy, backward, clip, Adam -- one replayed HIP graph per
+  sub-group).  The timed region is WHOLE EPOCHS of the 5-fold job (135 steps each: 134 full batches + the ragged tail of every
+  fold, entropy-only batches included) -- at least one epoch, more if --steps asks for more; `value` = training patients
+  processed / wall time.  The cohort is resident in HBM before the timed region; each step's batches are gathered
+  device-to-device by one launch fed by one small index copy.  `--h2d` adds the host-resident variant.
 
-K-fold cross-validation trains independent models of one shape, and at batch 4 one model's step is a chain of ~560 small
-dependent kernels that leaves most of the 256 CUs idle.  Fold models are therefore advanced in lock-step as FOLD GROUPS
-(DESIGN.md section 3a): every launch of the step carries the parameter blocks of all G models of a group, and F groups run
-concurrently on F streams (one step graph each).  Default: F = 2 groups x G = 10 models = 20 fold models in flight (four
-5-fold cross-validations; the reference's own experiment set is 3-5 scripts x 5 folds), the K timed steps dealt over
-them.  Per-model semantics are untouched (tests/test_gpu_fold_group.py).  The same run also reports, in `config`, one
-5-fold CV alone on the GPU (5 lock-step models, `one_cv_5_lockstep_patients_per_s`) and ONE model alone
-(`single_chain_patients_per_s`).
+Other workloads: `--workload c2` (BASELINE configs[1]: MultiModalSurvivalNet, 109 complete patients, fold models in flight
+configurable -- round 1's headline), `--workload c5` (BASELINE config 5: RNA-seq-only model, batch 2048).
 
   python bench.py [--gpus N] [--steps K] [--warmup W]            (N>1: launched by torch.distributed.run)
-N>1 shards K-fold units over ranks (fold k -> rank k mod N, no data-path collective): weak scaling.
+N > 1 (weak scaling, no data-path collective): rank r runs repetition r of the 5-fold cross-validation (repeated K-fold:
+same cohort, KFold random_state 42 + r, its own 5 models); the same run also times ONE cross-validation's 5 folds dealt over
+the ranks (fold k -> rank k mod N, BASELINE config 3's layout) and reports it as `one_cv_sharded_patients_per_s`.
+`--mode ddp` = BASELINE config 4's data-parallel step (one model, global batch N*B, gradient all-reduce over RCCL).
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
-  "roofline":     dominant kernel, algorithmic FLOPs / measured average launch duration vs the fp32 MFMA peak
+  "roofline":     dominant kernel family, algorithmic FLOPs / measured average launch duration vs the fp32 MFMA peak
   "cpu_baseline": the CPU oracle (torch fp32 restatement of the same model/loop) timed on this box's host cores.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -38,60 +44,153 @@ PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 BLOCKS = ((6, 64), (12, 128), (24, 256), (16, 512))     # (layers, first-layer input channels) of DenseNet121
 
 
-def measure_dominant_kernel(B, dims, device, G=1, reps=20):
-    """Average launch duration of the dominant kernel -- the weight gradient of the dense-layer 3x3x3 conv
-    (mms_conv3_bwd_weight_group: conv3_bwdw_mt_kernel for the block-1 launches of groups, tile_gemm_kernel<Conv3BwdWOp>
-    otherwise; 58 launches per group step, the largest share of GPU time in profiles/r01_*) -- timed live
-    with HIP events on the launch stream (torch's current stream), launched exactly as the timed region launches it:
-    one launch carries the G models of a fold group (mms_conv3_bwd_weight_group), shape by shape with the driver's own
-    split factors, weighted by the launch counts.  Algorithmic FLOPs per launch = G * 2 * M * 27 * 128 * 32."""
-    import ctypes
+# ---- roofline leg: the dense-layer 3x3x3 convolution family, timed live ------------------------------------------------
+def _stat_reps(M):                 # dn_net.hip make_plan: statistic-accumulator replicas of a level
+    r = 1
+    while r < 8 and M // (2 * r) >= 2048:
+        r *= 2
+    return r
+
+
+def _conv3_nsplit(M, ng):          # dn_net.hip conv3_nsplit (scratch assumed large enough)
+    target = int(os.environ.get("MMS_SPLIT_WGS", "0")) or (256 if ng > 1 else 864)
+    tiles = ((M + 31) // 32) * ng
+    if tiles >= 256 and tiles >= target:
+        return 1
+    ns = max(1, min(27, (target + tiles - 1) // tiles))
+    tpw = (27 + ns - 1) // ns
+    return (27 + tpw - 1) // tpw
+
+
+def _bwdw_msplit(M, G):            # dn_net.hip dn121_backward_impl: rows per weight-gradient workgroup
+    rows, rows_s = (1024, 256) if G >= 4 else (512, 128)
+    fills = lambda w: w * 10 >= -(-w // 768) * 768 * 9                     # dn_ops.h: mms_conv3w_mt_fills
+    if G >= 4 and M > 1024 and not fills(-(-M // 1024) * G * 9) and fills(-(-M // 512) * G * 9):
+        rows = 512
+    return (M + rows - 1) // rows if M > 1024 else max((M + rows_s - 1) // rows_s, 1)
+
+
+def measure_conv2_family(B, dims, device, G, reps=20):
+    """The three kernels of the dense layers' 3x3x3 convolution (norm2/relu2/conv2 of MONAI's _DenseLayer): forward
+    (mms_conv3_fwd_group), backward-data (mms_conv3_bwd_data_group) and weight gradient (mms_conv3_bwd_weight_group) -- 58
+    launches each per lock-step step, together the largest share of GPU time in profiles/.  Each is timed live with HIP
+    events on the launch stream (torch's current stream), launched exactly as the step launches it: one launch carries the G
+    models of a sub-group, shape by shape (the four dense blocks) with the driver's own split factors, weighted by the layer
+    counts.  Algorithmic FLOPs per launch of any of the three = G * 2 * M * 27 * 128 * 32.
+    -> {op: (avg seconds per launch, avg FLOPs per launch)}"""
     from multimodal_survival_prediction_amd import _lib, ops
     lib, S = _lib.load_library(), _lib.structs()
-    tot_t, tot_f, n = 0.0, 0.0, 0
     D, H, W = dims
-    g, b = torch.ones(128, device=device), torch.zeros(128, device=device)
+    gam, bet = torch.ones(128, device=device), torch.zeros(128, device=device)
+    tot = {k: [0.0, 0.0] for k in ("fwd", "bwd_data", "bwd_weight")}
+    nl = 0
+    w = torch.randn(32, 128, 3, 3, 3, device=device) * 0.03
+    wpf, wpb = ops.pack_conv3(w)
     for i, (layers, _) in enumerate(BLOCKS):
         gd = (D // 4 >> i, H // 4 >> i, W // 4 >> i)
         M = B * gd[0] * gd[1] * gd[2]
-        rows, rows_s = (1024, 256) if G >= 4 else (512, 128)                     # dn_net.hip: ms3
-        fills = lambda w: w * 10 >= -(-w // 768) * 768 * 9                     # dn_ops.h: mms_conv3w_mt_fills
-        if G >= 4 and M > 1024 and not fills(-(-M // 1024) * G * 9) and fills(-(-M // 512) * G * 9):
-            rows = 512                                                           # ... e.g. 5 models: multi-tap kernel on 512-row chunks
-        ms = (M + rows - 1) // rows if M > 1024 else max((M + rows_s - 1) // rows_s, 1)
+        R = _stat_reps(M)
+        ns = _conv3_nsplit(M, G)
         coords = ops.init_coords(B, gd, device)
-        keep, blocks = [], []
+        keep, fw, bd, bw = [], [], [], []
         for _ in range(G):
             y1 = torch.randn(M, 128, device=device)
             s, q = y1.double().sum(0), (y1.double() ** 2).sum(0)
-            bn = ops.bnsrc(g, b, M, True, s, q)
+            bn = ops.bnsrc(gam, bet, M, True, s, q)
+            slab = torch.zeros(M, 256, device=device)
             dslab = torch.randn(M, 256, device=device)
+            ost = torch.zeros(R, 2, 256, dtype=torch.float64, device=device)
+            bst = torch.zeros(R, 2, 128, dtype=torch.float64, device=device)
+            dbn = torch.zeros(M, 128, device=device)
+            part = torch.zeros(max(ns, 1) * M * 128, device=device) if ns > 1 else None
             dwp = torch.zeros(27 * 32 * 128, device=device)
-            dz = dslab[:, 64:96]
-            keep.append((y1, s, q, dslab, dwp))
-            blocks.append(S["Conv3BwdWP"](y1.data_ptr(), coords.data_ptr(), ops.dims3(gd), M, bn, dz.data_ptr(), dz.stride(0),
-                                          dwp.data_ptr(), ms, 1))
-        arr = (S["Conv3BwdWP"] * G)(*blocks)
+            out, dz = slab[:, 64:96], dslab[:, 64:96]
+            keep.append((y1, s, q, slab, dslab, ost, bst, dbn, part, dwp))
+            f = S["Conv3FwdP"](y1.data_ptr(), coords.data_ptr(), ops.dims3(gd), M, wpf.data_ptr(), out.data_ptr(), out.stride(0), bn,
+                               ost[0, 0, 64:].data_ptr(), ost[0, 1, 64:].data_ptr(), ops.ptr(part), ns, R, 2 * 256)
+            d = S["Conv3BwdDataP"](dz.data_ptr(), dz.stride(0), coords.data_ptr(), ops.dims3(gd), M, wpb.data_ptr(), y1.data_ptr(), bn,
+                                   dbn.data_ptr(), bst[0, 0].data_ptr(), bst[0, 1].data_ptr(), ops.ptr(part), ns, R, 2 * 128)
+            g_ = S["Conv3BwdWP"](y1.data_ptr(), coords.data_ptr(), ops.dims3(gd), M, bn, dz.data_ptr(), dz.stride(0),
+                                 dwp.data_ptr(), _bwdw_msplit(M, G), 1)
+            fw.append(f); bd.append(d); bw.append(g_)
+        arrs = {"fwd": ((S["Conv3FwdP"] * G)(*fw), lib.mms_conv3_fwd_group),
+                "bwd_data": ((S["Conv3BwdDataP"] * G)(*bd), lib.mms_conv3_bwd_data_group),
+                "bwd_weight": ((S["Conv3BwdWP"] * G)(*bw), lib.mms_conv3_bwd_weight_group)}
+        for op, (arr, fn) in arrs.items():
+            for _ in range(3):
+                _lib.check(fn(arr, G, ops.stream()), op)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                _lib.check(fn(arr, G, ops.stream()), op)
+            e1.record()
+            torch.cuda.synchronize()
+            tot[op][0] += e0.elapsed_time(e1) * 1e-3 / reps * layers
+            tot[op][1] += G * 2.0 * M * 27 * 128 * 32 * layers
+        nl += layers
+    return {op: (t / nl, f / nl) for op, (t, f) in tot.items()}
 
-        def launch():
-            _lib.check(lib.mms_conv3_bwd_weight_group(arr, G, ops.stream()), "mms_conv3_bwd_weight_group")
-        for _ in range(3):
-            launch()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            launch()
-        e1.record()
-        torch.cuda.synchronize()
-        t = e0.elapsed_time(e1) * 1e-3 / reps
-        tot_t += t * layers
-        tot_f += G * 2.0 * M * 27 * 128 * 32 * layers
-        n += layers
-    return tot_t / n, tot_f / n
+
+_ROOF_NAMES = {"fwd": "mms_conv3_fwd_group = conv3_fwd_mt_kernel / tile_gemm_kernel<Conv3FwdOp> (+ conv3_fwd_reduce_kernel)",
+               "bwd_data": "mms_conv3_bwd_data_group = tile_gemm_kernel<Conv3BwdDataOp> (+ conv3_bwd_data_reduce_kernel)",
+               "bwd_weight": "mms_conv3_bwd_weight_group = conv3_bwdw_mt_kernel / tile_gemm_kernel<Conv3BwdWOp>"}
 
 
-def cpu_baseline(cohort, train_idx, steps, B):
-    """The CPU oracle (same model, same loop body) on this box's host cores: bounded sample of `steps` batches."""
+def roofline_block(B, dims, dev, group_sizes):
+    """`roofline` object of the JSON line.  group_sizes: models per launch of the sub-groups the timed region ran (e.g. (3, 2));
+    per op the launches of all sub-groups are pooled (time and FLOPs summed).  The dominant kernel = the op with the largest
+    time per lock-step step; the other two are listed beside it."""
+    fam = {}
+    for G in group_sizes:
+        for op, (t, f) in measure_conv2_family(B, dims, dev, G).items():
+            a = fam.setdefault(op, [0.0, 0.0, 0])
+            a[0] += t; a[1] += f; a[2] += 1
+    dom = max(fam, key=lambda k: fam[k][0])
+    t, f, n = fam[dom]
+    traffic = None      # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)
+    for name in ("r02_pmc_conv2_traffic.json", "r01_pmc_conv3bwdw_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                j = json.load(fh)
+            traffic = j.get(dom, j).get("avg_hbm_bytes_per_launch") if isinstance(j.get(dom, j), dict) else None
+            if traffic is not None:
+                break
+        except (OSError, KeyError, ValueError, AttributeError):
+            pass
+    return {"bound": "mfma", "kernel": _ROOF_NAMES[dom] + f"; 58 launches per lock-step step and sub-group, sub-groups of {'+'.join(map(str, group_sizes))} fold models per launch",
+            "achieved": f / t / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": f / t / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            "traffic": traffic, "avg_launch_us": t / n * 1e6, "avg_flops_per_launch": f / n,
+            "family": {op: {"avg_launch_us": v[0] / v[2] * 1e6, "achieved": v[1] / v[0] / 1e12,
+                            "frac": v[1] / v[0] / 1e12 / PEAK_FP32_MFMA_TFLOPS} for op, v in fam.items()}}
+
+
+# ---- CPU baselines (the oracle = torch fp32 restatement; bench.py's cpu_baseline leg is one of the three places allowed to use it)
+def cpu_baseline_partial(cohort, train_idx, steps, B):
+    """The CPU oracle's train_epoch_partial loop body (oracle/loops.py, partial_modality_training.py:382-435) on the SAME cohort
+    and fold split, on this box's host cores: bounded sample of `steps` batches after one warm-up batch."""
+    from oracle import loops as OLP
+    from oracle import models as OM
+    torch.manual_seed(0)
+    model = OM.PartialModalityNet(rna_dim=cohort["rnaseq"].shape[1], use_monai=True)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-4)
+    cores = torch.get_num_threads()
+
+    def loader(lo, hi):
+        for i in range(lo, hi):
+            j = train_idx[i * B:(i + 1) * B]
+            yield dict(image=cohort["image"][j], rnaseq=cohort["rnaseq"][j], clinical=cohort["clinical"][j], label=cohort["label"][j],
+                       mask=cohort["mask"][j], has_survival=cohort["has_survival"][j].tolist())
+    OLP.train_epoch_partial(model, loader(0, 1), opt, "cpu")
+    t0 = time.perf_counter()
+    OLP.train_epoch_partial(model, loader(1, steps + 1), opt, "cpu")
+    dt = time.perf_counter() - t0
+    return dict(value=steps * B / dt, unit="patients/s", cores=cores, kind="port",
+                sample=f"{steps} batches (batch {B}) of the torch-fp32 CPU oracle's train_epoch_partial on fold 1's training split "
+                       f"of the same cohort, after 1 warm-up batch, {dt:.1f} s")
+
+
+def cpu_baseline_final(cohort, train_idx, steps, B):
+    """Config 2: the CPU oracle's final_multimodal loop body."""
     from oracle import losses as OL
     from oracle import models as OM
     torch.manual_seed(0)
@@ -118,6 +217,182 @@ def cpu_baseline(cohort, train_idx, steps, B):
                 sample=f"{steps} training steps (batch {B}) of the torch-fp32 CPU oracle after 1 warm-up step, {dt:.1f} s")
 
 
+# ---- workload c3: BASELINE config 3 (the metric's configuration) -------------------------------------------------------------
+def run_config3(args, world, rank, dev):
+    import numpy as np
+    from multimodal_survival_prediction_amd import data, distributed as D, models
+    from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
+    from multimodal_survival_prediction_amd.training import train_epoch_lockstep, validate_lockstep
+
+    B, dims, K = args.batch, tuple(args.volume), args.folds
+    cohort_cpu = data.make_cohort(n=args.patients, dims=dims, rna_dim=5005, seed=608, complete=False)
+    cohort = data.cohort_to(cohort_cpu, dev)                      # resident in HBM before the timed region
+    has = cohort_cpu["has_survival"].numpy()
+    survival, non_survival = np.nonzero(has)[0], np.nonzero(~has)[0]
+
+    def cv_loaders(random_state):
+        folds = data.kfold_indices(len(survival), K, seed=random_state)
+        tr = [np.concatenate([survival[f[0]], non_survival]) for f in folds]          # partial_modality_training.py:508-513
+        va = [survival[f[1]] for f in folds]
+        return ([data.BatchLoader(cohort, t, B, shuffle=True, seed=random_state + k, lazy=True, with_valid=True) for k, t in enumerate(tr)],
+                [data.BatchLoader(cohort, v, B, shuffle=False) for v in va], tr, folds)
+
+    rep = rank                                                     # N > 1: rank r = repetition r of the K-fold CV
+    train_loaders, val_loaders, train_sets, folds = cv_loaders(42 + rep)
+    ms = []
+    for k in range(K):
+        torch.manual_seed(42 + rep * K + k)
+        ms.append(models.PartialModalityNet(rna_dim=5005).to(dev).train())
+    group = FoldGroupEngine(ms, lr=1e-4, weight_decay=1e-4, adamw=False, gate_entropy_weight=0.01)
+    conc = args.lockstep_streams
+    steps_per_epoch = max(len(l) for l in train_loaders)
+    patients_per_epoch = sum(len(t) for t in train_sets)
+
+    def epoch(members=None):
+        mem = tuple(range(K)) if members is None else tuple(members)
+        return train_epoch_lockstep(group, [train_loaders[g] for g in mem], "partial", members=mem, concurrent=conc)
+
+    def timed(fn):
+        torch.cuda.synchronize(); D.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize(); D.barrier(); torch.cuda.synchronize()
+        return D.max_over_ranks(time.perf_counter() - t0, dev), r
+
+    n_warm = max(1, math.ceil(args.warmup / steps_per_epoch))       # whole epochs: every sub-group / ragged-tail graph gets captured
+    for _ in range(n_warm):
+        epoch()
+    n_ep = max(1, math.ceil(args.steps / steps_per_epoch))
+    last = []
+
+    def run_epochs():
+        for _ in range(n_ep):
+            last[:] = epoch()
+    dt, _ = timed(run_epochs)
+    value = world * n_ep * patients_per_epoch / dt
+    if args.timed_only:
+        if rank == 0:
+            print(f"timed-only: {value:.1f} patients/s, {dt / (n_ep * steps_per_epoch) * 1e3:.3f} ms per lock-step step, "
+                  f"{dt / n_ep:.3f} s per epoch", flush=True)
+        D.barrier()
+        return
+    sub_groups = (K,) if conc <= 1 or K < 4 else ((K + 1) // 2, K // 2)
+
+    # ONE cross-validation's folds dealt over the ranks (BASELINE config 3's layout: fold k -> rank k mod N), one epoch
+    sharded = None
+    if world > 1:
+        mine = D.folds_of_rank(K, world, rank)
+        if mine:
+            epoch(mine)                                              # capture the sub-group graphs of this member set
+        dts, _ = timed(lambda: epoch(mine) if mine else None)
+        sharded = patients_per_epoch / dts
+    # one fold model alone on the GPU (what a rank with a single fold of config 3 runs)
+    n1 = max(20, min(steps_per_epoch, args.steps // 3))
+    idx1 = train_loaders[0].idx
+
+    def chain(n):
+        for i in range(n):
+            group.train_step_indexed(train_loaders[0].view, idx1[(i % (len(idx1) // B)) * B:][:B].view(1, B), members=(0,),
+                                     skip_if_unusable=False)
+    chain(3)
+    dt1, _ = timed(lambda: chain(n1))
+    dt1 /= n1
+    # validation (reported separately): validate_lockstep over the K validation splits
+    validate_lockstep(group, val_loaders, "partial", dev)
+    dtv, val = timed(lambda: validate_lockstep(group, val_loaders, "partial", dev))
+    n_val = sum(len(l.idx) for l in val_loaders)
+    for e_ in group.engines:
+        e_.model.train()
+    # host-resident variant (the reference moves every batch host -> device, final_multimodal.py:244-247)
+    h2d = run_h2d_epoch(args, group, cohort_cpu, train_sets, B, dev, timed, conc) if args.h2d else None
+    # the same kernels with the chip filled: 2 concurrent groups x 10 lock-step fold models (four cross-validations in flight)
+    many = None
+    if args.many_folds:
+        many = run_many(args, cohort, train_sets, B, dev, timed, models, FoldGroupEngine)
+
+    if rank == 0:
+        out = {
+            "metric": "patients/sec per epoch (training epoch of the K-fold job: fwd + Cox + gate entropy + bwd + clip + Adam)",
+            "value": value, "unit": "patients/s", "n_gpus": world, "steps": n_ep * steps_per_epoch,
+            "warmup": n_warm * steps_per_epoch, "ms_per_step": dt / (n_ep * steps_per_epoch) * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "BASELINE config 3, N=1 leg (the metric's configuration): %d synthetic patients with modality masks "
+                            "(%d CT / %d RNA-seq / %d clinical / %d labelled), PartialModalityNet (DenseNet121-3D CT %dx%dx%d + RNA-seq 5005 + "
+                            "clinical, softmax gate + 0.01 x gate entropy), %d-fold CV over the labelled patients with all %d unlabelled "
+                            "patients in every training split (%d training patients per epoch over the folds), batch %d, Adam lr 1e-4 wd "
+                            "1e-4, clip 1.0; %d whole epoch(s) timed, ragged tails and entropy-only batches included"
+                            % (args.patients, int(cohort_cpu["mask"][:, 0].sum()), int(cohort_cpu["mask"][:, 1].sum()),
+                               int(cohort_cpu["mask"][:, 2].sum()), len(survival), dims[0], dims[1], dims[2], K, len(non_survival),
+                               patients_per_epoch, B, n_ep),
+                "step": "one lock-step step of the K-fold job: every fold model takes one batch (<= %d x %d patients)" % (K, B),
+                "steps_requested": args.steps, "warmup_requested": args.warmup, "epochs_timed": n_ep, "steps_per_epoch": steps_per_epoch,
+                "train_patients_per_epoch": patients_per_epoch, "seconds_per_epoch": dt / n_ep,
+                "global_batch": world * K * B,
+                "parallelism": (f"{world} rank(s), each its own repetition of the {K}-fold CV (repeated K-fold, no data-path collective); "
+                                f"per GPU the {K} fold models in lock-step as sub-groups of {'+'.join(map(str, sub_groups))} on "
+                                f"{len(sub_groups)} HIP stream(s), one step graph per sub-group"),
+                "fold_models_in_flight": K, "lockstep_streams": conc,
+                "one_cv_sharded_patients_per_s": sharded,
+                "single_chain_patients_per_s": world * B / dt1, "single_chain_ms_per_step": dt1 * 1e3,
+                "validation_patients_per_s": world * n_val / dtv,
+                "h2d": h2d, "many_folds": many,
+                "hip_graph": True, "bn": "per-model batch statistics", "cox": "per-batch risk sets (Breslow = reference on distinct times)",
+                "train_loss_last_epoch": [[float(a), float(b)] for a, b in last],
+                "val_loss_cindex": [[float(a), float(b)] for a, b in val]},
+        }
+        out["roofline"] = roofline_block(B, dims, dev, sub_groups)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_partial(cohort_cpu, torch.as_tensor(train_sets[0]), args.cpu_steps, B)
+        print(json.dumps(out), flush=True)
+    D.barrier()
+
+
+def run_h2d_epoch(args, group, cohort_cpu, train_sets, B, dev, timed, conc):
+    """One epoch of the same K-fold job with the cohort in PINNED HOST memory: every step's batches are assembled on the host
+    side by index and copied host -> device asynchronously (the reference does `.to(device)` per batch,
+    final_multimodal.py:244-247), the copy of step i+1 overlapping the kernels of step i on the training stream's queue."""
+    from multimodal_survival_prediction_amd import data
+    from multimodal_survival_prediction_amd.training import train_epoch_lockstep
+    pinned = {k: (v.pin_memory() if isinstance(v, torch.Tensor) else v) for k, v in cohort_cpu.items()}
+    loaders = [data.HostBatchLoader(pinned, t, B, shuffle=True, seed=142 + k, device=dev) for k, t in enumerate(train_sets)]
+    train_epoch_lockstep(group, loaders, "partial", concurrent=conc)
+    dt, _ = timed(lambda: train_epoch_lockstep(group, loaders, "partial", concurrent=conc))
+    return {"patients_per_s": sum(len(t) for t in train_sets) / dt,
+            "what": "same epoch, cohort in pinned host memory, per-batch async H2D copies (PCIe) inside the timed region"}
+
+
+def run_many(args, cohort, train_sets, B, dev, timed, models, FoldGroupEngine):
+    """2 concurrent groups x 10 lock-step PartialModalityNet fold models (four cross-validations in flight): the throughput of the
+    same kernels when the launches fill the chip -- a capability figure, not the metric."""
+    F, G = 2, 10
+    groups, streams, orders = [], [], []
+    for f in range(F):
+        ms = []
+        for g in range(G):
+            torch.manual_seed(1000 + f * G + g)
+            ms.append(models.PartialModalityNet(rna_dim=5005).to(dev).train())
+            gen = torch.Generator().manual_seed(7 + f * G + g)
+            t = torch.as_tensor(train_sets[(f * G + g) % len(train_sets)])
+            orders.append(t[torch.randperm(len(t), generator=gen)])
+        groups.append(FoldGroupEngine(ms, lr=1e-4, weight_decay=1e-4, adamw=False, gate_entropy_weight=0.01))
+        streams.append(torch.cuda.Stream(device=dev))
+    from multimodal_survival_prediction_amd import data
+    view = data.gather_view(cohort, True)
+
+    def run(n):
+        for u in range(n):
+            f, k = u % F, u // F
+            with torch.cuda.stream(streams[f]):
+                idx = [orders[f * G + g][(k % (len(orders[f * G + g]) // B)) * B:][:B] for g in range(G)]
+                groups[f].train_step_indexed(view, torch.stack(idx), skip_if_unusable=False)
+    run(3 * F)
+    n = 12
+    dt, _ = timed(lambda: run(n))
+    return {"patients_per_s": n * G * B / dt, "fold_models_in_flight": F * G}
+
+
+# ---- workload c5 --------------------------------------------------------------------------------------------------------------
 def run_config5(args, dev):
     """BASELINE config 5 (`--workload c5`, single GPU): RNA-seq-only model 5005 -> 1024 -> 512 -> 256 -> 1 at batch 2048, one full
     training step per replay (zero-grad, forward, O(B^2) Cox partial likelihood, backward, AdamW; train_rnaseq_only.py:153-176)
@@ -188,65 +463,15 @@ def run_config5(args, dev):
     print(json.dumps(out), flush=True)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=240)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=4)
-    ap.add_argument("--volume", type=int, nargs=3, default=(64, 64, 32), metavar=("D", "H", "W"),
-                    help="CT volume (default: the headline 64 64 32; BASELINE config 4 uses 128 128 64)")
-    ap.add_argument("--workload", choices=["c2", "c5"], default="c2",
-                    help="c2 (default): BASELINE configs[1], the headline; c5: BASELINE config 5 (RNA-seq-only model, batch 2048, single GPU)")
-    ap.add_argument("--cpu-steps", type=int, default=6)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--timed-only", action="store_true", help="profiling aid: stop after the timed region (no extra legs, no JSON)")
-    ap.add_argument("--roofline-only", action="store_true",
-                    help="profiling aid: run only the roofline leg (the dominant kernel's isolated group launches), so that a "
-                         "rocprofv3 --stats summary of this command holds exactly the launches the live measurement times")
-    ap.add_argument("--concurrent-folds", type=int, default=2,
-                    help="fold groups trained concurrently per GPU, one HIP stream + step graph each (mode fold)")
-    ap.add_argument("--fold-group", type=int, default=10,
-                    help="fold models advanced in lock-step by ONE launch sequence (FoldGroupEngine, *_group entry points); "
-                         "--concurrent-folds then counts concurrent groups")
-    ap.add_argument("--global-cox", action="store_true",
-                    help="mode ddp: Cox risk set over the whole global batch (all-gather of hazards/times/events, gradients "
-                         "summed) instead of rank-local risk sets")
-    ap.add_argument("--mode", choices=["fold", "ddp"], default="fold",
-                    help="N>1: 'fold' = K-fold units sharded over ranks, no collective (default); 'ddp' = one model, global "
-                         "batch N*B, flat gradient all-reduce (RCCL) per step")
-    args = ap.parse_args()
-
-    from multimodal_survival_prediction_amd import distributed as D
-    world, rank, local = D.init()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-
-    from multimodal_survival_prediction_amd import _build, _lib
-    if not os.path.exists(_lib.lib_path()):
-        _build.build()
-    if args.workload == "c5":
-        if world > 1:
-            raise SystemExit("--workload c5 is a single-GPU run")
-        if args.steps == 240 and args.warmup == 20:
-            args.steps, args.warmup = 200, 10
-        run_config5(args, dev)
-        return
-    from multimodal_survival_prediction_amd import data, models
+# ---- workload c2 (round 1's headline) and --mode ddp (config 4's step) ---------------------------------------------------------
+def run_config2(args, world, rank, dev):
+    """BASELINE configs[1]: MultiModalSurvivalNet, 109 complete patients; a step = one batch of 4 patients of ONE fold model, the K
+    timed steps dealt over --concurrent-folds groups of --fold-group lock-step fold models.  --mode ddp: one model, this rank's
+    shard of the global batch per step, gradient all-reduce (RCCL) between backward and clip+Adam."""
+    from multimodal_survival_prediction_amd import data, distributed as D, models
     from multimodal_survival_prediction_amd.training import FusedOptimizer
 
     B, dims, rna_dim = args.batch, tuple(args.volume), 5005
-    if args.roofline_only:
-        Gr = max(1, min(args.fold_group, 10))
-        avg_t, avg_f = measure_dominant_kernel(B, dims, dev, Gr)
-        print(json.dumps({"kernel": "mms_conv3_bwd_weight_group (conv3_bwdw_mt_kernel / tile_gemm_kernel<Conv3BwdWOp>)", "models_per_launch": Gr, "avg_launch_us": avg_t * 1e6,
-                          "avg_flops_per_launch": avg_f, "achieved_tflops": avg_f / avg_t / 1e12}), flush=True)
-        return
     cohort_cpu = data.make_cohort(n=109, dims=dims, rna_dim=rna_dim, seed=608, complete=True)
     cohort = data.cohort_to(cohort_cpu, dev)                      # resident in HBM before the timed region
     folds = data.kfold_indices(cohort["n"], 5, seed=42)
@@ -294,7 +519,7 @@ def main():
                                              skip_if_unusable=True, use_graph=not args.no_graph)
             else:
                 engines[f].train_step(skip_if_unusable=True, use_graph=not args.no_graph, ddp_world=world if ddp else 1,
-                                      global_cox=bool(ddp and args.global_cox), **batch_of(f, k))
+                                      global_cox=bool(ddp and args.global_cox), sync_bn=bool(ddp and args.sync_bn), **batch_of(f, k))
 
     def run(nsteps, nf):
         """exactly nsteps steps (one step = one batch of one fold model), dealt over nf groups of G lock-step models"""
@@ -324,105 +549,96 @@ def main():
             print(f"timed-only: {world * args.steps * B / dt:.1f} patients/s, {dt / args.steps * 1e3:.3f} ms/step", flush=True)
         D.barrier()
         return
-    # single chain: ONE fold model alone on the GPU (no grouping, no concurrency), same graph-replayed step
-    if F * G > 1:
-        n1 = max(args.steps // (3 * F * G), 10)
-        if G > 1:
-            def one(i):
-                nb0 = len(orders[0]) // B
-                groups[0].train_step_indexed(cohort, orders[0][(i % nb0) * B:][:B].view(1, B), members=(0,),
-                                             skip_if_unusable=True, use_graph=not args.no_graph)
-            for i in range(3):
-                one(i)
-            torch.cuda.synchronize(); D.barrier()
-            t0 = time.perf_counter()
-            for i in range(n1):
-                one(i)
-            torch.cuda.synchronize(); D.barrier()
-            dt1 = D.max_over_ranks(time.perf_counter() - t0, dev) / n1
-        else:
-            dt1 = timed(n1, 1) / n1
-    else:
-        dt1 = dt / args.steps
-    # one 5-fold cross-validation alone on the GPU: its 5 models and nothing else (members 0-4 of group 0, stepped as two
-    # concurrent lock-step sub-groups of 3 + 2)
-    dt5 = None
-    if G >= 5:
-        cv5_split = os.environ.get("MMS_CV5_SPLIT", "1") == "1" and F >= 2      # sub-groups (0,1,2) and (3,4) on two streams (+4.5 % over one group of 5)
-
-        def cv5(i):
-            idx = [orders[g][(i % (len(orders[g]) // B)) * B:][:B] for g in range(5)]
-            if not cv5_split:
-                groups[0].train_step_indexed(cohort, torch.stack(idx), members=(0, 1, 2, 3, 4), skip_if_unusable=True,
-                                             use_graph=not args.no_graph)
-                return
-            for sidx, mem in ((0, (0, 1, 2)), (1 % F, (3, 4))):
-                with torch.cuda.stream(streams[sidx]):
-                    groups[0].train_step_indexed(cohort, torch.stack([idx[m] for m in mem]), members=mem, skip_if_unusable=True,
-                                                 use_graph=not args.no_graph)
-        n5 = max(args.steps // (2 * F * G), 6)
-        for i in range(3):
-            cv5(i)
-        torch.cuda.synchronize(); D.barrier()
-        t0 = time.perf_counter()
-        for i in range(n5):
-            cv5(i)
-        torch.cuda.synchronize(); D.barrier()
-        dt5 = D.max_over_ranks(time.perf_counter() - t0, dev) / (5 * n5)
-    # validation (reported separately): eval-mode forwards of the same models, same grouping/concurrency
-    val_rate = None
-    if G > 1:
-        for e_ in engines:
-            e_.model.eval()
-        nv = max(args.steps // (F * G), 4)
-
-        def vrun(n):
-            for u in range(n):
-                f = u % F
-                with torch.cuda.stream(streams[f]):
-                    bs = [batch_of(f * G + g, u // F) for g in range(G)]
-                    groups[f].forward_eval([dict(ct=b["ct"], rna=b["rna"], clinical=b["clinical"]) for b in bs])
-        vrun(2 * F)
-        torch.cuda.synchronize(); D.barrier()
-        t0 = time.perf_counter()
-        vrun(nv)
-        torch.cuda.synchronize(); D.barrier()
-        val_rate = world * nv * G * B / D.max_over_ranks(time.perf_counter() - t0, dev)
-        for e_ in engines:
-            e_.model.train()
     stats = engines[0].epoch_stats()
-
     if rank == 0:
         out = {
             "metric": "patients/sec per epoch (training: fwd + Cox + bwd + clip + Adam)",
             "value": world * args.steps * B / dt, "unit": "patients/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "MultiModalSurvivalNet (DenseNet121-3D CT %dx%dx%d + RNA-seq 5005 + clinical), "
+            "config": {"workload": "BASELINE config 2: MultiModalSurvivalNet (DenseNet121-3D CT %dx%dx%d + RNA-seq 5005 + clinical), "
                                    "109 synthetic complete patients, 5-fold split, batch %d, Adam lr 1e-4 wd 1e-4, clip 1.0" % (dims + (B,)),
-                       "global_batch": world * B, "parallelism": (f"ddp x{world} (flat gradient all-reduce per step, local BN + {'global' if args.global_cox else 'local'} Cox risk set)" if ddp else
+                       "global_batch": world * B,
+                       "parallelism": (f"ddp x{world} (gradient all-reduce per step in {args.ddp_buckets} bucket(s) overlapped with backward, "
+                                       f"{'Sync' if args.sync_bn else 'local'} BN + {'global' if args.global_cox else 'local'} Cox risk set)" if ddp else
                                        f"kfold-shard x{world} ranks x {F} concurrent groups x {G} lock-step fold models per GPU (one stream + step graph per group, no collective)"),
                        "concurrent_folds": F, "fold_group": G, "fold_models_in_flight": F * G,
-                       "one_cv_5_lockstep_patients_per_s": (world * B / dt5) if dt5 else None,
-                       "validation_patients_per_s": val_rate, "single_chain_patients_per_s": world * B / dt1, "single_chain_ms_per_step": dt1 * 1e3,
                        "hip_graph": not args.no_graph, "mean_train_loss": stats["sum_loss"] / max(stats["n_batches"], 1)},
         }
-        avg_t, avg_f = measure_dominant_kernel(B, dims, dev, G)
-        traffic = None      # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_conv3bwdw_traffic.json")) as f:
-                traffic = json.load(f)["avg_hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
-        out["roofline"] = {"bound": "mfma", "kernel": f"mms_conv3_bwd_weight_group = conv3_bwdw_mt_kernel (block-1 launches of well-filled groups) / tile_gemm_kernel<Conv3BwdWOp> "
-                                                       f"(weight gradient of the dense-layer 3x3x3 conv; 58 launches per group step, {G} fold models per launch)",
-                           "achieved": avg_f / avg_t / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": avg_f / avg_t / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                           "avg_launch_us": avg_t * 1e6, "avg_flops_per_launch": avg_f}
+        out["roofline"] = roofline_block(B, dims, dev, (G,))
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cohort_cpu, torch.as_tensor(folds[0][0]), args.cpu_steps, B)
+            out["cpu_baseline"] = cpu_baseline_final(cohort_cpu, torch.as_tensor(folds[0][0]), args.cpu_steps, B)
         print(json.dumps(out), flush=True)
     D.barrier()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="c3: lock-step steps (rounded up to whole epochs, default one epoch); "
+                                                            "c2/c5: optimisation steps (default 240 / 200)")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--volume", type=int, nargs=3, default=(64, 64, 32), metavar=("D", "H", "W"),
+                    help="CT volume (default: the headline 64 64 32; BASELINE config 4 uses 128 128 64)")
+    ap.add_argument("--workload", choices=["c3", "c2", "c5"], default="c3",
+                    help="c3 (default): BASELINE config 3's N=1 leg, the metric's configuration; c2: BASELINE configs[1] (round 1's "
+                         "headline; also hosts --mode ddp); c5: BASELINE config 5 (RNA-seq-only model, batch 2048, single GPU)")
+    ap.add_argument("--patients", type=int, default=608)
+    ap.add_argument("--folds", type=int, default=5)
+    ap.add_argument("--lockstep-streams", type=int, default=2, help="c3: 2 = the folds step as two lock-step sub-groups on two HIP streams")
+    ap.add_argument("--h2d", action="store_true", default=True, help="c3: also time the epoch with the cohort in pinned host memory")
+    ap.add_argument("--no-h2d", dest="h2d", action="store_false")
+    ap.add_argument("--many-folds", action="store_true", default=True, help="c3: also time 2 x 10 fold models in flight")
+    ap.add_argument("--no-many-folds", dest="many_folds", action="store_false")
+    ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--timed-only", action="store_true", help="profiling aid: stop after the timed region (no extra legs, no JSON)")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="profiling aid: run only the roofline leg (the conv2 family's isolated group launches), so that a "
+                         "rocprofv3 --stats summary of this command holds exactly the launches the live measurement times")
+    ap.add_argument("--concurrent-folds", type=int, default=2, help="c2: fold groups trained concurrently per GPU")
+    ap.add_argument("--fold-group", type=int, default=10, help="c2: fold models advanced in lock-step by ONE launch sequence")
+    ap.add_argument("--global-cox", action="store_true",
+                    help="mode ddp: Cox risk set over the whole global batch (all-gather of hazards/times/events, gradients "
+                         "summed) instead of rank-local risk sets")
+    ap.add_argument("--sync-bn", action="store_true", help="mode ddp: BatchNorm statistics over the global batch (SyncBN)")
+    ap.add_argument("--ddp-buckets", type=int, default=6, help="mode ddp: gradient all-reduce buckets (reverse-layer order)")
+    ap.add_argument("--mode", choices=["fold", "ddp"], default="fold",
+                    help="c2, N>1: 'fold' = K-fold units sharded over ranks, no collective; 'ddp' = one model, global "
+                         "batch N*B, bucketed gradient all-reduce (RCCL) per step")
+    args = ap.parse_args()
+
+    from multimodal_survival_prediction_amd import distributed as D
+    world, rank, local = D.init()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from multimodal_survival_prediction_amd import _build, _lib
+    if not os.path.exists(_lib.lib_path()):
+        _build.build()
+    if args.mode == "ddp":
+        args.workload = "c2"
+    dflt = {"c3": (1, 1), "c2": (240, 20), "c5": (200, 10)}[args.workload]
+    args.steps = dflt[0] if args.steps is None else args.steps
+    args.warmup = dflt[1] if args.warmup is None else args.warmup
+    if args.roofline_only:
+        sub = ((args.folds + 1) // 2, args.folds // 2) if args.workload == "c3" and args.lockstep_streams > 1 else (max(1, min(args.fold_group, 10)),)
+        print(json.dumps(roofline_block(args.batch, tuple(args.volume), dev, sub)), flush=True)
+        return
+    if args.workload == "c5":
+        if world > 1:
+            raise SystemExit("--workload c5 is a single-GPU run")
+        run_config5(args, dev)
+    elif args.workload == "c2":
+        run_config2(args, world, rank, dev)
+    else:
+        run_config3(args, world, rank, dev)
 
 
 if __name__ == "__main__":

@@ -115,3 +115,49 @@ def kfold_indices(n, n_splits, seed=42):
     """sklearn KFold(n_splits, shuffle=True, random_state=seed).split(range(n)) (final_multimodal.py:316)."""
     from sklearn.model_selection import KFold
     return list(KFold(n_splits=n_splits, shuffle=True, random_state=seed).split(np.arange(n)))
+
+
+class HostBatchLoader:
+    """The reference's situation (final_multimodal.py:228-247: host-side DataLoader collate, `.to(device)` per batch): the cohort
+    lives in PINNED host memory, a batch is collated on the host into a ring of pinned staging buffers and handed to the
+    consumer, whose `copy_(..., non_blocking=True)` into the step graph's static inputs is then an asynchronous PCIe copy that
+    overlaps the previous step's kernels.  A staging slot is reused only after the event recorded behind its copies completed."""
+
+    KEYS = ("image", "rnaseq", "clinical", "label", "mask")
+
+    def __init__(self, cohort_pinned, indices, batch_size, shuffle=False, seed=0, device="cuda", depth=4):
+        self.c, self.idx, self.bs, self.shuffle = cohort_pinned, torch.as_tensor(indices), batch_size, shuffle
+        self.gen = torch.Generator().manual_seed(seed)
+        self.device = device
+        self.hs = cohort_pinned["has_survival"].tolist()
+        self.ring = [{k: torch.empty((batch_size,) + tuple(cohort_pinned[k].shape[1:]), dtype=cohort_pinned[k].dtype).pin_memory()
+                      for k in self.KEYS} for _ in range(depth)]
+        self.events = [None] * depth
+
+    def __len__(self):
+        return (len(self.idx) + self.bs - 1) // self.bs
+
+    def __iter__(self):
+        idx = self.idx[torch.randperm(len(self.idx), generator=self.gen)] if self.shuffle else self.idx
+        slot, prev = 0, None
+        for i in range(0, len(idx), self.bs):
+            if prev is not None:                     # the consumer has enqueued its copies of the previous batch by now
+                ev = torch.cuda.Event()
+                ev.record()
+                self.events[prev] = ev
+            if self.events[slot] is not None:
+                self.events[slot].synchronize()
+            j = idx[i:i + self.bs]
+            n = len(j)
+            st = self.ring[slot]
+            b = {}
+            for k in self.KEYS:
+                torch.index_select(self.c[k], 0, j, out=st[k][:n])
+                b[k] = st[k][:n]
+            b["has_survival"] = [self.hs[int(q)] for q in j]
+            prev, slot = slot, (slot + 1) % len(self.ring)
+            yield b
+        if prev is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            self.events[prev] = ev

@@ -446,6 +446,8 @@ class SurvivalEngine:
             self._backward_from_dhz(P)
             if part == "grad":
                 return
+        if part == "update":
+            self.sumsq.zero_()                 # mms_grad_sumsq ADDS into it; the other parts that zero it are not in this graph
         ad = P.adam_skip if skip_if_unusable else P.adam
         _lib.check(lib.mms_grad_sumsq(ctypes.byref(ad), st), "mms_grad_sumsq")
         _lib.check(lib.mms_clip_adam(ctypes.byref(ad), st), "mms_clip_adam")
@@ -498,7 +500,7 @@ class SurvivalEngine:
         return G
 
     def train_step(self, ct=None, rna=None, clinical=None, mask=None, time=None, event=None, valid=None, skip_if_unusable=True,
-                   use_graph=True, ddp_world=1, global_cox=False):
+                   use_graph=True, ddp_world=1, global_cox=False, sync_bn=False):
         """One optimisation step on one batch (inputs may live on host or device).  Returns nothing: losses are
         accumulated on the device (`epoch_stats()`), exactly one host sync per epoch instead of one per batch.
         ddp_world > 1: data-parallel step -- this rank's shard of the global batch; the flat gradient buffer is averaged
@@ -507,6 +509,8 @@ class SurvivalEngine:
         B = rna.shape[0]
         P = self.plan(B, tuple(ct.shape[-3:]) if ct is not None else None)
         self.load_batch(P, ct, rna, clinical, mask, time, event, valid)
+        if sync_bn:
+            raise NotImplementedError("sync_bn")
         if ddp_world > 1 and global_cox:
             # Cox is batch-coupled: for parity with ONE process stepping on the world*B patients, the risk sets must span all
             # ranks (SURVEY 8e ii).  [zero-grad, forward] | all-gather (h, time, event, valid) | [global Cox -> dL/dh of all

@@ -1,7 +1,7 @@
 #!/bin/bash
 # single-chain per-kernel profile of one training step (GPU box): prints the top kernels by time per step
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd /tmp; export TMPDIR=/tmp
-rm -rf /tmp/pstep; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pstep -- python3 $R/bench.py --steps ${STEPS:-20} --warmup 4 --no-cpu-baseline --timed-only --concurrent-folds 1 --fold-group ${GROUP:-1} > /tmp/pstep.log 2>&1
+rm -rf /tmp/pstep; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pstep -- python3 $R/bench.py --steps ${STEPS:-20} --warmup 4 --workload c2 --no-cpu-baseline --timed-only --concurrent-folds 1 --fold-group ${GROUP:-1} > /tmp/pstep.log 2>&1
 python3 - <<'PY'
 import csv,glob,collections
 f=glob.glob('/tmp/pstep/*/*_kernel_trace.csv')[0]
