@@ -290,8 +290,8 @@ typedef struct GateP {
     float* entropy;                 // optional scalar out (fwd): -mean_b(entropy_b)
 } GateP;
 
-/* Cox negative partial log-likelihood, Breslow risk sets (R/scripts/training/final_multimodal.py:171-186;
- * torchsurv on untied times): loss = -(1/n_e) sum_{i:e_i} (h_i - log sum_{j: t_j>=t_i} exp h_j).
+/* Cox negative partial log-likelihood (R/scripts/training/final_multimodal.py:158-186): Breslow risk sets
+ * loss = -(1/n_e) sum_{i:e_i} (h_i - log sum_{j: t_j>=t_i} exp h_j), or torchsurv's Efron tie handling (tie_mode).
  * valid: optional per-sample 0/1 (has_survival); excluded samples get dh = 0.
  * out[0] = loss, out[1] = 1 if the batch is usable (>=2 valid samples and >=1 event) else 0 (loss 0, dh 0). */
 typedef struct CoxP {
@@ -301,6 +301,12 @@ typedef struct CoxP {
     float* lse;                     // [n] workspace (multi-block path)
     float* dh; int lddh;            // dL/dh (null = forward only)
     float* out;                     // [2]
+    int tie_mode;                   // 0: Breslow risk sets (= every formulation of the reference on distinct times);
+                                    // 1: Efron tie correction as torchsurv's neg_partial_log_likelihood applies it when times
+                                    //    repeat (R/scripts/training/final_multimodal.py:158-162): the m events tied at a time
+                                    //    take the denominators D - (l/m) T, l = 0..m-1, and the loss is the MEAN over the
+                                    //    distinct event times (on distinct times both modes give the same value)
+    float* tie_frac;                // [n] workspace (tie_mode 1): l/m of each event
 } CoxP;
 
 /* Harrell C, pair counting (R/scripts/training/simple_fusion.py:59-73): counts[0]=concordant (h_i>h_j),

@@ -132,5 +132,14 @@ def load_cohort(root, device, target_size=(64, 64, 32), rna_dim=None):
         if pd.notna(row.survival_time):
             label[i, 0], label[i, 1] = float(row.survival_time), int(row.survival_status)
             has_surv[i] = True
+    # real survival times repeat (days); the fused step's Cox loss then follows losses.USE_TORCHSURV (Efron, torchsurv's rule) -- with
+    # the switch off it is the Breslow risk-set form, whereas the reference's in-file fallback is order-dependent under ties
+    t_lab = label[has_surv, 0]
+    n_dup = int(t_lab.numel() - torch.unique(t_lab).numel())
+    if n_dup:
+        import warnings
+        from . import losses
+        warnings.warn("cohort has %d repeated survival times among %d labelled patients: tie handling = %s (losses.USE_TORCHSURV = %s)"
+                      % (n_dup, int(t_lab.numel()), losses.default_ties(), losses.USE_TORCHSURV))
     return dict(image=image, rnaseq=rna.to(dev), clinical=clin.to(dev), label=label.to(dev), mask=mask.to(dev),
-                has_survival=has_surv.to(dev), n=n, dims=tuple(target_size), patient_id=list(mt["patient_id"]))
+                has_survival=has_surv.to(dev), n=n, dims=tuple(target_size), patient_id=list(mt["patient_id"]), tied_times=n_dup)

@@ -1,6 +1,8 @@
 // Shared device helpers for the mmsurv gfx950 kernels (CDNA4, wave64, fp32-input MFMA).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <mutex>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -167,8 +169,18 @@ __device__ __forceinline__ float4 buf_load4(buf_rsrc_t r, int voff, int soff) {
 }
 
 // Launch with a clean error slate: hipGetLastError() is sticky per thread and the host framework may leave benign
-// errors behind (e.g. attribute probes), which must not be reported as ours.
-#define MMS_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+// errors behind (e.g. attribute probes), which must not be reported as OUR launch failing -- but an error that was already
+// pending is not dropped silently either: it is logged once per distinct code (it may be a previous kernel's asynchronous fault).
+static inline void mms_note_pending_error(const char* where) {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return;
+    static std::atomic<int> last{0};
+    if (last.exchange((int)e) != (int)e)
+        fprintf(stderr, "mmsurv: note: HIP error '%s' was pending before the launch at %s (not raised by this launch)\n", hipGetErrorString(e), where);
+}
+#define MMS_STR2(x) #x
+#define MMS_STR(x) MMS_STR2(x)
+#define MMS_LAUNCH(...) do { mms_note_pending_error(__FILE__ ":" MMS_STR(__LINE__)); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
 static inline int mms_check_launch() {
     hipError_t e = hipGetLastError();

@@ -438,11 +438,8 @@ extern "C" int mms_conv3_fwd_group(const Conv3FwdP* pp, int ng, hipStream_t s) {
     if (!p.partial && conv3_mt_ok(p.M, ng, p.g)) {
         constexpr int smem_max = (C3M_TM + 2 * C3M_MAXHALO) * C3M_PITCH * (int)sizeof(float);
         int smem = (C3M_TM + 2 * (p.g.W + 1)) * C3M_PITCH * (int)sizeof(float);       // W = 8: 43 KB -> 3 workgroups per CU
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipFuncSetAttribute((const void*)conv3_fwd_mt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem_max);
-            attr_set = true;
-        }
+        static std::once_flag attr_once;
+        std::call_once(attr_once, [&] { hipFuncSetAttribute((const void*)conv3_fwd_mt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem_max); });
         Grp<Conv3FwdP> a;
         grp_fill(a, pp, ng, 1);
         MMS_LAUNCH(conv3_fwd_mt_kernel, dim3((p.M + C3M_TM - 1) / C3M_TM, 1, ng), dim3(256), smem, s, a);
@@ -825,11 +822,8 @@ extern "C" int mms_pack_conv3_table_group(const void* const* tables_dev, int ng,
     TabPtrs tp;
     for (int g = 0; g < ng; ++g) tp.t[g] = tables_dev[g];
     constexpr int smem = 32 * PACK_CO_STRIDE * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)pack_conv3_table_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_set = true;
-    }
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [&] { hipFuncSetAttribute((const void*)pack_conv3_table_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem); });
     MMS_LAUNCH(pack_conv3_table_kernel, dim3(4, nlayers, ng), dim3(256), smem, s, tp);
     return mms_check_launch();
 }

@@ -378,51 +378,84 @@ __global__ __launch_bounds__(256) void cox_lse_kernel(const Grp<CoxP> grp) {
     const CoxP& p = grp.p[blockIdx.z];
     const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= p.n) return;
-    if (!cox_valid(p, i)) { if (lane == 0) p.lse[i] = 0.f; return; }
+    if (!cox_valid(p, i)) { if (lane == 0) { p.lse[i] = 0.f; if (p.tie_mode == 1) p.tie_frac[i] = -1.f; } return; }
     const float ti = p.time[i];
     float mx = -INFINITY;
     for (int j = lane; j < p.n; j += 64)
         if (cox_valid(p, j) && p.time[j] >= ti) mx = fmaxf(mx, p.h[(size_t)j * p.ldh]);
     mx = wave_max(mx);
     float s = 0.f;
+    if (p.tie_mode != 1) {
+        for (int j = lane; j < p.n; j += 64)
+            if (cox_valid(p, j) && p.time[j] >= ti) s += expf(p.h[(size_t)j * p.ldh] - mx);
+        s = wave_sum(s);
+        if (lane == 0) p.lse[i] = mx + logf(s);
+        return;
+    }
+    // Efron (torchsurv _partial_likelihood_efron): the m events tied at t_i take the denominators D - (l/m) T, l = 0..m-1,
+    // D = sum over the risk set, T = sum over the tied events; event i takes l = its rank (by index) among them.
+    float st = 0.f, m = 0.f, l = 0.f;
     for (int j = lane; j < p.n; j += 64)
-        if (cox_valid(p, j) && p.time[j] >= ti) s += expf(p.h[(size_t)j * p.ldh] - mx);
-    s = wave_sum(s);
-    if (lane == 0) p.lse[i] = mx + logf(s);
+        if (cox_valid(p, j)) {
+            const float tj = p.time[j];
+            if (tj >= ti) {
+                const float e = expf(p.h[(size_t)j * p.ldh] - mx);
+                s += e;
+                if (tj == ti && p.event[j] != 0.f) { st += e; m += 1.f; l += j < i ? 1.f : 0.f; }
+            }
+        }
+    s = wave_sum(s); st = wave_sum(st); m = wave_sum(m); l = wave_sum(l);
+    if (lane == 0) {
+        const bool ev = p.event[i] != 0.f;
+        const float f = ev ? l / m : 0.f;            // (censored rows: lse unused)
+        p.lse[i] = mx + logf(s - f * st);
+        p.tie_frac[i] = ev ? f : -1.f;
+    }
 }
 
 __global__ __launch_bounds__(256) void cox_grad_kernel(const Grp<CoxP> grp) {
     const CoxP& p = grp.p[blockIdx.z];
     __shared__ float red[8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k = blockIdx.x * 4 + wave;
-    // batch counts (every block recomputes them: n is small)
-    float nv = 0.f, ne = 0.f, ls = 0.f;
+    const bool efron = p.tie_mode == 1;
+    // batch counts (every block recomputes them: n is small).  ne = events (Breslow / untied: mean over events);
+    // Efron: nd = distinct event times = events of tie rank 0 (torchsurv averages its per-time terms)
+    float nv = 0.f, ne = 0.f, ls = 0.f, nd = 0.f;
     for (int j = threadIdx.x; j < p.n; j += 256)
         if (cox_valid(p, j)) {
             nv += 1.f;
-            if (p.event[j] != 0.f) { ne += 1.f; ls += p.h[(size_t)j * p.ldh] - p.lse[j]; }
+            if (p.event[j] != 0.f) {
+                ne += 1.f; ls += p.h[(size_t)j * p.ldh] - p.lse[j];
+                if (efron && p.tie_frac[j] == 0.f) nd += 1.f;
+            }
         }
-    nv = wave_sum(nv); ne = wave_sum(ne); ls = wave_sum(ls);
+    nv = wave_sum(nv); ne = wave_sum(ne); ls = wave_sum(ls); nd = wave_sum(nd);
     if (lane == 0) { red[wave] = nv; red[4 + wave] = ne; }
     __syncthreads();
     nv = red[0] + red[1] + red[2] + red[3]; ne = red[4] + red[5] + red[6] + red[7];
     __syncthreads();
-    if (lane == 0) red[wave] = ls;
+    if (lane == 0) { red[wave] = ls; red[4 + wave] = nd; }
     __syncthreads();
-    ls = red[0] + red[1] + red[2] + red[3];
+    ls = red[0] + red[1] + red[2] + red[3]; nd = red[4] + red[5] + red[6] + red[7];
     const bool usable = nv >= 2.f && ne > 0.f;      // final_multimodal.py:173-176
+    const float denom = efron ? nd : ne + 1e-8f;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        p.out[0] = usable ? -ls / (ne + 1e-8f) : 0.f;
+        p.out[0] = usable ? -ls / denom : 0.f;
         p.out[1] = usable ? 1.f : 0.f;
     }
     if (k >= p.n || p.dh == nullptr) return;
     float gsum = 0.f;
     if (usable && cox_valid(p, k)) {
         const float tk = p.time[k], hk = p.h[(size_t)k * p.ldh];
+        const bool ek = p.event[k] != 0.f;
         for (int i = lane; i < p.n; i += 64)
-            if (cox_valid(p, i) && p.event[i] != 0.f && p.time[i] <= tk) gsum += expf(hk - p.lse[i]);
+            if (cox_valid(p, i) && p.event[i] != 0.f && p.time[i] <= tk) {
+                float w = 1.f;
+                if (efron && ek && p.time[i] == tk) w -= p.tie_frac[i];      // d/dh_k of D_i - f_i T_i
+                gsum += w * expf(hk - p.lse[i]);
+            }
         gsum = wave_sum(gsum);
-        if (lane == 0) p.dh[(size_t)k * p.lddh] = -p.scale * ((p.event[k] != 0.f ? 1.f : 0.f) - gsum) / (ne + 1e-8f);
+        if (lane == 0) p.dh[(size_t)k * p.lddh] = -p.scale * ((ek ? 1.f : 0.f) - gsum) / denom;
     } else if (lane == 0) {
         p.dh[(size_t)k * p.lddh] = 0.f;
     }
@@ -431,7 +464,8 @@ extern "C" int mms_cox_fwd_bwd_group(const CoxP* pp, int ng, hipStream_t s) {
     Grp<CoxP> a;
     if (!grp_fill(a, pp, ng, 1)) return MMS_ERR_ARG;
     const CoxP& p = *pp;
-    for (int g = 0; g < ng; ++g) if (pp[g].n != p.n || pp[g].n <= 0 || !pp[g].lse || !pp[g].out) return MMS_ERR_ARG;
+    for (int g = 0; g < ng; ++g)
+        if (pp[g].n != p.n || pp[g].n <= 0 || !pp[g].lse || !pp[g].out || pp[g].tie_mode < 0 || pp[g].tie_mode > 1 || (pp[g].tie_mode == 1 && !pp[g].tie_frac)) return MMS_ERR_ARG;
     MMS_LAUNCH(cox_lse_kernel, dim3((p.n + 3) / 4, 1, ng), dim3(256), 0, s, a);
     MMS_LAUNCH(cox_grad_kernel, dim3((p.n + 3) / 4, 1, ng), dim3(256), 0, s, a);
     return mms_check_launch();

@@ -527,11 +527,8 @@ extern "C" int mms_linear_big_fwd(const LinBigP* pp, hipStream_t s) {
     const char* e = getenv("MMS_LINBIG_WIDE");           // 0: GEMM-core form only (A/B measurements, tests)
     if (plain && xa && wa && p.M >= 256 && p.N >= 128 && p.K >= 512 && !(e && e[0] == '0')) {
         constexpr int smem = 2 * LFW_STAGE * (int)sizeof(float);             // 73.7 KB: 2 workgroups per CU
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipFuncSetAttribute((const void*)lin_fwd_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-            attr_set = true;
-        }
+        static std::once_flag attr_once;
+        std::call_once(attr_once, [&] { hipFuncSetAttribute((const void*)lin_fwd_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem); });
         int ks = 1;
         const int kc = lfw_kc(p, ks);
         MMS_LAUNCH(lin_zero_y_kernel, dim3((p.N + 255) / 256, (p.M + 63) / 64), dim3(256), 0, s, p);
@@ -553,11 +550,8 @@ extern "C" int mms_linear_big_bwd_w(const LinBigP* pp, hipStream_t s) {
     const char* e = getenv("MMS_LINBIG_WIDE");           // 0: GEMM-core form only (A/B measurements, tests)
     if (plain && x_aligned(p) && p.N >= 128 && p.K >= 128 && p.M >= 256 && !(e && e[0] == '0')) {
         constexpr int smem = 2 * LBW_STAGE * (int)sizeof(float);             // 67.6 KB: 2 workgroups per CU
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipFuncSetAttribute((const void*)lin_bwdw_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-            attr_set = true;
-        }
+        static std::once_flag attr_once;
+        std::call_once(attr_once, [&] { hipFuncSetAttribute((const void*)lin_bwdw_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem); });
         const int ms = lbw_msplit(p);
         MMS_LAUNCH(lin_bwdw_wide_kernel, dim3((p.N + 127) / 128, (p.K + 127) / 128, ms), dim3(256), smem, s, p, ms);
         return mms_check_launch();

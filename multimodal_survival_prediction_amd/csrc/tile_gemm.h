@@ -252,10 +252,9 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(const Grp<typename Op::P
 template <class Op>
 static inline int launch_tile_gemm(const typename Op::Params* pp, int ng, dim3 grid, hipStream_t s) {
     constexpr size_t smem = TileGemmCfg<Op>::smem_bytes();
-    static bool attr_set = false;
-    if (smem > 64 * 1024 && !attr_set) {
-        hipFuncSetAttribute((const void*)tile_gemm_kernel<Op>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
+    if (smem > 64 * 1024) {      // once per instantiation, safe under concurrent host threads (the ABI is documented re-entrant)
+        static std::once_flag attr_once;
+        std::call_once(attr_once, [] { hipFuncSetAttribute((const void*)tile_gemm_kernel<Op>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
     }
     if (grid.x == 0 || grid.y == 0 || grid.z == 0) return MMS_OK;
     Grp<typename Op::Params> a;

@@ -64,8 +64,9 @@ def head_program(model):
             _Lin(f[4], ("f1", 0), ("f2", 0), True, pro_bn=f[1], pro_drop=f[3]),
             _Lin(f[7], ("f2", 0), ("hz", 0), False, pro_drop=f[6]),
         ]
-        bufs = dict(rna=r[0].in_features, r1=1024, r2=512, feats=384, f1=256, f2=128, hz=1)
-        return dict(kind=kind, width=384, ct_cols=256, lins=lins, gate=None, bufs=bufs, encoder=model.image_encoder,
+        rd = r[8].out_features                      # rna_feature_dim (simple_fusion.py:163); the encoder's 128 columns follow
+        bufs = dict(rna=r[0].in_features, r1=1024, r2=512, feats=rd + 128, f1=256, f2=128, hz=1)
+        return dict(kind=kind, width=rd + 128, ct_cols=rd, lins=lins, gate=None, bufs=bufs, encoder=model.image_encoder,
                     n_pre=3)
     if kind == "FlexibleMultimodalModel":      # flexible_multimodal.py:157-256: simple-fusion heads, [image | rna] order, missing bias
         r, f = model.rna_encoder, model.fusion
@@ -77,9 +78,10 @@ def head_program(model):
             _Lin(f[4], ("f1", 0), ("f2", 0), True, pro_bn=f[1], pro_drop=f[3]),
             _Lin(f[7], ("f2", 0), ("hz", 0), False, pro_drop=f[6]),
         ]
-        bufs = dict(rna=r[0].in_features, r1=1024, r2=512, feats=384, f1=256, f2=128, hz=1)
-        return dict(kind=kind, width=384, ct_cols=0, lins=lins, gate=None, bufs=bufs, encoder=model.image_encoder, n_pre=3,
-                    mix=dict(biases=[model.missing_image_bias, model.missing_rna_bias], segs=[(0, 128), (128, 256)]))
+        rd = r[8].out_features
+        bufs = dict(rna=r[0].in_features, r1=1024, r2=512, feats=128 + rd, f1=256, f2=128, hz=1)
+        return dict(kind=kind, width=128 + rd, ct_cols=0, lins=lins, gate=None, bufs=bufs, encoder=model.image_encoder, n_pre=3,
+                    mix=dict(biases=[model.missing_image_bias, model.missing_rna_bias], segs=[(0, 128), (128, rd)]))
     if kind == "RNASeqSurvivalModel":          # train_rnaseq_only.py:126-151: [Linear, BN1d, ReLU, Dropout] x n + Linear(., 1)
         mods = list(model.mlp)
         lin_idx = [i for i, m in enumerate(mods) if isinstance(m, nn.Linear)]
@@ -105,7 +107,7 @@ class _Plan:
 
 class SurvivalEngine:
     def __init__(self, model, adamw=None, lr=1e-4, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0,
-                 gate_entropy_weight=0.01, _slots=None):
+                 gate_entropy_weight=0.01, cox_ties=None, _slots=None):
         """_slots (used by FoldGroupEngine): dict(gflat=[n] fp32, sumsq=[1] fp64, entropy=[1] fp32) views of group-wide
         buffers, so the per-step zeroing of a whole fold group is three memsets."""
         self.lib = _lib.load_library()
@@ -129,6 +131,8 @@ class SurvivalEngine:
         self.step_count = torch.zeros(1, device=self.device)
         self.rng = torch.tensor([0x5EED, 0], dtype=torch.int32, device=self.device)
         self.ent_weight = gate_entropy_weight
+        from . import losses
+        self.tie_mode = ops.TIE_MODES[cox_ties or losses.default_ties()]    # CoxP.tie_mode of the fused step's loss
         self.side_stream = torch.cuda.Stream(device=self.device)
         self.ev_fork, self.ev_join = torch.cuda.Event(), torch.cuda.Event()
         self.ev_fork.record(); self.ev_join.record()          # materialise the handles
@@ -201,6 +205,7 @@ class SurvivalEngine:
         P.valid = torch.ones(B, device=dev)
         P.cox_out = torch.zeros(2, device=dev)
         P.lse = torch.zeros(B, device=dev)
+        P.tie_frac = torch.zeros(B, device=dev)
         # encoder: DenseNet121-3D (MONAI topology) or the reference's 3-conv fallback
         enc = prog["encoder"]
         gmap = {id(p): g for p, g in zip(self.params, self.gviews)}
@@ -271,7 +276,7 @@ class SurvivalEngine:
             P.mix = M
         hz = P.buf["hz"]
         P.cox = _S()["CoxP"](hz.data_ptr(), 1, P.time.data_ptr(), P.event.data_ptr(), P.valid.data_ptr(), B, 1.0,
-                             P.lse.data_ptr(), P.dbuf["hz"].data_ptr(), 1, P.cox_out.data_ptr())
+                             P.lse.data_ptr(), P.dbuf["hz"].data_ptr(), 1, P.cox_out.data_ptr(), self.tie_mode, P.tie_frac.data_ptr())
         book = dict(acc=self.acc, cox_out=P.cox_out, entropy=self.entropy, rng=self.rng)   # per-step bookkeeping, in-kernel
         P.adam = ops.adam_params(self.flat, self.gflat, self.m, self.v, self.hyper, self.sumsq, self.step_count,
                                  None, self.adamw, **book)
@@ -416,9 +421,10 @@ class SurvivalEngine:
         if getattr(P, "gcox", None) is None or P.gcox["world"] != world:
             n, dev = world * P.B, self.device
             G = dict(world=world, h=torch.zeros(n, device=dev), time=torch.zeros(n, device=dev), event=torch.zeros(n, device=dev),
-                     valid=torch.ones(n, device=dev), lse=torch.zeros(n, device=dev), dh=torch.zeros(n, device=dev), rank=0)
+                     valid=torch.ones(n, device=dev), lse=torch.zeros(n, device=dev), dh=torch.zeros(n, device=dev), rank=0,
+                     frac=torch.zeros(n, device=dev))
             G["cox"] = _S()["CoxP"](G["h"].data_ptr(), 1, G["time"].data_ptr(), G["event"].data_ptr(), G["valid"].data_ptr(), n, 1.0,
-                                    G["lse"].data_ptr(), G["dh"].data_ptr(), 1, P.cox_out.data_ptr())
+                                    G["lse"].data_ptr(), G["dh"].data_ptr(), 1, P.cox_out.data_ptr(), self.tie_mode, G["frac"].data_ptr())
             P.gcox = G
         return P.gcox
 

@@ -123,8 +123,8 @@ class PartialModalityNet(nn.Module):
 class SimpleFusionModel(nn.Module):
     def __init__(self, rna_dim=5005, img_feature_dim=128, rna_feature_dim=256):
         super().__init__()
-        if img_feature_dim != 128 or rna_feature_dim != 256:
-            raise ValueError("kernel widths are fixed to the reference defaults (img 128, rna 256)")
+        if img_feature_dim != 128:       # rna_feature_dim is free (simple_fusion.py:163); the DenseNet121 driver's class_layers.out is 1024 -> 128
+            raise ValueError("img_feature_dim must be 128 (the reference default): the DenseNet121-3D driver writes a 128-wide feature")
         self.rna_encoder = nn.Sequential(
             nn.Linear(rna_dim, 1024), nn.BatchNorm1d(1024), nn.ReLU(), nn.Dropout(0.3),
             nn.Linear(1024, 512), nn.BatchNorm1d(512), nn.ReLU(), nn.Dropout(0.3),
@@ -148,8 +148,8 @@ class FlexibleMultimodalModel(nn.Module):
 
     def __init__(self, rna_dim=5005, img_feature_dim=128, rna_feature_dim=256):
         super().__init__()
-        if img_feature_dim != 128 or rna_feature_dim != 256:
-            raise ValueError("kernel widths are fixed to the reference defaults (img 128, rna 256)")
+        if img_feature_dim != 128:       # rna_feature_dim is free (simple_fusion.py:163); the DenseNet121 driver's class_layers.out is 1024 -> 128
+            raise ValueError("img_feature_dim must be 128 (the reference default): the DenseNet121-3D driver writes a 128-wide feature")
         self.image_encoder = _ct_encoder(img_feature_dim)
         self.use_monai = USE_MONAI
         if USE_MONAI:

@@ -173,13 +173,18 @@ def gate_params(feats, mask, w1, b1, w2, b2, hidden, gate, fused, dfused=None, e
                          ptr(dw2), ptr(db2), ptr(entropy))
 
 
-def cox_fwd_bwd(h, time, event, valid=None, scale=1.0, want_grad=True):
-    """h: [n] or [n,1] fp32 on device -> (out[2] = {loss, usable}, dh or None)."""
+TIE_MODES = {"breslow": 0, "efron": 1}
+
+
+def cox_fwd_bwd(h, time, event, valid=None, scale=1.0, want_grad=True, ties="breslow"):
+    """h: [n] or [n,1] fp32 on device -> (out[2] = {loss, usable}, dh or None).  ties: CoxP.tie_mode (include/mmsurv.h)."""
     n = h.shape[0]
     lse = torch.empty(n, device=h.device)
     out = torch.empty(2, device=h.device)
     dh = torch.empty(n, device=h.device) if want_grad else None
-    p = _S()["CoxP"](ptr(h), h.stride(0), ptr(time), ptr(event), ptr(valid), n, float(scale), ptr(lse), ptr(dh), 1, ptr(out))
+    frac = torch.empty(n, device=h.device) if TIE_MODES[ties] == 1 else None
+    p = _S()["CoxP"](ptr(h), h.stride(0), ptr(time), ptr(event), ptr(valid), n, float(scale), ptr(lse), ptr(dh), 1, ptr(out),
+                     TIE_MODES[ties], ptr(frac))
     call("mms_cox_fwd_bwd", p)
     return out, dh
 

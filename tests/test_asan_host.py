@@ -1,0 +1,117 @@
+"""CPU only: AddressSanitizer build of the HOST side of libmmsurv_hip (argument validation, workspace planning, parameter-block
+assembly of the network drivers) exercised through the C ABI in a child process ("-fsanitize=address host
+builds of the C++ extension").  Device code is not instrumented (-fno-gpu-sanitize; GPU ASan is unavailable on this pool) and no
+kernel runs: without a GPU the first launch of a driver fails cleanly, which is part of what is checked (error code, no crash)."""
+import glob
+import os
+import subprocess
+import sys
+import textwrap
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "multimodal_survival_prediction_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+OUT = os.path.join(os.environ.get("TMPDIR", "/tmp"), "mmsurv_asan_build")
+
+
+def _asan_runtime():
+    c = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
+    return c[0] if c else None
+
+
+def _build():
+    os.makedirs(OUT, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(ROOT, "include", "mmsurv.h")]
+    lib = os.path.join(OUT, "libmmsurv_hip_asan.so")
+    if os.path.exists(lib) and all(os.path.getmtime(d) <= os.path.getmtime(lib) for d in deps):
+        return lib
+    flags = ["-O1", "-g", "--offload-arch=gfx950", "-fsanitize=address", "-fno-gpu-sanitize", "-shared-libsan", "-munsafe-fp-atomics",
+             "-fPIC", "-std=c++17", "-Wno-unused-value", "-Wno-comment"]
+
+    def cc(src):
+        obj = os.path.join(OUT, os.path.basename(src)[:-4] + ".o")
+        r = subprocess.run([HIPCC] + flags + ["-c", src, "-o", obj], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return obj
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        objs = list(ex.map(cc, srcs))
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-fsanitize=address", "-fno-gpu-sanitize", "-shared-libsan", "-shared", "-fPIC",
+                        "-o", lib] + objs, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return lib
+
+
+CHILD = textwrap.dedent('''
+    import ctypes, re, sys
+    lib = ctypes.CDLL(sys.argv[1])
+    hdr = open(sys.argv[2]).read()
+    # 1. ABI self-description for every struct of the header
+    names = re.findall(r"typedef\\s+struct\\s+(\\w+)\\s*\\{", hdr)
+    assert len(names) > 20
+    for n in names:
+        assert lib.mms_abi_sizeof(n.encode()) > 0, n
+    assert lib.mms_abi_sizeof(b"Nope") == -1
+    # 2. workspace planning: valid shapes, every invalid-shape exit
+    nb = ctypes.c_size_t(0)
+    f = lib.mms_dn121_workspace_bytes
+    f.argtypes = [ctypes.c_int] * 4 + [ctypes.POINTER(ctypes.c_size_t)]
+    for B, D, H, W in ((1, 32, 32, 32), (4, 64, 64, 32), (2, 128, 128, 64), (16, 32, 64, 96)):
+        assert f(B, D, H, W, ctypes.byref(nb)) == 0 and nb.value > 0
+    for B, D, H, W in ((0, 64, 64, 32), (4, 16, 64, 32), (4, 64, 63, 32), (4, 64, 64, 4096), (-1, 32, 32, 32)):
+        assert f(B, D, H, W, ctypes.byref(nb)) == -1
+    assert f(4, 64, 64, 32, None) == -1
+    g = lib.mms_dn121_region
+    g.argtypes = [ctypes.c_int] * 4 + [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+    off = ctypes.c_size_t(0)
+    for name, idx, ok in ((b"y0", 0, 0), (b"slab", 3, 0), (b"slab", 4, -1), (b"y1", 57, 0), (b"y1", 58, -1), (b"stats", 0, 0), (b"bogus", 0, -1)):
+        assert g(4, 64, 64, 32, name, idx, ctypes.byref(off), ctypes.byref(nb)) == ok, name
+    # 3. network drivers: argument validation, then (no GPU here) a clean launch failure -- never a crash or an ASan report
+    VP = ctypes.c_void_p
+    host = (ctypes.c_char * (1 << 20))()          # fake "device" memory: the host side only does pointer arithmetic on it
+    base = ctypes.addressof(host)
+    ptab = (VP * 364)(*[base] * 364)
+    btab = (VP * 363)(*[base] * 363)
+    fw = lib.mms_dn121_forward
+    fw.argtypes = [VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, VP, VP, VP, VP, ctypes.c_int, ctypes.c_int, VP]
+    assert fw(None, 4, 64, 64, 32, base, ptab, btab, base, 288, 1, None) == -1
+    assert fw(base, 4, 64, 64, 31, base, ptab, btab, base, 288, 1, None) == -1
+    rc = fw(base, 4, 64, 64, 32, base, ptab, btab, base, 288, 1, None)
+    assert rc in (0, -2), rc
+    bw = lib.mms_dn121_backward
+    bw.argtypes = [VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, VP, VP, VP, ctypes.c_int, VP, VP]
+    assert bw(base, 4, 64, 64, 32, base, ptab, None, 288, ptab, None) == -1
+    rc = bw(base, 4, 64, 64, 32, base, ptab, base, 288, ptab, None)
+    assert rc in (0, -2), rc
+    fg = lib.mms_dn121_forward_group
+    fg.argtypes = [ctypes.c_int, VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, VP, VP, VP, VP, ctypes.c_int, ctypes.c_int, VP]
+    for ng in (0, 11):
+        assert fg(ng, None, 4, 64, 64, 32, None, None, None, None, 288, 1, None) == -1
+    wsv = (VP * 10)(*[base] * 10)
+    pv = (VP * 10)(*[ctypes.addressof(ptab)] * 10)
+    bv = (VP * 10)(*[ctypes.addressof(btab)] * 10)
+    rc = fg(10, wsv, 4, 64, 64, 32, wsv, pv, bv, wsv, 288, 1, None)
+    assert rc in (0, -2), rc
+    # 4. small-op launchers: null / inconsistent parameter blocks
+    for name in ("mms_cox_fwd_bwd_group", "mms_gate_fwd_group", "mms_linear_fwd_group", "mms_clip_adam_group", "mms_conv3_fwd_group"):
+        fn = getattr(lib, name)
+        fn.argtypes = [VP, ctypes.c_int, VP]
+        assert fn(base, 0, None) == -1, name
+        assert fn(base, 11, None) == -1, name
+    print("ASAN_CHILD_OK")
+''')
+
+
+def test_host_side_under_address_sanitizer():
+    rt = _asan_runtime()
+    if rt is None or not os.path.exists(HIPCC):
+        pytest.skip("no ASan runtime / hipcc in this image")
+    lib = _build()
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:halt_on_error=1:verify_asan_link_order=0")
+    r = subprocess.run([sys.executable, "-c", CHILD, lib, os.path.join(ROOT, "include", "mmsurv.h")], capture_output=True, text=True,
+                       env=env, timeout=600)
+    assert "ERROR: AddressSanitizer" not in r.stderr, r.stderr[-4000:]
+    assert r.returncode == 0 and "ASAN_CHILD_OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])

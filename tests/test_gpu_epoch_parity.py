@@ -1,0 +1,216 @@
+"""Epoch-level parity: the HIP `train_epoch_*` / `validate_*` functions -- fused-graph steps,
+device-side loss accumulation, skip rules, denominators -- against the CPU oracle's restatement of the reference loops
+(oracle/loops.py: final_multimodal.py:238-305, partial_modality_training.py:382-485, simple_fusion.py:242-333) on ONE short epoch of
+a cohort that contains every special case of those loops:
+  batch 0  all labelled, events present                       -> ordinary step
+  batch 1  all labelled, NO event                             -> final: zero loss without graph, no update; partial: entropy-only
+                                                                 step, not counted in the Cox mean; simple: forward runs (BatchNorm
+                                                                 running statistics move), then `continue`
+  batch 2  ONE labelled patient + 3 unlabelled                -> partial: entropy-only step; simple: skipped BEFORE the forward
+  batch 3  2 labelled (1 event) + 2 unlabelled                -> Cox on the labelled subset only
+  batch 4  all labelled
+  batch 5  ragged tail of 2 patients
+Dropout is off (its RNG cannot be matched); DenseNet121-3D encoder on the headline 64x64x32 volumes.
+
+Two variants per style.  lr = 0 ("frozen weights"): everything but the weight update runs -- per-batch losses, skip rules,
+denominators, BatchNorm running statistics, validation loss, C-index, held-out hazards -- and must agree at the north_star
+tolerance 1e-4.  lr = 1e-4 (the scripts' value): after ONE Adam step the two fp32 implementations' weights differ by up to 2 lr
+wherever a gradient entry is within rounding of zero (Adam's first steps are lr * sign(g)), which moves the next batch's hazards
+by ~1e-3 and the fifth batch's by ~1e-2 (measured; the CPU oracle against its own fp64 run behaves the same), so that variant
+checks the exact counts and the returned means at 3e-2 -- enough to catch a wrong denominator or skip rule (>= 17 % here); the
+update arithmetic itself is pinned at step level in tests/test_gpu_models.py and tests/test_gpu_heads.py.
+Config 1 of BASELINE.json (simple_fusion, 88 complete patients, CT encoder input stubbed to zeros) runs once at the end."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import DEV, assert_close
+from test_gpu_densenet import structured_volumes
+
+import os as _os
+DIMS, RNA = tuple(int(v) for v in _os.environ.get("MMS_TEST_DIMS", "64,64,32").split(",")), 96
+
+
+def _cohort(n_extra_val=10, seed=5):
+    """22 training patients laid out as the six batches above + a validation split with an unlabelled patient, a batch without
+    events and a single-labelled batch."""
+    rng = np.random.default_rng(seed)
+    n = 22 + n_extra_val
+    img = structured_volumes(n, DIMS, seed).reshape(n, 1, *DIMS)
+    rna = rng.normal(0, 1, (n, RNA)).astype(np.float32)
+    age = (np.clip(rng.normal(60, 11, n), 30, 90) / 100).astype(np.float32)
+    time = (rng.exponential(1000, n) + 1 + np.arange(n) * 1e-2).astype(np.float32)
+    event = (rng.random(n) < 0.6).astype(np.float32)
+    has = np.ones(n, bool)
+    event[0], event[3] = 1, 0                     # batch 0: events and a censored patient
+    event[4:8] = 0                                # batch 1: no event
+    has[9:12] = False; event[8] = 1               # batch 2: one labelled patient
+    has[14:16] = False; event[12], event[13] = 1, 0   # batch 3
+    event[16] = 1                                 # batch 4
+    event[20], event[21] = 1, 0                   # tail
+    v = 22                                        # validation: batch A ordinary, batch B no event, batch C one labelled + tail
+    event[v] = 1
+    event[v + 4:v + 8] = 0
+    has[v + 8] = False
+    event[v + 9] = 1
+    mask = np.ones((n, 3), np.float32)
+    mask[1, 0] = 0; mask[5, 1] = 0; mask[10, 0] = 0; mask[13, 2] = 0; mask[17, 0] = 0; mask[v + 1, 0] = 0
+    img[mask[:, 0] == 0] = 0.0
+    rna[mask[:, 1] == 0] = 0.0
+    clin = age * mask[:, 2]
+    time = np.where(has, time, 0.0).astype(np.float32)
+    event = np.where(has, event, 0.0).astype(np.float32)
+    return dict(image=img.contiguous(), rnaseq=torch.tensor(rna), clinical=torch.tensor(clin).view(n, 1),
+                label=torch.tensor(np.stack([time, event], 1)), mask=torch.tensor(mask), has_survival=torch.tensor(has), n=n, dims=DIMS)
+
+
+def _pair(cls, seed):
+    from oracle import models as OM
+    from multimodal_survival_prediction_amd import models as HM
+    torch.manual_seed(seed)
+    ref = getattr(OM, cls)(rna_dim=RNA, use_monai=True)
+    for m in ref.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    net = getattr(HM, cls)(rna_dim=RNA)
+    net.load_state_dict(ref.state_dict())
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    return ref, net.to(DEV)
+
+
+def _loaders(cohort, style, dev_cohort):
+    from multimodal_survival_prediction_amd import data
+    tr, va = np.arange(22), np.arange(22, cohort["n"])
+    mk = lambda c, idx: data.BatchLoader(c, idx, 4, shuffle=False, style=style)
+    return mk(cohort, tr), mk(cohort, va), mk(dev_cohort, tr), mk(dev_cohort, va)
+
+
+def _check_buffers(ref, net, tol=2e-3):
+    for (k, b), (_, c) in zip(ref.named_buffers(), net.named_buffers()):
+        if "num_batches" in k:
+            assert int(b) == int(c), (k, int(b), int(c))       # counts the training-mode forwards (simple_fusion's second skip keeps one)
+        else:
+            assert_close(c, b, tol, k)
+
+
+STYLES = {
+    "final": ("MultiModalSurvivalNet", False, 1e-4),
+    "partial": ("PartialModalityNet", False, 1e-4),
+    "simple": ("SimpleFusionModel", True, 1e-3),
+}
+
+
+@pytest.mark.parametrize("lr", [0.0, 1e-4])
+@pytest.mark.parametrize("style", ["final", "partial", "simple"])
+def test_epoch_and_validate_match_oracle_loops(style, lr):
+    from oracle import loops as OLP
+    from multimodal_survival_prediction_amd import data, training
+    from multimodal_survival_prediction_amd.training import FusedOptimizer
+    cls, adamw, wd = STYLES[style]
+    cohort = _cohort()
+    if style == "final":                          # final_multimodal.py trains on complete, fully labelled patients
+        cohort["has_survival"][:] = True
+        lab = cohort["label"]
+        lab[lab[:, 0] == 0, 0] = torch.arange(1, 1 + int((lab[:, 0] == 0).sum()), dtype=torch.float32) * 7.5
+    dev_cohort = data.cohort_to(cohort, DEV)
+    ref, net = _pair(cls, 11)
+    tr_c, va_c, tr_d, va_d = _loaders(cohort, style, dev_cohort)
+    opt_ref = (torch.optim.AdamW(ref.parameters(), lr=lr, weight_decay=wd) if adamw
+               else torch.optim.Adam(ref.parameters(), lr=lr, weight_decay=wd))
+    fo = FusedOptimizer(net, lr=lr, weight_decay=wd, adamw=adamw)
+    cpu = torch.device("cpu")
+    tol = 1e-4 if lr == 0 else 3e-2
+    want = getattr(OLP, "train_epoch_" + style)(ref, tr_c, opt_ref, cpu)
+    got = getattr(training, "train_epoch_" + style)(net, tr_d, fo, DEV)
+    st = fo.engine.epoch_stats()
+    print(style, "train_epoch oracle", want, "hip", got, st)
+    if style == "final":
+        # :249-262: every batch counts in the mean, the no-event batch with loss 0 (and no update)
+        assert st["n_batches"] == 6 and st["n_usable"] == 5
+        assert got == pytest.approx(want, rel=tol)
+    elif style == "partial":
+        # :401-428: 4 of 6 batches are Cox-usable (denominator n_usable); the entropy mean runs over all 6
+        assert st["n_batches"] == 6 and st["n_usable"] == 4
+        assert got[0] == pytest.approx(want[0], rel=tol) and got[1] == pytest.approx(want[1], rel=tol)
+    else:
+        # :257-268: batch 2 never reaches the engine, batch 1 runs the forward only
+        assert st["n_batches"] == 5 and st["n_usable"] == 4
+        assert got == pytest.approx(want, rel=tol)
+    _check_buffers(ref, net, 1e-4 if lr == 0 else 6e-2)
+    if lr != 0:
+        return
+    # validate: (avg_loss, c_index) with the reference's inclusion rules
+    vw = getattr(OLP, "validate_" + style)(ref, va_c, cpu)
+    vg = getattr(training, "validate_" + style)(net, va_d, DEV)
+    print(style, "validate oracle", vw, "hip", vg)
+    assert vg[0] == pytest.approx(vw[0], rel=1e-4)
+    assert abs(vg[1] - vw[1]) <= 1e-6                 # identical pair counts (ConcordanceIndex returns an fp32 tensor)
+    # hazards of the held-out patients after the epoch (running statistics of six training forwards)
+    ref.eval(); net.eval()
+    j = torch.arange(22, 26)
+    with torch.no_grad():
+        if style == "final":
+            w = ref(cohort["image"][j], cohort["rnaseq"][j], cohort["clinical"][j])
+            g = net(dev_cohort["image"][j], dev_cohort["rnaseq"][j], dev_cohort["clinical"][j])
+        elif style == "partial":
+            w = ref(cohort["image"][j], cohort["rnaseq"][j], cohort["clinical"][j], cohort["mask"][j])[0]
+            g = net(dev_cohort["image"][j], dev_cohort["rnaseq"][j], dev_cohort["clinical"][j], dev_cohort["mask"][j])[0]
+        else:
+            w = ref(cohort["image"][j], cohort["rnaseq"][j])
+            g = net(dev_cohort["image"][j], dev_cohort["rnaseq"][j])
+    assert_close(g, w, 1e-4, "held-out hazards after one epoch")
+
+
+@pytest.mark.parametrize("lr", [0.0, 1e-4])
+def test_lockstep_epoch_matches_oracle_loops(lr):
+    """The path the entry points and bench.py run: train_epoch_lockstep / validate_lockstep of a FoldGroupEngine (two fold models,
+    lazily named batches gathered on the GPU) -- each fold against the oracle's train_epoch_partial / validate_partial."""
+    from oracle import loops as OLP
+    from multimodal_survival_prediction_amd import data, training
+    from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
+    cohort = _cohort()
+    dev_cohort = data.cohort_to(cohort, DEV)
+    pairs = [_pair("PartialModalityNet", 21), _pair("PartialModalityNet", 22)]
+    splits = [np.arange(22), np.concatenate([np.arange(4, 22), np.arange(0, 2)])]       # second fold: other batches, no ragged tail
+    group = FoldGroupEngine([p[1] for p in pairs], lr=lr, weight_decay=1e-4, adamw=False, gate_entropy_weight=0.01)
+    tl = [data.BatchLoader(dev_cohort, s, 4, shuffle=False, lazy=True, with_valid=True) for s in splits]
+    vl = [data.BatchLoader(dev_cohort, np.arange(22, cohort["n"]), 4, shuffle=False) for _ in splits]
+    got = training.train_epoch_lockstep(group, tl, "partial")
+    vgot = training.validate_lockstep(group, vl, "partial", DEV)
+    for f, ((ref, net), s) in enumerate(zip(pairs, splits)):
+        opt = torch.optim.Adam(ref.parameters(), lr=lr, weight_decay=1e-4)
+        tol = 1e-4 if lr == 0 else 3e-2
+        want = OLP.train_epoch_partial(ref, data.BatchLoader(cohort, s, 4, shuffle=False), opt, torch.device("cpu"))
+        vwant = OLP.validate_partial(ref, data.BatchLoader(cohort, np.arange(22, cohort["n"]), 4, shuffle=False), torch.device("cpu"))
+        print("fold", f, "oracle", want, vwant, "hip", got[f], vgot[f])
+        assert got[f][0] == pytest.approx(want[0], rel=tol) and got[f][1] == pytest.approx(want[1], rel=tol)
+        _check_buffers(ref, net, 1e-4 if lr == 0 else 6e-2)
+        if lr == 0:
+            assert vgot[f][0] == pytest.approx(vwant[0], rel=1e-4) and abs(vgot[f][1] - vwant[1]) <= 1e-6
+
+
+def test_config1_simple_fusion_ct_stubbed():
+    """BASELINE config 1: simple_fusion.py, 88 synthetic complete patients, CT encoder input stubbed to zero volumes (RNA-seq heads do
+    the work), batch 4, fold 1 of 3: one epoch of the HIP train_epoch + validate against the oracle loops (dropout off)."""
+    from oracle import loops as OLP
+    from multimodal_survival_prediction_amd import data, training
+    from multimodal_survival_prediction_amd.training import FusedOptimizer
+    cohort = data.make_cohort(n=88, dims=DIMS, rna_dim=RNA, seed=88, complete=True)
+    cohort["image"].zero_()
+    dev_cohort = data.cohort_to(cohort, DEV)
+    tr, va = data.kfold_indices(88, 3, seed=42)[0]
+    ref, net = _pair("SimpleFusionModel", 31)
+    opt = torch.optim.AdamW(ref.parameters(), lr=1e-4, weight_decay=1e-3)
+    fo = FusedOptimizer(net, lr=1e-4, weight_decay=1e-3, adamw=True)
+    mk = lambda c, idx: data.BatchLoader(c, idx, 4, shuffle=False, style="simple")
+    want = OLP.train_epoch_simple(ref, mk(cohort, tr), opt, torch.device("cpu"))
+    got = training.train_epoch_simple(net, mk(dev_cohort, tr), fo, DEV)
+    vw = OLP.validate_simple(ref, mk(cohort, va), torch.device("cpu"))
+    vg = training.validate_simple(net, mk(dev_cohort, va), DEV)
+    print("config 1: train", want, got, "validate", vw, vg)
+    assert got == pytest.approx(want, rel=3e-2)
+    assert vg[0] == pytest.approx(vw[0], rel=3e-2) and abs(vg[1] - vw[1]) <= 0.05

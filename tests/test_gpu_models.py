@@ -192,3 +192,96 @@ def test_config4_volume_shape_parity():
     # 1.6e-4; global L2 1.1e-3, worst tensor 3.3e-2, heads 1.2e-5)
     assert hmax <= 1e-4, hmax
     assert p10 <= 5e-4 and mx <= 0.15 and l2 <= 1e-2
+
+
+def _per_tensor_err(ref_named, got_named):
+    """{name: max-abs error relative to the reference tensor's max} over tensors with a non-negligible exact gradient."""
+    gmax = max(float(g.abs().max()) for g in ref_named.values())
+    out = {}
+    for k, a in ref_named.items():
+        if float(a.abs().max()) < 1e-5 * gmax:
+            continue
+        out[k] = float((got_named[k].double() - a.double()).abs().max() / a.double().abs().max())
+    return out
+
+
+def test_gradient_error_vs_fp64_is_fp32_rounding():
+    """Evidence for the loose network-level gradient bounds above: the SAME batch through (a) the oracle in
+    fp64, (b) the oracle in fp32, (c) the HIP path, for two model classes.  Taking fp64 as exact, the HIP path's per-tensor gradient
+    errors must lie inside the envelope of the fp32 CPU oracle's OWN errors: both are fp32 implementations that differ from exact
+    arithmetic by rounding and by the handful of ReLU inputs that sit within rounding of zero.  Which implementation draws an
+    early-block flip on a given batch is a lottery (measured: MultiModalSurvivalNet -- oracle median 3.2e-3 / HIP 1.0e-3;
+    PartialModalityNet -- oracle 1.2e-5 / HIP 3.9e-3), so the envelope is taken over the cases, with a factor 2."""
+    from oracle import losses as OL
+    from multimodal_survival_prediction_amd import losses as HL
+    B, dims, rna_dim = 4, (64, 64, 32), 5005
+    rows = []
+    for cls in ("MultiModalSurvivalNet", "PartialModalityNet"):
+        ref, net = _pair(cls, 3, rna_dim)
+        ct, rna, clin, t, e, mask = _batch(B, dims, rna_dim, 9)
+        ref64 = copy.deepcopy(ref).double()
+        d = lambda x: x.to(DEV)
+
+        def run(model, cast):
+            model.train()
+            args = (cast(ct), cast(rna), cast(clin)) + ((cast(mask),) if cls == "PartialModalityNet" else ())
+            out = model(*args)
+            if cls == "PartialModalityNet":
+                loss = OL.cox_loss(out[0], cast(e), cast(t)) + 0.01 * OL.gate_entropy_loss(out[1])
+            else:
+                loss = OL.cox_loss(out, cast(e), cast(t))
+            loss.backward()
+            return {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+        g64 = run(ref64, lambda x: x.double())
+        g32 = run(ref, lambda x: x)
+        net.train()
+        args = (d(ct), d(rna), d(clin)) + ((d(mask),) if cls == "PartialModalityNet" else ())
+        out = net(*args)
+        lg = (HL.cox_loss(out[0], d(e), d(t)) + 0.01 * HL.gate_entropy_loss(out[1])) if cls == "PartialModalityNet" else HL.cox_loss(out, d(e), d(t))
+        lg.backward()
+        torch.cuda.synchronize()
+        ghip = {k: p.grad.detach().cpu() for k, p in net.named_parameters()}
+        e32, ehip = _per_tensor_err(g64, g32), _per_tensor_err(g64, ghip)
+        keys = sorted(e32)
+        a32, ah = np.array([e32[k] for k in keys]), np.array([ehip[k] for k in keys])
+        l2 = lambda g: (sum(float(((g[k].double() - g64[k]) ** 2).sum()) for k in g64) / sum(float((g64[k] ** 2).sum()) for k in g64)) ** 0.5
+        heads = [k for k in keys if "encoder.features" not in k and "encoder.class_layers" not in k]
+        rows.append(dict(cls=cls, med32=np.median(a32), max32=a32.max(), l232=l2(g32), medh=np.median(ah), maxh=ah.max(), l2h=l2(ghip),
+                         headh=max(ehip[k] for k in heads), head32=max(e32[k] for k in heads)))
+        print(f"{cls}: vs fp64 -- fp32 oracle: median {rows[-1]['med32']:.2e} max {rows[-1]['max32']:.2e} L2 {rows[-1]['l232']:.2e} heads {rows[-1]['head32']:.2e}"
+              f" | HIP: median {rows[-1]['medh']:.2e} max {rows[-1]['maxh']:.2e} L2 {rows[-1]['l2h']:.2e} heads {rows[-1]['headh']:.2e}")
+    env = {k: max(r[k] for r in rows) for k in ("med32", "max32", "l232")}
+    for r in rows:
+        assert r["medh"] <= 2 * env["med32"] + 1e-5, r
+        assert r["maxh"] <= 2 * env["max32"] + 1e-5, r
+        assert r["l2h"] <= 2 * env["l232"] + 1e-5, r
+        assert r["headh"] <= 1e-4, r          # no encoder ReLU on the heads' gradient path: strict
+
+
+def test_run_twice_spread():
+    """Determinism (SURVEY.md section 5 "run twice, compare"): the weight gradients are accumulated with fp32 atomics and the
+    BatchNorm statistics with fp64 atomics, so the summation order is not fixed and two runs are NOT bit-identical; this test
+    quantifies the spread: same weights, same batch, two fresh engines -> hazards within 1e-6, every gradient tensor within 1e-4
+    of its maximum (measured: worst tensor 1.1e-6, 338 of 364+ tensors bit-identical)."""
+    from multimodal_survival_prediction_amd import losses as HL
+    B, dims, rna_dim = 4, (64, 64, 32), 5005
+    ct, rna, clin, t, e, mask = _batch(B, dims, rna_dim, 9)
+    d = lambda x: x.to(DEV)
+    runs = []
+    for _ in range(2):
+        _, net = _pair("MultiModalSurvivalNet", 3, rna_dim)
+        net.train()
+        hz = net(d(ct), d(rna), d(clin))
+        HL.cox_loss(hz, d(e), d(t)).backward()
+        torch.cuda.synchronize()
+        runs.append((hz.detach().cpu(), [p.grad.detach().cpu().clone() for p in net.parameters()]))
+    assert_close(runs[1][0], runs[0][0], 1e-6, "hazards of two runs")
+    gmax = max(float(g.abs().max()) for g in runs[0][1])
+    worst, same = 0.0, 0
+    for a, b in zip(*[r[1] for r in runs]):
+        if float(a.abs().max()) < 1e-5 * gmax:
+            continue
+        worst = max(worst, rel_err(b, a))
+        same += int(torch.equal(a, b))
+    print(f"run-twice spread: worst per-tensor gradient difference {worst:.2e}; {same} tensors bit-identical")
+    assert worst <= 1e-4
