@@ -618,11 +618,11 @@ struct Conv1BwdDataOp {
     }
 };
 
-static bool conv1_bwd_same(const Conv1BwdP* pp, int ng) {
+static bool conv1_bwd_same(const Conv1BwdP* pp, int ng, bool same_k = true) {
     const Conv1BwdP& p = *pp;
     for (int g = 1; g < ng; ++g) {
         const Conv1BwdP& q = pp[g];
-        if (q.M != p.M || q.N != p.N || q.K != p.K || q.ldx % 4 != 0 || q.lddy % 4 != 0 || q.pool != p.pool || q.has_bn_out != p.has_bn_out ||
+        if (q.M != p.M || q.N != p.N || (same_k && q.K != p.K) || q.K % 32 != 0 || q.ldx % 4 != 0 || q.lddy % 4 != 0 || q.pool != p.pool || q.has_bn_out != p.has_bn_out ||
             q.msplit != p.msplit || q.in.D != p.in.D || q.in.H != p.in.H || q.in.W != p.in.W) return false;
     }
     return true;
@@ -677,7 +677,10 @@ struct Conv1BwdWOp {
             p.dbeta_out[n0r + tid] += (float)rep_sum(p.bb_out.s1, n0r + tid, p.bb_out.nrep, p.bb_out.rep_stride);
         }
     }
-    __device__ void krange(const Params&, int, int& kb, int& ke) { kb = mb; ke = me; }
+    __device__ void krange(const Params& p, int, int& kb, int& ke) {
+        kb = mb; ke = me;
+        if (k0c >= p.K) ke = kb;        // members of one launch may differ in K (layers of a dense block): nothing to do here
+    }
     struct ARaw { float4 g, y; };
     typedef float4 BRaw;
     __device__ ARaw a_ld(const Params& p, int, int n, int m, bool& ok) const {   // A(row n..n+3, m) = dy[m][n..n+3]
@@ -719,7 +722,7 @@ struct Conv1BwdWOp {
         return act4(v, k - k0c);
     }
     __device__ void epilogue(const Params& p, int, int, int, const float* Cs, int tid, bool active) {
-        if (mb >= me || !active) return;
+        if (mb >= me || !active || k0c >= p.K) return;
         for (int idx = tid; idx < TM * TN; idx += 256) {
             const int r = idx / TN, c = idx % TN, n = n0r + r, k = k0c + c;
             if (n < p.N && k < p.K) atomicAdd(&p.dw[(size_t)n * p.K + k], Cs[r * (TN + 1) + c]);
@@ -731,8 +734,10 @@ extern "C" int mms_conv1_bwd_weight_group(const Conv1BwdP* pp, int ng, hipStream
     if (!pp || ng < 1 || ng > MMS_MAX_GROUP) return MMS_ERR_ARG;
     const Conv1BwdP& p = *pp;
     if (p.M <= 0 || p.msplit <= 0 || p.K % 32 != 0 || p.N % 32 != 0) return MMS_ERR_ARG;
-    if (!conv1_bwd_same(pp, ng)) return MMS_ERR_ARG;
-    dim3 g((p.N + 63) / 64, (p.K + 63) / 64, p.msplit);
+    if (!conv1_bwd_same(pp, ng, false)) return MMS_ERR_ARG;
+    int kmax = p.K;                     // members may differ in K (input channels): the grid covers the widest, the others' surplus
+    for (int g = 1; g < ng; ++g) if (pp[g].K > kmax) kmax = pp[g].K;      // workgroups return at once (Conv1BwdWOp::krange)
+    dim3 g((p.N + 63) / 64, (kmax + 63) / 64, p.msplit);
     return p.pool ? launch_tile_gemm<Conv1BwdWOp<true>>(pp, ng, g, s) : launch_tile_gemm<Conv1BwdWOp<false>>(pp, ng, g, s);
 }
 MMS_SINGLE(mms_conv1_bwd_weight, Conv1BwdP)

@@ -32,7 +32,7 @@ struct Plan {
     int R0, R[NB];     // statistic-accumulator replicas of the stem level / of each block (common.h: stat_rep)
     // byte offsets into the workspace
     size_t coords0, coords[NB], y0, argmax, slab[NB], dslab[NB], y1[NLAYER], wpf[NLAYER], wpb[NLAYER];
-    size_t dbn_mid, dbn_in, dbn0, pooled, tab_pack, tab_bn, partial, dwp[NLAYER];
+    size_t dbn_mid, dbn_mid_l[NLAYER], dbn_in, dbn0, pooled, tab_pack, tab_bn, partial, dwp[NLAYER];
     // fp64 statistic accumulators (one contiguous region, zeroed once per step)
     size_t stats_begin, stats_end;
     size_t st_y0, st_slab[NB], st_y1[NLAYER];          // forward (sum | sumsq), each 2*C doubles
@@ -71,6 +71,12 @@ bool make_plan(Plan& P, int B, int D, int H, int W) {
             P.wpb[l] = take((size_t)32 * 27 * 128 * 4);
         }
     P.dbn_mid = take((size_t)P.M[0] * 128 * 4);
+    {   // conv2's input gradient of a layer: block 1 reuses one buffer; blocks 2-4 keep one per layer, so that their conv1
+        // weight-gradient kernels (off the backward's critical chain) can run batched over layers at the end of the block
+        int l2 = 0;
+        for (int b = 0; b < NB; ++b)
+            for (int i = 0; i < LAYERS[b]; ++i, ++l2) P.dbn_mid_l[l2] = b == 0 ? P.dbn_mid : take((size_t)P.M[b] * 128 * 4);
+    }
     size_t mx = 0;
     for (int b = 0; b < NB; ++b) { size_t v = (size_t)P.M[b] * CTOT[b] * 4; if (v > mx) mx = v; }
     P.dbn_in = take(mx);
@@ -361,10 +367,29 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
         }
         TRY(mms_head_bwd_group(hb, ng, s));
     }
+    // Weight gradients are off the backward's critical chain (nothing reads them before the optimiser).  In blocks 2-4 a
+    // layer's two weight-gradient launches are far too small to fill the chip (27-216 workgroups per model), so they are
+    // deferred and issued batched over layers -- as many (model, layer) members per launch as the group entry points carry --
+    // once the block's chain is through: dz_l = dslab[:, C_l:C_l+32] is final from the moment layer l has been processed (earlier
+    // layers only add into columns < C_l), y1 / the statistic accumulators are per layer, and dbn_mid is per layer there.
+    // MMS_BATCH_W=0 restores one launch pair per layer.
+    const char* ebw = getenv("MMS_BATCH_W");
+    const bool batch_w = !(ebw && ebw[0] == '0') && !side;
+    Conv3BwdWP bwq[MMS_MAX_GROUP];
+    Conv1BwdP c1q[MMS_MAX_GROUP];
+    int nq = 0;
+    auto flush_w = [&]() -> int {
+        if (nq == 0) return MMS_OK;
+        TRY(mms_conv3_bwd_weight_group(bwq, nq, s));
+        TRY(mms_conv1_bwd_weight_group(c1q, nq, s));
+        nq = 0;
+        return MMS_OK;
+    };
     int l = NLAYER;
     for (int b = NB - 1; b >= 0; --b) {
         int C = CTOT[b];
         const int M = P.M[b];
+        const bool defer = batch_w && b > 0 && 2 * ng <= MMS_MAX_GROUP;
         for (int i = LAYERS[b] - 1; i >= 0; --i) {
             --l; C -= 32;
             const int ip = IDX.layer[l];
@@ -375,22 +400,24 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
             const int ns3 = conv3_nsplit(M, ng, P.partial_rows);
             // rows per weight-gradient workgroup: every chunk flushes 27 x 16 KB of fp32 atomics, so groups (which bring their own
             // parallelism) take chunks twice as long -- half the fabric writes (PMC WRITE_SIZE) for the same FLOPs
+            const int ngw = defer ? MMS_MAX_GROUP / ng * ng : ng;        // (model, layer) members per weight-gradient launch
             const char* e3 = getenv("MMS_MS3_ROWS");
-            int rows3 = e3 ? atoi(e3) : (ng >= 4 ? 1024 : 512);
-            const int rows3s = e3 ? 128 : (ng >= 4 ? 256 : 128);
+            int rows3 = e3 ? atoi(e3) : (ngw >= 4 ? 1024 : 512);
+            const int rows3s = e3 ? 128 : (ngw >= 4 ? 256 : 128);
             // 512-row chunks when that (and not the default) puts the launch on the multi-tap kernel with a well-filled grid (5-model groups)
-            if (!e3 && ng >= 4 && M > 1024 && !mms_conv3w_mt_fills((long)((M + 1023) / 1024) * ng * 9) && mms_conv3w_mt_fills((long)((M + 511) / 512) * ng * 9)) rows3 = 512;
+            if (!e3 && ngw >= 4 && M > 1024 && !mms_conv3w_mt_fills((long)((M + 1023) / 1024) * ngw * 9) && mms_conv3w_mt_fills((long)((M + 511) / 512) * ngw * 9)) rows3 = 512;
             int ms3 = M > 1024 ? (M + rows3 - 1) / rows3 : (M + rows3s - 1) / rows3s; if (ms3 < 1) ms3 = 1;
             int ms1 = M > 1024 ? M / 256 : M / 128; if (ms1 < 1) ms1 = 1; if (ms1 > 32) ms1 = 32;
-            { const char* e = getenv("MMS_MS1_DIV"); const int dv = e ? atoi(e) : (ng >= 4 ? 2 : 1); if (dv > 1) { ms1 = ms1 / dv; if (ms1 < 1) ms1 = 1; } }   // groups: half the chunks (fewer atomic flushes)
+            { const char* e = getenv("MMS_MS1_DIV"); const int dv = e ? atoi(e) : (ngw >= 4 ? 2 : 1); if (dv > 1) { ms1 = ms1 / dv; if (ms1 < 1) ms1 = 1; } }   // groups: half the chunks (fewer atomic flushes)
             FOR_G {
                 const Ctx& c = cx[g];
                 float* slab = at<float>(c.ws, P.slab[b]);
                 float* dslab = at<float>(c.ws, P.dslab[b]);
+                float* dmid = at<float>(c.ws, P.dbn_mid_l[l]);
                 const BnSrc bn1 = mk_bn(c.ws, P.st_slab[b], CTOT[b], c.prm, ip, nullptr, 0, M, 1, P.R[b]);
                 const BnSrc bn2 = mk_bn(c.ws, P.st_y1[l], 128, c.prm, ip + 3, nullptr, 0, M, 1, P.R[b]);
                 bd[g] = Conv3BwdDataP{dslab + C, CTOT[b], at<int>(c.ws, P.coords[b]), P.g[b], M, at<float>(c.ws, P.wpb[l]),
-                                      at<float>(c.ws, P.y1[l]), bn2, at<float>(c.ws, P.dbn_mid),
+                                      at<float>(c.ws, P.y1[l]), bn2, dmid,
                                       at<double>(c.ws, P.bb_y1[l]), at<double>(c.ws, P.bb_y1[l]) + 128,
                                       ns3 > 1 ? at<float>(c.ws, P.partial) : nullptr, ns3};
                 bd[g].srep = P.R[b]; bd[g].sstride = 2 * 128;
@@ -398,7 +425,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
                                    at<float>(c.ws, P.dwp[l]), ms3, 1};
                 Conv1BwdP& q = c1[g];
                 q = Conv1BwdP{};
-                q.dyraw = at<float>(c.ws, P.dbn_mid); q.lddy = 128;
+                q.dyraw = dmid; q.lddy = 128;
                 q.y = at<float>(c.ws, P.y1[l]); q.ldy = 128;
                 q.bn_out = bn2; q.bb_out = bbsrc(c.ws, P.bb_y1[l], 128, P.R[b]); q.has_bn_out = 1;
                 q.M = M; q.N = 128;
@@ -417,18 +444,24 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
                 side_pending = false;
             }
             TRY(mms_conv3_bwd_data_group(bd, ng, s));
-            if (side) {
-                if (hipEventRecord(ev_fork, s) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess) return MMS_ERR_LAUNCH;
-            }
-            TRY(mms_conv3_bwd_weight_group(bw, ng, sw));
-            TRY(mms_conv1_bwd_weight_group(c1, ng, sw));
-            if (side) {
-                if (hipEventRecord(ev_join, side) != hipSuccess) return MMS_ERR_LAUNCH;
-                side_pending = true;
+            if (defer) {
+                if (nq + ng > MMS_MAX_GROUP) TRY(flush_w());
+                FOR_G { bwq[nq] = bw[g]; c1q[nq] = c1[g]; ++nq; }
+            } else {
+                if (side) {
+                    if (hipEventRecord(ev_fork, s) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess) return MMS_ERR_LAUNCH;
+                }
+                TRY(mms_conv3_bwd_weight_group(bw, ng, sw));
+                TRY(mms_conv1_bwd_weight_group(c1, ng, sw));
+                if (side) {
+                    if (hipEventRecord(ev_join, side) != hipSuccess) return MMS_ERR_LAUNCH;
+                    side_pending = true;
+                }
             }
             TRY(mms_conv1_bwd_data_group(c1, ng, s));
             TRY(mms_bn_bwd_apply_group(ap, ng, s));
         }
+        TRY(flush_w());
         if (side && side_pending) {
             if (hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) return MMS_ERR_LAUNCH;
             side_pending = false;
