@@ -276,7 +276,8 @@ def run_config3(args, world, rank, dev):
                   f"{dt / n_ep:.3f} s per epoch", flush=True)
         D.barrier()
         return
-    sub_groups = (K,) if conc <= 1 or K < 4 else ((K + 1) // 2, K // 2)
+    nsub = 1 if conc <= 1 or K < 4 else min(conc, K)
+    sub_groups = tuple(K // nsub + (1 if h < K % nsub else 0) for h in range(nsub))
 
     # ONE cross-validation's folds dealt over the ranks (BASELINE config 3's layout: fold k -> rank k mod N), one epoch
     sharded = None
@@ -628,7 +629,9 @@ def main():
     args.steps = dflt[0] if args.steps is None else args.steps
     args.warmup = dflt[1] if args.warmup is None else args.warmup
     if args.roofline_only:
-        sub = ((args.folds + 1) // 2, args.folds // 2) if args.workload == "c3" and args.lockstep_streams > 1 else (max(1, min(args.fold_group, 10)),)
+        ns = min(args.lockstep_streams, args.folds) if args.folds >= 4 else 1
+        sub = (tuple(args.folds // ns + (1 if h < args.folds % ns else 0) for h in range(ns)) if args.workload == "c3" and ns > 1
+               else (max(1, min(args.fold_group, 10)) if args.workload != "c3" else args.folds,))
         print(json.dumps(roofline_block(args.batch, tuple(args.volume), dev, sub)), flush=True)
         return
     if args.workload == "c5":

@@ -177,6 +177,11 @@ typedef struct Conv1BwdP {
     int msplit;
     float* dgamma_out; float* dbeta_out;   // [N] BN2 parameter grads (= s2_out, s1_out), written by the weight kernel
     int srep; int sstride;          // statistic-accumulator replicas written by this op: workgroup x adds to replica x % srep (stride in doubles)
+    /* optional (data kernel, pool = 0, M <= 128 rows): norm1's backward fused into the epilogue -- a workgroup then owns all rows of
+       its channels, so the two BN-backward sums are complete locally: fuse_dx[:, 0:K] (+)= gamma*rstd*(dbn - s1/M - xhat*s2/M),
+       fuse_dgamma += s2, fuse_dbeta += s1; dbn / s1 / s2 are not written and no mms_bn_bwd_apply launch follows. */
+    float* fuse_dx; int fuse_lddx; int fuse_accumulate;
+    float* fuse_dgamma; float* fuse_dbeta;
 } Conv1BwdP;
 
 // dslab[:, 0:C] (+)= g*rstd*(dbn - s1/M - xhat*s2/M)

@@ -590,7 +590,7 @@ struct Conv1BwdDataOp {
                     const size_t m = m0_ + r;
                     const float xh = (p.x[m * p.ldx + k] - mu) * rs;
                     const float g = fmaf(ga, xh, be) > 0.f ? da : 0.f;
-                    p.dbn[m * p.lddbn + k] = g;
+                    if (!p.fuse_dx) p.dbn[m * p.lddbn + k] = g;
                     s1 += g; s2 += (double)g * xh;
                 } else {
                     const int base = srcbase[r], HW = p.in.H * p.in.W, W = p.in.W;
@@ -609,6 +609,26 @@ struct Conv1BwdDataOp {
         double* red = (double*)(ein + 4 * TN + TM);     // offset (640 + 4TN + TM)*4 bytes: multiple of 8
         if (active) { red[(rg * 2 + 0) * TN + c] = s1; red[(rg * 2 + 1) * TN + c] = s2; }
         __syncthreads();
+        if (!POOL && p.fuse_dx) {
+            // This workgroup holds ALL rows of its channels (launcher: M <= TM, one row tile): the BN1-backward sums are complete
+            // right here, so norm1's backward is applied in place -- dx[:, k] (+)= gamma*rstd*(g - s1/M - xhat*s2/M), dgamma, dbeta --
+            // without the dbn scratch, the atomics and the separate mms_bn_bwd_apply launch (same arithmetic as that kernel).
+            if (k < p.K && active) {
+                double a = 0, b = 0;
+                for (int g = 0; g < RG; ++g) { a += red[(g * 2) * TN + c]; b += red[(g * 2 + 1) * TN + c]; }
+                const float gr = ga * rs, m1 = (float)(a * (double)p.bn_in.inv_count), m2 = rs * (float)(b * (double)p.bn_in.inv_count);
+                for (int r = rg; r < rows; r += RG) {
+                    const size_t m = m0_ + r;
+                    const float x = p.x[m * p.ldx + k];
+                    const float g = fmaf(ga, (x - mu) * rs, be) > 0.f ? Cs[r * (TN + 1) + c] : 0.f;
+                    float* dst = p.fuse_dx + m * p.fuse_lddx + k;
+                    const float o = p.fuse_accumulate ? *dst : 0.f;
+                    *dst = o + gr * (g - m1 - (x - mu) * m2);
+                }
+                if (rg == 0 && p.fuse_dgamma) { p.fuse_dgamma[k] += (float)b; p.fuse_dbeta[k] += (float)a; }
+            }
+            return;
+        }
         if (rg == 0 && k < p.K && active) {
             double a = 0, b = 0;
             for (int g = 0; g < RG; ++g) { a += red[(g * 2) * TN + c]; b += red[(g * 2 + 1) * TN + c]; }
@@ -633,6 +653,13 @@ extern "C" int mms_conv1_bwd_data_group(const Conv1BwdP* pp, int ng, hipStream_t
     if (p.M <= 0 || p.K % 32 != 0 || p.N % 32 != 0 || p.ldx % 4 != 0 || p.lddy % 4 != 0) return MMS_ERR_ARG;
     if (p.has_bn_out && p.N != 128) return MMS_ERR_ARG;
     if (!conv1_bwd_same(pp, ng)) return MMS_ERR_ARG;
+    for (int g = 0; g < ng; ++g) if ((pp[g].fuse_dx != nullptr) != (p.fuse_dx != nullptr)) return MMS_ERR_ARG;
+    if (p.fuse_dx) {      // norm1 backward fused into the epilogue: one workgroup must own every row of its 32 channels
+        if (p.pool || p.M > 128 || p.fuse_lddx % 4 != 0) return MMS_ERR_ARG;
+        dim3 g(1, (p.K + 31) / 32, 1);
+        return p.M <= 32 ? launch_tile_gemm<Conv1BwdDataOp<1, 1, 4, false>>(pp, ng, g, s)
+                         : launch_tile_gemm<Conv1BwdDataOp<4, 1, 1, false>>(pp, ng, g, s);
+    }
     const int big_ng = getenv("MMS_BIG_NG") ? atoi(getenv("MMS_BIG_NG")) : 1;      // 1: count the whole group's tiles (0: tests that need ng-independent arithmetic)
     const bool big = (long)p.M * p.K * (big_ng ? ng : 1) >= 256L * 64 * 64;
     if (big) {

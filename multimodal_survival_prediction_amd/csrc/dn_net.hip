@@ -390,6 +390,9 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
         int C = CTOT[b];
         const int M = P.M[b];
         const bool defer = batch_w && b > 0 && 2 * ng <= MMS_MAX_GROUP;
+        // blocks of <= 128 rows: norm1's backward rides in conv1_bwd_data's epilogue (Conv1BwdP.fuse_dx), no mms_bn_bwd_apply launch
+        const char* efa = getenv("MMS_FUSE_APPLY");
+        const bool fuse_apply = M <= 128 && !(efa && efa[0] == '0');
         for (int i = LAYERS[b] - 1; i >= 0; --i) {
             --l; C -= 32;
             const int ip = IDX.layer[l];
@@ -436,6 +439,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
                 q.s1 = at<double>(c.ws, P.bb_in[l]); q.s2 = at<double>(c.ws, P.bb_in[l]) + 1024;
                 q.srep = P.R[b]; q.sstride = 2 * 1024;
                 q.msplit = ms1; q.dgamma_out = c.grd[ip + 3]; q.dbeta_out = c.grd[ip + 4];
+                if (fuse_apply) { q.fuse_dx = dslab; q.fuse_lddx = CTOT[b]; q.fuse_accumulate = 1; q.fuse_dgamma = c.grd[ip]; q.fuse_dbeta = c.grd[ip + 1]; }
                 ap[g] = BnBwdApplyP{at<float>(c.ws, P.dbn_in), CTOT[b], slab, CTOT[b], dslab, CTOT[b], M, C, bn1,
                                     bbsrc(c.ws, P.bb_in[l], 1024, P.R[b]), 1, c.grd[ip], c.grd[ip + 1]};
             }
@@ -459,7 +463,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
                 }
             }
             TRY(mms_conv1_bwd_data_group(c1, ng, s));
-            TRY(mms_bn_bwd_apply_group(ap, ng, s));
+            if (!fuse_apply) TRY(mms_bn_bwd_apply_group(ap, ng, s));
         }
         TRY(flush_w());
         if (side && side_pending) {

@@ -132,6 +132,10 @@ class HostBatchLoader:
         self.hs = cohort_pinned["has_survival"].tolist()
         self.ring = [{k: torch.empty((batch_size,) + tuple(cohort_pinned[k].shape[1:]), dtype=cohort_pinned[k].dtype).pin_memory()
                       for k in self.KEYS} for _ in range(depth)]
+        for st in self.ring:      # contiguous pinned copies of the per-patient scalars: a strided or pageable source would make the
+            for k in ("_time", "_event", "_valid"):      # "asynchronous" copy stage through a temporary and block the host
+                st[k] = torch.empty(batch_size).pin_memory()
+        self.hs_f = cohort_pinned["has_survival"].to(torch.float32)
         self.events = [None] * depth
 
     def __len__(self):
@@ -155,6 +159,9 @@ class HostBatchLoader:
                 torch.index_select(self.c[k], 0, j, out=st[k][:n])
                 b[k] = st[k][:n]
             b["has_survival"] = [self.hs[int(q)] for q in j]
+            torch.index_select(self.c["label"][:, 0], 0, j, out=st["_time"][:n]); b["_time"] = st["_time"][:n]
+            torch.index_select(self.c["label"][:, 1], 0, j, out=st["_event"][:n]); b["_event"] = st["_event"][:n]
+            torch.index_select(self.hs_f, 0, j, out=st["_valid"][:n]); b["_valid"] = st["_valid"][:n]
             prev, slot = slot, (slot + 1) % len(self.ring)
             yield b
         if prev is not None:

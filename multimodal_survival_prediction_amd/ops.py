@@ -98,7 +98,8 @@ def conv3_bwd_weight(y1, coords, dims, bn, dz, dw, msplit=1, tapmajor=False):
 
 
 def conv1_bwd(which, dyraw, M, N, x, K, bn_in, w, dw, dbn, s1, s2, y=None, bn_out=None, bb_out=None, pool=False,
-              in_dims=(0, 0, 0), msplit=1, dgamma_out=None, dbeta_out=None):
+              in_dims=(0, 0, 0), msplit=1, dgamma_out=None, dbeta_out=None, fuse_dx=None, fuse_accumulate=True, fuse_dgamma=None,
+              fuse_dbeta=None):
     S = _S()
     p = S["Conv1BwdP"]()
     p.dyraw, p.lddy = ptr(dyraw), dyraw.stride(0)
@@ -116,6 +117,9 @@ def conv1_bwd(which, dyraw, M, N, x, K, bn_in, w, dw, dbn, s1, s2, y=None, bn_ou
     p.s1, p.s2 = ptr(s1), ptr(s2)
     p.msplit = msplit
     p.dgamma_out, p.dbeta_out = ptr(dgamma_out), ptr(dbeta_out)
+    if fuse_dx is not None:          # norm1 backward in the data kernel's epilogue (Conv1BwdP.fuse_dx, M <= 128)
+        p.fuse_dx, p.fuse_lddx, p.fuse_accumulate = ptr(fuse_dx), fuse_dx.stride(0), 1 if fuse_accumulate else 0
+        p.fuse_dgamma, p.fuse_dbeta = ptr(fuse_dgamma), ptr(fuse_dbeta)
     call("mms_conv1_bwd_weight" if which == "weight" else "mms_conv1_bwd_data", p)
 
 

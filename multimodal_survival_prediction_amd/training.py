@@ -277,6 +277,9 @@ def _train_kwargs(style, batch):
         return dict(ct=batch['image'], rna=batch['rnaseq'], clinical=batch['clinical'], time=label[:, 0], event=label[:, 1])
     if style == "rnaseq":
         return dict(rna=batch['rnaseq'], time=batch['time'].reshape(-1), event=batch['event'].reshape(-1))
+    if style == "partial" and "_valid" in batch:      # data.HostBatchLoader: contiguous pinned scalars -> truly asynchronous copies
+        return dict(ct=batch['image'], rna=batch['rnaseq'], clinical=batch['clinical'], mask=batch['mask'], time=batch['_time'],
+                    event=batch['_event'], valid=batch['_valid'])
     valid = torch.as_tensor(batch['has_survival'], dtype=torch.float32)
     if style == "partial":
         label = batch['label']
@@ -313,9 +316,9 @@ def _lockstep(loaders, members):
 
 def train_epoch_lockstep(group, loaders, style, members=None, concurrent=1):
     """One epoch of the folds `members` (default: all) of a FoldGroupEngine, each on its own loader.
-    concurrent = 2: the members are split into two fixed halves that step as two lock-step sub-groups on two HIP streams
-    (one sub-group's latency-bound kernels overlap the other's; 5 folds as 3 + 2: +4.5 % over one group of 5).  Every member's
-    loader is iterated under its half's stream, so batch tensors are allocated and consumed on the same stream.
+    concurrent = n >= 2: the members are split into n fixed sub-groups that step as n lock-step sub-groups on n HIP streams
+    (one sub-group's latency-bound kernels overlap the others').  Every member's loader is iterated under its sub-group's
+    stream, so batch tensors are allocated and consumed on the same stream.
     -> per member, what train_epoch_<style> returns for that fold."""
     members = tuple(range(len(group))) if members is None else tuple(members)
     for g in members:
@@ -347,26 +350,33 @@ def train_epoch_lockstep(group, loaders, style, members=None, concurrent=1):
         for pos in _lockstep(loaders, members):
             advance(pos)
     else:
-        if not hasattr(group, "_side_streams"):
-            group._side_streams = [torch.cuda.Stream(device=group.device) for _ in range(2)]
-        cut = (len(members) + 1) // 2
-        halves = [(members[:cut], loaders[:cut]), (members[cut:], loaders[cut:])]
+        nsub = min(int(concurrent), len(members))
+        streams = group.__dict__.setdefault("_side_streams", [])
+        while len(streams) < nsub:
+            streams.append(torch.cuda.Stream(device=group.device))
+        # fixed, contiguous sub-groups of near-equal size (5 folds on 2 streams: 3 + 2; on 3 streams: 2 + 2 + 1)
+        base, extra = divmod(len(members), nsub)
+        cuts, o = [], 0
+        for h in range(nsub):
+            n = base + (1 if h < extra else 0)
+            cuts.append((members[o:o + n], loaders[o:o + n]))
+            o += n
         cur = torch.cuda.current_stream()
-        for s in group._side_streams:
+        for s in streams[:nsub]:
             s.wait_stream(cur)
-        its = [_lockstep(ld, mem) for mem, ld in halves]
-        live = [True, True]
+        its = [_lockstep(ld, mem) for mem, ld in cuts]
+        live = [True] * nsub
         while any(live):
-            for h in (0, 1):
+            for h in range(nsub):
                 if not live[h]:
                     continue
-                with torch.cuda.stream(group._side_streams[h]):
+                with torch.cuda.stream(streams[h]):
                     pos = next(its[h], None)         # the loaders gather their batches on this stream
                     if pos is None:
                         live[h] = False
                     else:
                         advance(pos)
-        for s in group._side_streams:
+        for s in streams[:nsub]:
             cur.wait_stream(s)
         torch.cuda.synchronize()
     out = []

@@ -21,6 +21,7 @@ def _d(t):
 
 
 @pytest.mark.parametrize("B,dims,C,Ctot,ms", [(2, (4, 4, 2), 64, 256, 1), (4, (8, 8, 4), 96, 256, 4), (3, (2, 2, 1), 512, 1024, 1),
+                                              (4, (4, 4, 2), 352, 1024, 1), (4, (2, 2, 1), 992, 1024, 1),     # blocks 3 / 4 at batch 4 (128 / 16 rows)
                                               (2, (16, 16, 8), 224, 256, 16),
                                               # shapes that take the multi-tap forward kernel in the layer's forward: ragged last tile, W = 16
                                               (3, (7, 7, 8), 64, 256, 4), (2, (8, 16, 16), 96, 256, 8)])
@@ -76,7 +77,17 @@ def test_dense_layer_backward(ops, B, dims, C, Ctot, ms, split, monkeypatch):
     kw = dict(y=y1d, bn_out=bn2, bb_out=bb2, msplit=ms, dgamma_out=dg2, dbeta_out=db2)
     ops.conv1_bwd("weight", dbn_mid, M, 128, slab, C, bn1, w1, dw1, dbn_in, e1, e2, **kw)
     ops.conv1_bwd("data", dbn_mid, M, 128, slab, C, bn1, w1, dw1, dbn_in, e1, e2, **kw)
+    dslab_f = dslab.clone()
     ops.bn_bwd_apply(dbn_in, slab, dslab, M, C, bn1, ops.bnbwd(e1, e2), True, dg1, db1)
+    if M <= 128:      # small-M blocks: norm1 backward fused into conv1_bwd_data's epilogue (no dbn scratch, no apply launch)
+        dg1f, db1f = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        f1, f2 = stats(DEV, 1024)
+        ops.conv1_bwd("data", dbn_mid, M, 128, slab, C, bn1, w1, dw1, torch.empty(M, Ctot, device=DEV), f1, f2,
+                      fuse_dx=dslab_f, fuse_dgamma=dg1f, fuse_dbeta=db1f, **kw)
+        torch.cuda.synchronize()
+        assert_close(dslab_f[:, :C], cl(x.grad), 1e-4, "dx (fused norm1 backward)")
+        assert_close(dg1f, n1.weight.grad, 1e-4, "dgamma1 (fused)"); assert_close(db1f, n1.bias.grad, 1e-4, "dbeta1 (fused)")
+        assert torch.equal(dslab_f[:, C:], dslab[:, C:])
     torch.cuda.synchronize()
     assert_close(dw2, c2.weight.grad, 1e-4, "dW conv2")
     assert_close(dw2m, c2.weight.grad, 1e-4, "dW conv2 (multi-tap kernel)")
