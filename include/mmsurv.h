@@ -2,7 +2,7 @@
  * baek0203/multimodal_survival_prediction (per-batch forward/backward of the multimodal survival networks +
  * Cox partial likelihood).
  *
- * The reference has no FFI of its own: its boundary is the Python surface of scripts/training/*.py
+ * The reference has no FFI of its own: its boundary is the Python surface of scripts/training/<name>.py
  * (SURVEY.md section 8b).  Every entry point below replaces a torch/MONAI/torchsurv op sequence invoked from
  * that surface; the replaced call site is cited per function as R/<file>:<line> (R = the reference repo).
  *
@@ -201,6 +201,7 @@ typedef struct HeadBwdP {
     float* dw; float* dbias;        // [N][C], [N]
     float* dgamma; float* dbeta;    // [C]
     float* dslab; int ldd;          // [B*V][ldd] first C columns written
+    double* ext_sums;               // mms_head_bwd_sums / _apply only: [2][C] norm5-backward sums (s1 | s2), zeroed by the caller
 } HeadBwdP;
 
 typedef struct PoolBwdP {                   // maxpool backward + relu0 mask -> dbn0, sums
@@ -452,6 +453,25 @@ int mms_dn121_forward(void* ws, int B, int D, int H, int W, const float* x, cons
                       const void* const* buffers, float* out, int ldo, int train, hipStream_t s);
 int mms_dn121_backward(void* ws, int B, int D, int H, int W, const float* x, const void* const* params,
                        const float* dout, int lddout, void* const* grads, hipStream_t s);
+/* ---- data-parallel (one process per GPU) variants of the single-model drivers --------------------------------------------
+ * The reference is single-process (R/scripts/training/final_multimodal.py:52,345); BASELINE config 4 shards a global batch over
+ * ranks.  Two things then leave the rank: (a) the gradients, all-reduced bucket by bucket while the backward still runs -- the
+ * backward is issued in STAGES, dense blocks block_hi..block_lo (3 = denseblock4 + norm5/class_layers + transition3, ..., 0 =
+ * denseblock1 + stem), each finalising one contiguous range of the parameter table (incl. its conv2 gradient unpack);
+ * (b) with SyncBN, every BatchNorm statistic: the drivers call `hook` right after each kernel that produced accumulator words and
+ * before the first kernel that consumes them; the hook all-reduces (SUM over ranks, in place) the words
+ *     base[r * rep_stride + j * pair_stride + c],  r < nrep, j < 2, c < ncols        (fp64)
+ * on stream s and returns 0.  bn_world = ranks the statistics span (counts become bn_world * rows); hook may be null (bn_world 1).
+ * mms_dn121_init_sync: as mms_dn121_init, running-statistics table built for bn_world * rows. */
+typedef int (*mms_sync_fn)(void* user, double* base, int nrep, long rep_stride, int ncols, long pair_stride, hipStream_t s);
+int mms_dn121_init_sync(void* ws, int B, int D, int H, int W, const void* const* params, const void* const* buffers, int bn_world, hipStream_t s);
+int mms_dn121_forward_sync(void* ws, int B, int D, int H, int W, const float* x, const void* const* params,
+                           const void* const* buffers, float* out, int ldo, int bn_world, mms_sync_fn hook, void* user, hipStream_t s);
+int mms_dn121_backward_stage(void* ws, int B, int D, int H, int W, const float* x, const void* const* params,
+                             const float* dout, int lddout, void* const* grads, int block_hi, int block_lo,
+                             int bn_world, mms_sync_fn hook, void* user, hipStream_t s);
+int mms_head_bwd_sums(const HeadBwdP* p, hipStream_t s);         /* SyncBN split of mms_head_bwd: masked gradient stash + local sums */
+int mms_head_bwd_apply(const HeadBwdP* p, hipStream_t s);        /* ... norm5 backward with the (all-reduced) sums + class_layers.out gradients */
 /* same, with the per-layer weight-gradient kernels forked onto `side` (caller-created stream and two events): they
  * are off the critical path dslab -> dbn2 -> dbn1 -> dslab, so under graph capture they become parallel branches. */
 int mms_dn121_backward_mt(void* ws, int B, int D, int H, int W, const float* x, const void* const* params,

@@ -13,7 +13,12 @@ _PROTOS = {}
 _SCALARS = {"int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double,
             "uint32_t": ctypes.c_uint32, "uint64_t": ctypes.c_uint64, "int64_t": ctypes.c_int64,
             "size_t": ctypes.c_size_t, "long long": ctypes.c_longlong, "unsigned": ctypes.c_uint,
-            "hipStream_t": ctypes.c_void_p, "hipEvent_t": ctypes.c_void_p}
+            "hipStream_t": ctypes.c_void_p, "hipEvent_t": ctypes.c_void_p, "long": ctypes.c_long,
+            "mms_sync_fn": ctypes.c_void_p}
+
+# include/mmsurv.h: typedef int (*mms_sync_fn)(void* user, double* base, int nrep, long rep_stride, int ncols, long pair_stride, hipStream_t s)
+SYNC_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_long,
+                           ctypes.c_void_p)
 
 
 def lib_path():

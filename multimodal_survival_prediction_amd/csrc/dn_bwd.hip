@@ -906,6 +906,61 @@ extern "C" int mms_head_bwd_group(const HeadBwdP* pp, int ng, hipStream_t s) {
 }
 MMS_SINGLE(mms_head_bwd, HeadBwdP)
 
+// SyncBN split of the head backward: the two norm5-backward sums leave the kernel (ext_sums, all-reduced over the ranks by the
+// caller between the two launches); p.bn carries the GLOBAL statistics and count.  One thread per channel; not a hot path.
+__global__ __launch_bounds__(256) void head_bwd_sums_kernel(const HeadBwdP p) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= p.C) return;
+    float mu, rs;
+    bn_mean_rstd(p.bn, c, mu, rs);
+    const float ga = p.bn.gamma[c], be = p.bn.beta[c], invV = 1.f / (float)p.V;
+    double s1 = 0, s2 = 0;
+    for (int b = 0; b < p.B; ++b) {
+        float dp = 0;
+        for (int n = 0; n < p.N; ++n) dp = fmaf(p.dout[b * p.lddout + n], p.w[(size_t)n * p.C + c], dp);
+        dp *= invV;
+        for (int v = 0; v < p.V; ++v) {
+            const size_t m = (size_t)b * p.V + v;
+            const float xh = (p.slab[m * p.ld + c] - mu) * rs;
+            const float g = fmaf(ga, xh, be) > 0.f ? dp : 0.f;
+            p.dslab[m * p.ldd + c] = g;
+            s1 += g; s2 += (double)g * xh;
+        }
+    }
+    p.ext_sums[c] = s1; p.ext_sums[p.C + c] = s2;
+}
+__global__ __launch_bounds__(256) void head_bwd_apply_kernel(const HeadBwdP p) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= p.C) return;
+    float mu, rs;
+    bn_mean_rstd(p.bn, c, mu, rs);
+    const float ga = p.bn.gamma[c];
+    const double t1 = p.ext_sums[c], t2 = p.ext_sums[p.C + c];
+    const float m1 = (float)(t1 * (double)p.bn.inv_count), m2 = (float)(t2 * (double)p.bn.inv_count);
+    for (int m = 0; m < p.B * p.V; ++m) {
+        const float xh = (p.slab[(size_t)m * p.ld + c] - mu) * rs;
+        const float g = p.dslab[(size_t)m * p.ldd + c];
+        p.dslab[(size_t)m * p.ldd + c] = ga * rs * (g - m1 - xh * m2);
+    }
+    // (like every BatchNorm parameter gradient under SyncBN these are the GLOBAL sums on every rank: the caller scales them by
+    // 1/ranks before its SUM all-reduce of the gradients)
+    p.dgamma[c] += (float)t2;
+    p.dbeta[c] += (float)t1;
+}
+extern "C" int mms_head_bwd_sums(const HeadBwdP* pp, hipStream_t s) {
+    if (!pp || pp->B <= 0 || !pp->ext_sums) return MMS_ERR_ARG;
+    MMS_LAUNCH(head_bwd_sums_kernel, dim3((pp->C + 255) / 256), dim3(256), 0, s, *pp);
+    return mms_check_launch();
+}
+extern "C" int mms_head_bwd_apply(const HeadBwdP* pp, hipStream_t s) {
+    if (!pp || pp->B <= 0 || !pp->ext_sums) return MMS_ERR_ARG;
+    Grp<HeadBwdP> a;
+    if (!grp_fill(a, pp, 1, 1)) return MMS_ERR_ARG;
+    MMS_LAUNCH(head_bwd_apply_kernel, dim3((pp->C + 255) / 256), dim3(256), 0, s, *pp);
+    MMS_LAUNCH(head_bwd_w_kernel, dim3((pp->N * pp->C + 255) / 256, 1, 1), dim3(256), 0, s, a);
+    return mms_check_launch();
+}
+
 // ------------------------------------------------------------------------------------------------------
 // maxpool(3,2,1) backward (gather form, no atomics on the gradient) + relu0 mask -> dbn0, BN0 sums
 // one workgroup = 256 conv0-grid voxels x 64 channels

@@ -37,7 +37,7 @@ struct Plan {
     size_t stats_begin, stats_end;
     size_t st_y0, st_slab[NB], st_y1[NLAYER];          // forward (sum | sumsq), each 2*C doubles
     size_t counters;                                   // split-fixup tickets (zeroed at init, re-armed by their users)
-    size_t bb_y0, bb_y1[NLAYER], bb_in[NLAYER], bb_tr[3];   // backward (s1 | s2)
+    size_t bb_y0, bb_y1[NLAYER], bb_in[NLAYER], bb_tr[3], bb_head;   // backward (s1 | s2)
     size_t total;
 };
 
@@ -100,6 +100,7 @@ bool make_plan(Plan& P, int B, int D, int H, int W) {
     for (int i = 0; i < NLAYER; ++i) P.bb_y1[i] = take((size_t)P.R[blk_of[i]] * 2 * 128 * 8);
     for (int i = 0; i < NLAYER; ++i) P.bb_in[i] = take((size_t)P.R[blk_of[i]] * 2 * 1024 * 8);
     for (int i = 0; i < 3; ++i) P.bb_tr[i] = take((size_t)P.R[i] * 2 * 1024 * 8);
+    P.bb_head = take((size_t)2 * 1024 * 8);
     P.stats_end = o;
     P.counters = take(4096 * 4);
     P.total = o;
@@ -158,6 +159,8 @@ extern "C" int mms_conv1_bwd_data_group(const Conv1BwdP*, int, hipStream_t);
 extern "C" int mms_conv1_bwd_weight_group(const Conv1BwdP*, int, hipStream_t);
 extern "C" int mms_bn_bwd_apply_group(const BnBwdApplyP*, int, hipStream_t);
 extern "C" int mms_head_bwd_group(const HeadBwdP*, int, hipStream_t);
+extern "C" int mms_head_bwd_sums(const HeadBwdP*, hipStream_t);
+extern "C" int mms_head_bwd_apply(const HeadBwdP*, hipStream_t);
 extern "C" int mms_pool_bwd_group(const PoolBwdP*, int, hipStream_t);
 extern "C" int mms_conv0_bwd_weight_group(const Conv0BwdWP*, int, hipStream_t);
 
@@ -188,10 +191,10 @@ extern "C" int mms_dn121_region(int B, int D, int H, int W, const char* name, in
 }
 
 // One-time (per workspace / per parameter-pointer set) initialisation: coordinate tables + device tables.
-extern "C" int mms_dn121_init(void* ws, int B, int D, int H, int W, const void* const* params,
-                              const void* const* buffers, hipStream_t s) {
+static int dn121_init_impl(void* ws, int B, int D, int H, int W, const void* const* params,
+                           const void* const* buffers, int bn_world, hipStream_t s) {
     Plan P;
-    if (!make_plan(P, B, D, H, W) || !ws || !params || !buffers) return MMS_ERR_ARG;
+    if (!make_plan(P, B, D, H, W) || !ws || !params || !buffers || bn_world < 1) return MMS_ERR_ARG;
     TRY(mms_init_coords(at<int>(ws, P.coords0), B, P.g0.D, P.g0.H, P.g0.W, s));
     for (int b = 0; b < NB; ++b) TRY(mms_init_coords(at<int>(ws, P.coords[b]), B, P.g[b].D, P.g[b].H, P.g[b].W, s));
     (void)hipGetLastError();
@@ -201,7 +204,7 @@ extern "C" int mms_dn121_init(void* ws, int B, int D, int H, int W, const void* 
         bn[ord].nrep = nrep; bn[ord].rep_stride = 2 * Ctot_;
         bn[ord].sum = at<double>(ws, st); bn[ord].sumsq = at<double>(ws, st) + Ctot_;
         bn[ord].rmean = (float*)buffers[3 * ord]; bn[ord].rvar = (float*)buffers[3 * ord + 1];
-        bn[ord].nbt = (long long*)buffers[3 * ord + 2]; bn[ord].C = C; bn[ord].count = (float)count;
+        bn[ord].nbt = (long long*)buffers[3 * ord + 2]; bn[ord].C = C; bn[ord].count = (float)count * (float)bn_world;
     };
     set_bn(0, P.st_y0, 64, 64, P.M0, P.R0);
     int l = 0;
@@ -225,6 +228,15 @@ extern "C" int mms_dn121_init(void* ws, int B, int D, int H, int W, const void* 
         return MMS_ERR_LAUNCH;
     }
     return MMS_OK;
+}
+
+extern "C" int mms_dn121_init(void* ws, int B, int D, int H, int W, const void* const* params,
+                              const void* const* buffers, hipStream_t s) {
+    return dn121_init_impl(ws, B, D, H, W, params, buffers, 1, s);
+}
+extern "C" int mms_dn121_init_sync(void* ws, int B, int D, int H, int W, const void* const* params,
+                                   const void* const* buffers, int bn_world, hipStream_t s) {
+    return dn121_init_impl(ws, B, D, H, W, params, buffers, bn_world, s);
 }
 
 // Tap split of the 3x3x3 convolutions (forward and backward-data): a launch should put about `target` workgroups on the
@@ -254,12 +266,22 @@ struct Ctx {
     void* ws; const float* x; const float* const* prm; const void* const* buf; float* out;      // forward
     const float* dout; float* const* grd;                                                        // backward
 };
+// Data-parallel extras of the single-model drivers (mms_dn121_*_sync / _stage): BatchNorm statistics over bn_world ranks
+// (hook = the caller's all-reduce of freshly written accumulator words) and the dense-block range [b_lo, b_hi] of a backward stage.
+struct Dp {
+    int bn_world = 1; mms_sync_fn hook = nullptr; void* user = nullptr;
+    int b_hi = NB - 1, b_lo = 0;
+};
+#define SYNC(ptr, nrep, rstride, ncols, pstride) do { if (dp.hook) { int rc_ = dp.hook(dp.user, (ptr), (nrep), (long)(rstride), (ncols), (long)(pstride), s); \
+    if (rc_ != MMS_OK) { fprintf(stderr, "mmsurv: statistics all-reduce hook failed (dn_net.hip:%d)\n", __LINE__); return MMS_ERR_LAUNCH; } } } while (0)
 #define FOR_G for (int g = 0; g < ng; ++g)
 
 // Forward of ng models of identical shape in lock-step: every launch below carries all ng parameter blocks.
-static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W, int ldo, int train, hipStream_t s) {
+static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W, int ldo, int train, hipStream_t s, const Dp& dp = Dp()) {
     Plan P;
     if (!make_plan(P, B, D, H, W) || ng < 1 || ng > MMS_MAX_GROUP) return MMS_ERR_ARG;
+    if ((dp.hook || dp.bn_world > 1) && (ng != 1 || !train)) return MMS_ERR_ARG;
+    const int bw = dp.bn_world;        // BatchNorm statistics are taken over bw * M rows (SyncBN: the hook has summed them over the ranks)
     FOR_G if (!cx[g].ws || !cx[g].x || !cx[g].prm || !cx[g].out) return MMS_ERR_ARG;
     const void* tabs[MMS_MAX_GROUP];
     if (train) {
@@ -281,12 +303,14 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
                               st(c.ws, P.st_y0, 64, 0, false), st(c.ws, P.st_y0, 64, 0, true)};
             c0[g].srep = P.R0; c0[g].sstride = 2 * 64;
             pf[g] = PoolFwdP{at<float>(c.ws, P.y0), P.g0, P.g[0], B, at<float>(c.ws, P.slab[0]), CTOT[0], at<uint8_t>(c.ws, P.argmax),
-                             mk_bn(c.ws, P.st_y0, 64, c.prm, IDX.n0w, c.buf, IDX.bn0, P.M0, train, P.R0),
+                             mk_bn(c.ws, P.st_y0, 64, c.prm, IDX.n0w, c.buf, IDX.bn0, P.M0 * bw, train, P.R0),
                              st(c.ws, P.st_slab[0], CTOT[0], 0, false), st(c.ws, P.st_slab[0], CTOT[0], 0, true)};
             pf[g].srep = P.R[0]; pf[g].sstride = 2 * CTOT[0];
         }
         TRY(mms_conv0_fwd_group(c0, ng, s));
+        SYNC(at<double>(cx[0].ws, P.st_y0), P.R0, 2 * 64, 64, 64);
         TRY(mms_pool_fwd_group(pf, ng, s));
+        SYNC(at<double>(cx[0].ws, P.st_slab[0]), P.R[0], 2 * CTOT[0], 64, CTOT[0]);
     }
     int l = 0;
     for (int b = 0; b < NB; ++b) {
@@ -304,18 +328,20 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
                 const Ctx& c = cx[g];
                 float* slab = at<float>(c.ws, P.slab[b]);
                 c1[g] = Conv1FwdP{slab, CTOT[b], P.M[b], C, c.prm[ip + 2], 128, at<float>(c.ws, P.y1[l]), 128,
-                                  mk_bn(c.ws, P.st_slab[b], CTOT[b], c.prm, ip, c.buf, IDX.bn_layer1[l], P.M[b], train, P.R[b]),
+                                  mk_bn(c.ws, P.st_slab[b], CTOT[b], c.prm, ip, c.buf, IDX.bn_layer1[l], P.M[b] * bw, train, P.R[b]),
                                   st(c.ws, P.st_y1[l], 128, 0, false), st(c.ws, P.st_y1[l], 128, 0, true), 0, Dims3{0, 0, 0}};
                 c1[g].srep = P.R[b]; c1[g].sstride = 2 * 128;
                 if (ks1 > 1) { c1[g].partial = at<float>(c.ws, P.partial); c1[g].ksplit = ks1; c1[g].counters = at<unsigned>(c.ws, P.counters); }
                 c3[g] = Conv3FwdP{at<float>(c.ws, P.y1[l]), at<int>(c.ws, P.coords[b]), P.g[b], P.M[b], at<float>(c.ws, P.wpf[l]),
-                                  slab + C, CTOT[b], mk_bn(c.ws, P.st_y1[l], 128, c.prm, ip + 3, c.buf, IDX.bn_layer2[l], P.M[b], train, P.R[b]),
+                                  slab + C, CTOT[b], mk_bn(c.ws, P.st_y1[l], 128, c.prm, ip + 3, c.buf, IDX.bn_layer2[l], P.M[b] * bw, train, P.R[b]),
                                   st(c.ws, P.st_slab[b], CTOT[b], C, false), st(c.ws, P.st_slab[b], CTOT[b], C, true),
                                   ns3 > 1 ? at<float>(c.ws, P.partial) : nullptr, ns3};
                 c3[g].srep = P.R[b]; c3[g].sstride = 2 * CTOT[b];
             }
             TRY(mms_conv1_fwd_group(c1, ng, s));
+            SYNC(at<double>(cx[0].ws, P.st_y1[l]), P.R[b], 2 * 128, 128, 128);
             TRY(mms_conv3_fwd_group(c3, ng, s));
+            SYNC(at<double>(cx[0].ws, P.st_slab[b]) + C, P.R[b], 2 * CTOT[b], 32, CTOT[b]);
         }
         if (b < 3) {
             const int ip = IDX.trans[b];
@@ -324,18 +350,19 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
                 const Ctx& c = cx[g];
                 t[g] = Conv1FwdP{at<float>(c.ws, P.slab[b]), CTOT[b], P.M[b + 1], CTOT[b], c.prm[ip + 2], CTOT[b] / 2,
                                  at<float>(c.ws, P.slab[b + 1]), CTOT[b + 1],
-                                 mk_bn(c.ws, P.st_slab[b], CTOT[b], c.prm, ip, c.buf, IDX.bn_trans[b], P.M[b], train, P.R[b]),
+                                 mk_bn(c.ws, P.st_slab[b], CTOT[b], c.prm, ip, c.buf, IDX.bn_trans[b], P.M[b] * bw, train, P.R[b]),
                                  st(c.ws, P.st_slab[b + 1], CTOT[b + 1], 0, false), st(c.ws, P.st_slab[b + 1], CTOT[b + 1], 0, true), 1, P.g[b]};
                 t[g].srep = P.R[b + 1]; t[g].sstride = 2 * CTOT[b + 1];
             }
             TRY(mms_conv1_fwd_group(t, ng, s));
+            SYNC(at<double>(cx[0].ws, P.st_slab[b + 1]), P.R[b + 1], 2 * CTOT[b + 1], CTOT[b] / 2, CTOT[b + 1]);
         }
     }
     HeadFwdP hd[MMS_MAX_GROUP];
     FOR_G {
         const Ctx& c = cx[g];
         hd[g] = HeadFwdP{at<float>(c.ws, P.slab[3]), CTOT[3], 1024, B, P.M[3] / B,
-                         mk_bn(c.ws, P.st_slab[3], CTOT[3], c.prm, IDX.n5w, c.buf, IDX.bn5, P.M[3], train, P.R[3]),
+                         mk_bn(c.ws, P.st_slab[3], CTOT[3], c.prm, IDX.n5w, c.buf, IDX.bn5, P.M[3] * bw, train, P.R[3]),
                          c.prm[IDX.outw], c.prm[IDX.outb], 128, at<float>(c.ws, P.pooled), c.out, ldo};
     }
     TRY(mms_head_fwd_group(hd, ng, s));
@@ -350,22 +377,33 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
 // Backward of the training-mode forward that last ran on these workspaces.  grads are ACCUMULATED into
 // (caller zeroes them, e.g. one hipMemsetAsync over a flat gradient buffer).  dout: [B][128] per model.
 static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W, int lddout, hipStream_t s, hipStream_t side,
-                               hipEvent_t ev_fork, hipEvent_t ev_join) {
+                               hipEvent_t ev_fork, hipEvent_t ev_join, const Dp& dp = Dp()) {
     hipStream_t sw = side ? side : s;       // stream of the weight-gradient kernels
     bool side_pending = false;
     Plan P;
     if (!make_plan(P, B, D, H, W) || ng < 1 || ng > MMS_MAX_GROUP) return MMS_ERR_ARG;
     FOR_G if (!cx[g].ws || !cx[g].x || !cx[g].prm || !cx[g].dout || !cx[g].grd) return MMS_ERR_ARG;
+    if ((dp.hook || dp.bn_world > 1) && ng != 1) return MMS_ERR_ARG;
+    if (dp.b_hi < dp.b_lo || dp.b_hi >= NB || dp.b_lo < 0) return MMS_ERR_ARG;
+    const int bnw = dp.bn_world;
+    const bool sync = dp.hook != nullptr || bnw > 1;
     auto bbsrc = [&](void* ws, size_t off, int stride, int nrep) { return BnBwd{at<double>(ws, off), at<double>(ws, off) + stride, nrep, 2 * stride}; };
-    {
+    if (dp.b_hi == NB - 1) {
         HeadBwdP hb[MMS_MAX_GROUP];
         FOR_G {
             const Ctx& c = cx[g];
             hb[g] = HeadBwdP{c.dout, lddout, at<float>(c.ws, P.pooled), at<float>(c.ws, P.slab[3]), CTOT[3], 1024, B, P.M[3] / B,
-                             mk_bn(c.ws, P.st_slab[3], CTOT[3], c.prm, IDX.n5w, nullptr, 0, P.M[3], 1, P.R[3]), c.prm[IDX.outw], 128,
+                             mk_bn(c.ws, P.st_slab[3], CTOT[3], c.prm, IDX.n5w, nullptr, 0, P.M[3] * bnw, 1, P.R[3]), c.prm[IDX.outw], 128,
                              c.grd[IDX.outw], c.grd[IDX.outb], c.grd[IDX.n5w], c.grd[IDX.n5b], at<float>(c.ws, P.dslab[3]), CTOT[3]};
         }
-        TRY(mms_head_bwd_group(hb, ng, s));
+        if (sync) {     // norm5's backward sums must span all ranks: sums kernel | all-reduce | apply kernel
+            hb[0].ext_sums = at<double>(cx[0].ws, P.bb_head);
+            TRY(mms_head_bwd_sums(hb, s));
+            SYNC(at<double>(cx[0].ws, P.bb_head), 1, 2 * 1024, 1024, 1024);
+            TRY(mms_head_bwd_apply(hb, s));
+        } else {
+            TRY(mms_head_bwd_group(hb, ng, s));
+        }
     }
     // Weight gradients are off the backward's critical chain (nothing reads them before the optimiser).  In blocks 2-4 a
     // layer's two weight-gradient launches are far too small to fill the chip (27-216 workgroups per model), so they are
@@ -374,7 +412,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
     // layers only add into columns < C_l), y1 / the statistic accumulators are per layer, and dbn_mid is per layer there.
     // MMS_BATCH_W=0 restores one launch pair per layer.
     const char* ebw = getenv("MMS_BATCH_W");
-    const bool batch_w = !(ebw && ebw[0] == '0') && !side;
+    const bool batch_w = !(ebw && ebw[0] == '0') && !side;      // (fine under SyncBN too: the sums the weight kernels read are all-reduced by then)
     Conv3BwdWP bwq[MMS_MAX_GROUP];
     Conv1BwdP c1q[MMS_MAX_GROUP];
     int nq = 0;
@@ -386,13 +424,14 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
         return MMS_OK;
     };
     int l = NLAYER;
-    for (int b = NB - 1; b >= 0; --b) {
+    for (int b = NB - 1; b > dp.b_hi; --b) l -= LAYERS[b];
+    for (int b = dp.b_hi; b >= dp.b_lo; --b) {
         int C = CTOT[b];
         const int M = P.M[b];
         const bool defer = batch_w && b > 0 && 2 * ng <= MMS_MAX_GROUP;
         // blocks of <= 128 rows: norm1's backward rides in conv1_bwd_data's epilogue (Conv1BwdP.fuse_dx), no mms_bn_bwd_apply launch
         const char* efa = getenv("MMS_FUSE_APPLY");
-        const bool fuse_apply = M <= 128 && !(efa && efa[0] == '0');
+        const bool fuse_apply = M <= 128 && !(efa && efa[0] == '0') && !sync;      // SyncBN: the sums leave the workgroup (all-reduce) before they are applied
         for (int i = LAYERS[b] - 1; i >= 0; --i) {
             --l; C -= 32;
             const int ip = IDX.layer[l];
@@ -417,8 +456,8 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
                 float* slab = at<float>(c.ws, P.slab[b]);
                 float* dslab = at<float>(c.ws, P.dslab[b]);
                 float* dmid = at<float>(c.ws, P.dbn_mid_l[l]);
-                const BnSrc bn1 = mk_bn(c.ws, P.st_slab[b], CTOT[b], c.prm, ip, nullptr, 0, M, 1, P.R[b]);
-                const BnSrc bn2 = mk_bn(c.ws, P.st_y1[l], 128, c.prm, ip + 3, nullptr, 0, M, 1, P.R[b]);
+                const BnSrc bn1 = mk_bn(c.ws, P.st_slab[b], CTOT[b], c.prm, ip, nullptr, 0, M * bnw, 1, P.R[b]);
+                const BnSrc bn2 = mk_bn(c.ws, P.st_y1[l], 128, c.prm, ip + 3, nullptr, 0, M * bnw, 1, P.R[b]);
                 bd[g] = Conv3BwdDataP{dslab + C, CTOT[b], at<int>(c.ws, P.coords[b]), P.g[b], M, at<float>(c.ws, P.wpb[l]),
                                       at<float>(c.ws, P.y1[l]), bn2, dmid,
                                       at<double>(c.ws, P.bb_y1[l]), at<double>(c.ws, P.bb_y1[l]) + 128,
@@ -448,6 +487,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
                 side_pending = false;
             }
             TRY(mms_conv3_bwd_data_group(bd, ng, s));
+            SYNC(at<double>(cx[0].ws, P.bb_y1[l]), P.R[b], 2 * 128, 128, 128);
             if (defer) {
                 if (nq + ng > MMS_MAX_GROUP) TRY(flush_w());
                 FOR_G { bwq[nq] = bw[g]; c1q[nq] = c1[g]; ++nq; }
@@ -463,6 +503,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
                 }
             }
             TRY(mms_conv1_bwd_data_group(c1, ng, s));
+            SYNC(at<double>(cx[0].ws, P.bb_in[l]), P.R[b], 2 * 1024, C, 1024);
             if (!fuse_apply) TRY(mms_bn_bwd_apply_group(ap, ng, s));
         }
         TRY(flush_w());
@@ -477,7 +518,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
             BnBwdApplyP ap[MMS_MAX_GROUP];
             FOR_G {
                 const Ctx& c = cx[g];
-                const BnSrc bnt = mk_bn(c.ws, P.st_slab[t], CTOT[t], c.prm, ip, nullptr, 0, Mp, 1, P.R[t]);
+                const BnSrc bnt = mk_bn(c.ws, P.st_slab[t], CTOT[t], c.prm, ip, nullptr, 0, Mp * bnw, 1, P.R[t]);
                 Conv1BwdP& q = c1[g];
                 q = Conv1BwdP{};
                 q.dyraw = at<float>(c.ws, P.dslab[b]); q.lddy = CTOT[b]; q.y = nullptr; q.ldy = 0; q.has_bn_out = 0;
@@ -495,6 +536,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
             }
             TRY(mms_conv1_bwd_weight_group(c1, ng, s));
             TRY(mms_conv1_bwd_data_group(c1, ng, s));
+            SYNC(at<double>(cx[0].ws, P.bb_tr[t]), P.R[t], 2 * 1024, Kp, 1024);
             TRY(mms_bn_bwd_apply_group(ap, ng, s));
         } else {       // stem
             int ms0 = P.M0 / 1024; if (ms0 < 1) ms0 = 1; if (ms0 > 64) ms0 = 64;
@@ -502,7 +544,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
             Conv0BwdWP cw[MMS_MAX_GROUP];
             FOR_G {
                 const Ctx& c = cx[g];
-                const BnSrc bn0 = mk_bn(c.ws, P.st_y0, 64, c.prm, IDX.n0w, nullptr, 0, P.M0, 1, P.R0);
+                const BnSrc bn0 = mk_bn(c.ws, P.st_y0, 64, c.prm, IDX.n0w, nullptr, 0, P.M0 * bnw, 1, P.R0);
                 pb[g] = PoolBwdP{at<float>(c.ws, P.dslab[0]), CTOT[0], at<uint8_t>(c.ws, P.argmax), P.g[0], P.g0, B, at<float>(c.ws, P.y0), bn0,
                                  at<float>(c.ws, P.dbn0), at<double>(c.ws, P.bb_y0), at<double>(c.ws, P.bb_y0) + 64, at<int>(c.ws, P.coords0)};
                 pb[g].srep = P.R0; pb[g].sstride = 2 * 64;
@@ -510,24 +552,28 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
                                    at<int>(c.ws, P.coords0), P.M0, c.grd[IDX.conv0], ms0, c.grd[IDX.n0w], c.grd[IDX.n0b]};
             }
             TRY(mms_pool_bwd_group(pb, ng, s));
+            SYNC(at<double>(cx[0].ws, P.bb_y0), P.R0, 2 * 64, 64, 64);
             TRY(mms_conv0_bwd_weight_group(cw, ng, s));
         }
     }
     if (side && side_pending) {
         if (hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) return MMS_ERR_LAUNCH;
     }
-    {   // tap-major scratch -> canonical conv2 gradients, one launch for the group (the dwp regions are consecutive takes)
+    {   // tap-major scratch -> canonical conv2 gradients of the layers this call processed: one launch for the group
+        // (the dwp regions are consecutive takes)
         static_assert(NLAYER == 58, "UnpackGroup is sized for DenseNet121");
+        int l0 = 0, nl = 0;
+        for (int b = 0; b < NB; ++b) { if (b < dp.b_lo) l0 += LAYERS[b]; else if (b <= dp.b_hi) nl += LAYERS[b]; }
         const float* scr[MMS_MAX_GROUP];
         float* dwt[MMS_MAX_GROUP][NLAYER];
         float* const* dwp_[MMS_MAX_GROUP];
         if (P.dwp[1] - P.dwp[0] != (size_t)27 * 32 * 128 * 4) return MMS_ERR_ARG;
         FOR_G {
-            scr[g] = at<float>(cx[g].ws, P.dwp[0]);
-            for (int i = 0; i < NLAYER; ++i) dwt[g][i] = cx[g].grd[IDX.layer[i] + 5];
+            scr[g] = at<float>(cx[g].ws, P.dwp[l0]);
+            for (int i = 0; i < nl; ++i) dwt[g][i] = cx[g].grd[IDX.layer[l0 + i] + 5];
             dwp_[g] = dwt[g];
         }
-        TRY(mms_unpack_conv3_grads_group(scr, dwp_, ng, NLAYER, s));
+        TRY(mms_unpack_conv3_grads_group(scr, dwp_, ng, nl, s));
     }
     return MMS_OK;
 }
@@ -548,6 +594,24 @@ extern "C" int mms_dn121_backward_mt(void* ws, int B, int D, int H, int W, const
     if (!side || !ev_fork || !ev_join) return MMS_ERR_ARG;
     Ctx c{ws, x, (const float* const*)params, nullptr, nullptr, dout, (float* const*)grads};
     return dn121_backward_impl(&c, 1, B, D, H, W, lddout, s, side, ev_fork, ev_join);
+}
+
+// Data-parallel variants of the single-model drivers (one process per GPU; include/mmsurv.h).
+extern "C" int mms_dn121_forward_sync(void* ws, int B, int D, int H, int W, const float* x, const void* const* params_,
+                                      const void* const* buffers, float* out, int ldo, int bn_world, mms_sync_fn hook, void* user,
+                                      hipStream_t s) {
+    if (bn_world < 1) return MMS_ERR_ARG;
+    Ctx c{ws, x, (const float* const*)params_, buffers, out, nullptr, nullptr};
+    Dp dp; dp.bn_world = bn_world; dp.hook = hook; dp.user = user;
+    return dn121_forward_impl(&c, 1, B, D, H, W, ldo, 1, s, dp);
+}
+extern "C" int mms_dn121_backward_stage(void* ws, int B, int D, int H, int W, const float* x, const void* const* params,
+                                        const float* dout, int lddout, void* const* grads, int block_hi, int block_lo,
+                                        int bn_world, mms_sync_fn hook, void* user, hipStream_t s) {
+    if (bn_world < 1) return MMS_ERR_ARG;
+    Ctx c{ws, x, (const float* const*)params, nullptr, nullptr, dout, (float* const*)grads};
+    Dp dp; dp.bn_world = bn_world; dp.hook = hook; dp.user = user; dp.b_hi = block_hi; dp.b_lo = block_lo;
+    return dn121_backward_impl(&c, 1, B, D, H, W, lddout, s, nullptr, nullptr, nullptr, dp);
 }
 
 // Fold-group drivers: model g of the group is described by the g-th entry of each array (all models share B, D, H, W).

@@ -5,9 +5,10 @@ Two ways the path shards:
     result records are gathered at the end (`gather_fold_results`).  Reproduces single-GPU results exactly.
   * patient/batch level (DDP): each rank steps on its shard of the global batch; the flat gradient buffer is
     all-reduced (SUM then /world) between backward and the clip+Adam kernels (`allreduce_mean_`), one collective of
-    56 MB instead of 364 small ones.  Cox risk set: rank-local (default), or GLOBAL over the world*B patients of the step
-    (`train_step(..., ddp_world=N, global_cox=True)`: all-gather of hazards/times/events, every rank evaluates the global
-    loss and back-propagates its own slice, gradients are SUMMED).  BatchNorm statistics stay rank-local.
+    all-reduced (SUM) in 5 buckets -- heads, then the DenseNet121 backward stages 3..0 -- each launched asynchronously as soon as
+    its stage has been enqueued (`allreduce_ranges_async`), overlapping the rest of the backward; the update waits for them.
+    Cox risk set: rank-local (default), or GLOBAL over the world*B patients of the step (`train_step(..., ddp_world=N,
+    global_cox=True)`).  BatchNorm: rank-local, or `sync_bn=True` = exact global-batch semantics (engine._ddp_step_syncbn).
 """
 import os
 
@@ -85,6 +86,26 @@ def allreduce_mean_(flat, world):
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat.div_(world)
     return flat
+
+
+def allreduce_ranges_async(flat, ranges, world):
+    """SUM over ranks of the slices flat[a:a+n] of one gradient bucket, launched asynchronously: RCCL runs the collective on its
+    own stream behind the work already enqueued on the current stream, so it overlaps whatever the caller enqueues next.
+    -> a callable that makes the CURRENT stream wait for the bucket.  (gloo rehearsal path: synchronous, through host memory.)"""
+    if world <= 1:
+        return lambda: None
+    if flat.is_cuda and dist.get_backend() == "gloo":
+        for a, n in ranges:
+            h = flat[a:a + n].cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            flat[a:a + n].copy_(h)
+        return lambda: None
+    works = [dist.all_reduce(flat[a:a + n], op=dist.ReduceOp.SUM, async_op=True) for a, n in ranges]
+
+    def wait():
+        for w in works:
+            w.wait()
+    return wait
 
 
 def max_over_ranks(x, device):

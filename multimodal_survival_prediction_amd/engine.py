@@ -178,9 +178,11 @@ class SurvivalEngine:
             p.grad = g
 
     # ---- plans -----------------------------------------------------------------------------------
-    def plan(self, B, dims):
+    def plan(self, B, dims, heads_only=False, bn_world=1):
+        """heads_only: no encoder workspace (the replicated global-batch heads of the SyncBN data-parallel step: the encoder's
+        128 feature columns are filled by an all-gather); bn_world: ranks the encoder's BatchNorm statistics span."""
         dims = tuple(dims) if dims is not None else ()
-        key = (B,) + dims
+        key = (B,) + dims + (("heads",) if heads_only else ()) + ((("bnw", bn_world),) if bn_world > 1 else ())
         if key in self.plans:
             return self.plans[key]
         self._check_params()
@@ -188,7 +190,8 @@ class SurvivalEngine:
         P.B, P.dims = B, dims
         dev = self.device
         prog = self.prog
-        P.has_enc = prog["encoder"] is not None
+        P.has_enc = prog["encoder"] is not None and not heads_only
+        P.bn_world = bn_world
         D, H, W = dims if P.has_enc else (1, 1, 1)
         P.ct = torch.zeros(B, 1, D, H, W, device=dev)
         P.big = B > 32                 # rows beyond the one-lane-per-column head kernels: MFMA GEMM path (mms_linear_big_*)
@@ -223,9 +226,12 @@ class SurvivalEngine:
             P.btab = (ctypes.c_void_p * nbuf)(*[b.data_ptr() for b in ebufs])
             P.gtab = (ctypes.c_void_p * npar)(*[gmap[id(p)].data_ptr() for p in eparams])
             if P.fallback:
+                if bn_world > 1:
+                    raise RuntimeError("SyncBN drives the DenseNet121-3D encoder only")
                 _lib.check(self.lib.mms_fb_init(P.ws.data_ptr(), B, D, H, W, P.btab, ops.stream()), "mms_fb_init")
             else:
-                _lib.check(self.lib.mms_dn121_init(P.ws.data_ptr(), B, D, H, W, P.ptab, P.btab, ops.stream()), "mms_dn121_init")
+                _lib.check(self.lib.mms_dn121_init_sync(P.ws.data_ptr(), B, D, H, W, P.ptab, P.btab, bn_world, ops.stream()),
+                           "mms_dn121_init_sync")
         # head launches (train / eval variants)
         P.lin_fwd = {True: [], False: []}
         P.lin_bwd = []
@@ -378,6 +384,11 @@ class SurvivalEngine:
 
     def _backward_from_dhz(self, P):
         """dbuf['hz'] holds dL/dhazard; accumulates every parameter gradient into gflat."""
+        self._backward_heads(P)
+        self._backward_encoder(P)
+
+    def _backward_heads(self, P):
+        """Heads' backward: dbuf['hz'] -> every head parameter gradient and dbuf['feats'] (gradient wrt the encoder's output)."""
         st = ops.stream()
         lib, prog = self.lib, self.prog
         B, (D, H, W) = P.B, (P.dims if P.has_enc else (1, 1, 1))
@@ -398,10 +409,23 @@ class SurvivalEngine:
             _lib.check(lib.mms_missing_mix_bwd(ctypes.byref(P.mix), st), "mms_missing_mix_bwd")
         for i in range(n_pre - 1, -1, -1):
             _lib.check(lib.mms_linear_bwd(ctypes.byref(P.lin_bwd[i]), st), "mms_linear_bwd")
+
+    def _backward_encoder(self, P, stage=None, hook=None):
+        """Encoder backward from dbuf['feats'].  stage = (block_hi, block_lo): one stage of the DenseNet121 backward
+        (mms_dn121_backward_stage; the data-parallel step all-reduces each stage's gradient bucket while the next stage runs);
+        hook: SyncBN statistics all-reduce (P.bn_world ranks)."""
         if not P.has_enc:
             return
+        st = ops.stream()
+        lib, prog = self.lib, self.prog
+        B, (D, H, W) = P.B, P.dims
         dfe = P.dbuf["feats"]
         dct = dfe[:, prog["ct_cols"]:]
+        if stage is not None or hook is not None or P.bn_world > 1:
+            hi, lo = stage if stage is not None else (3, 0)
+            _lib.check(lib.mms_dn121_backward_stage(P.ws.data_ptr(), B, D, H, W, P.ct.data_ptr(), P.ptab, dct.data_ptr(), dfe.stride(0),
+                                                    P.gtab, hi, lo, P.bn_world, hook, None, st), "mms_dn121_backward_stage")
+            return
         # The weight-gradient fork (mms_dn121_backward_mt) is off by default: measured, it neither helps a single chain
         # (graph branches run mostly serially) nor concurrent fold models (it takes hardware queues away from them).
         if os.environ.get("MMS_SIDE_STREAM") != "1" and not P.fallback:
@@ -438,12 +462,29 @@ class SurvivalEngine:
             self.sumsq.zero_()
             self._forward(P, True)
             return
-        if part == "coxbwd":                   # ... second third: loss over the gathered world*B hazards, own slice of dL/dh
+        if part in ("coxbwd", "coxheads"):     # ... loss over the gathered world*B hazards, own slice of dL/dh [, heads only]
             G = P.gcox
             _lib.check(lib.mms_cox_fwd_bwd(ctypes.byref(G["cox"]), st), "mms_cox_fwd_bwd")
             P.dbuf["hz"][:, 0].copy_(G["dh"][G["rank"] * P.B:(G["rank"] + 1) * P.B])
-            self._backward_from_dhz(P)
+            if part == "coxheads":
+                self._backward_heads(P)
+            else:
+                self._backward_from_dhz(P)
             return
+        if part == "gradheads":                # rank-local risk set: zero-grad, forward, Cox, heads' backward
+            self.gflat.zero_()
+            self.sumsq.zero_()
+            self._forward(P, True)
+            _lib.check(lib.mms_cox_fwd_bwd(ctypes.byref(P.cox), st), "mms_cox_fwd_bwd")
+            self._backward_heads(P)
+            return
+        if isinstance(part, tuple) and part[0] == "enc":      # one stage of the encoder backward (None = all of it)
+            self._backward_encoder(P, stage=None if part[1] is None else (part[1], part[1]))
+            return
+        if isinstance(part, tuple) and part[0] == "update":   # gradients arrived as a SUM over ranks: scale (mean for rank-local losses)
+            if part[1] != 1.0:
+                self.gflat.mul_(part[1])
+            part = "update"
         if part in ("all", "grad"):
             self.gflat.zero_()
             self.sumsq.zero_()
@@ -509,59 +550,17 @@ class SurvivalEngine:
                    use_graph=True, ddp_world=1, global_cox=False, sync_bn=False):
         """One optimisation step on one batch (inputs may live on host or device).  Returns nothing: losses are
         accumulated on the device (`epoch_stats()`), exactly one host sync per epoch instead of one per batch.
-        ddp_world > 1: data-parallel step -- this rank's shard of the global batch; the flat gradient buffer is averaged
-        over ranks (ONE all-reduce of the contiguous 56-69 MB buffer) between the backward and the clip+Adam kernels.
-        BatchNorm statistics and the Cox risk set stay rank-local."""
+        ddp_world > 1: data-parallel step on this rank's shard of the global batch (`_ddp_step`: bucketed gradient all-reduce
+        overlapped with the backward; rank-local BatchNorm; rank-local or global_cox risk sets), or with sync_bn=True the exact
+        global-batch step (`_ddp_step_syncbn`: SyncBN + replicated heads + global risk set; eager launches)."""
         B = rna.shape[0]
-        P = self.plan(B, tuple(ct.shape[-3:]) if ct is not None else None)
+        P = self.plan(B, tuple(ct.shape[-3:]) if ct is not None else None, bn_world=ddp_world if (sync_bn and ddp_world > 1) else 1)
         self.load_batch(P, ct, rna, clinical, mask, time, event, valid)
-        if sync_bn:
-            raise NotImplementedError("sync_bn")
-        if ddp_world > 1 and global_cox:
-            # Cox is batch-coupled: for parity with ONE process stepping on the world*B patients, the risk sets must span all
-            # ranks (SURVEY 8e ii).  [zero-grad, forward] | all-gather (h, time, event, valid) | [global Cox -> dL/dh of all
-            # world*B hazards, own slice -> backward] | all-reduce SUM of the flat gradients | [clip, Adam]
-            from . import distributed as D
-            import torch.distributed as dist
-            G = self._global_cox_buffers(P, ddp_world)
-            G["rank"] = dist.get_rank() if dist.is_initialized() else 0
-
-            def sequence(run):
-                run("fwd")
-                D.all_gather_into(G["h"], P.buf["hz"][:, 0], ddp_world)
-                D.all_gather_into(G["time"], P.time, ddp_world); D.all_gather_into(G["event"], P.event, ddp_world)
-                D.all_gather_into(G["valid"], P.valid, ddp_world)
-                run("coxbwd")
-                D.allreduce_sum_(self.gflat, ddp_world)
-                run("update")
-            if not use_graph:
-                sequence(lambda part: self._train_body(P, False, part))
-                return
-            if ("fwd", False) not in P.graphs or ("coxbwd", False) not in P.graphs:
-                # the parts depend on each other through the workspace (statistic accumulators are zeroed by "fwd" only), so
-                # they are warmed up as ONE eager step, rolled back, and then captured without being executed
-                state = [self.flat.clone(), self.m.clone(), self.v.clone(), self.step_count.clone(), self.rng.clone(),
-                         self.acc.clone(), [b.clone() for b in self.model.buffers()]]
-                sequence(lambda part: self._train_body(P, False, part))
-                torch.cuda.synchronize()
-                with torch.no_grad():
-                    self.flat.copy_(state[0]); self.m.copy_(state[1]); self.v.copy_(state[2])
-                    self.step_count.copy_(state[3]); self.rng.copy_(state[4]); self.acc.copy_(state[5])
-                    for b, b0 in zip(self.model.buffers(), state[6]):
-                        b.copy_(b0)
-                for part in ("fwd", "coxbwd", "update"):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
-                        self._train_body(P, False, part)
-                    P.graphs[(part, False)] = g
-            sequence(lambda part: P.graphs[(part, False)].replay())
+        if ddp_world > 1 and sync_bn:
+            self._ddp_step_syncbn(P, ddp_world)
             return
         if ddp_world > 1:
-            from . import distributed as D
-            # a usable/unusable decision must be common to all ranks, otherwise Adam states diverge: DDP never skips
-            self._run_part(P, ("grad", False), use_graph)
-            D.allreduce_mean_(self.gflat, ddp_world)
-            self._run_part(P, ("update", False), use_graph)
+            self._ddp_step(P, ddp_world, global_cox, use_graph)
             return
         if not use_graph:
             self._train_body(P, skip_if_unusable)
@@ -593,36 +592,184 @@ class SurvivalEngine:
                     b.copy_(b0)
         P.graphs[key].replay()
 
-    def _run_part(self, P, key, use_graph):
-        part, skip = key
-        if not use_graph:
-            self._train_body(P, skip, part)
-            return
-        if key not in P.graphs:
-            state = [self.flat.clone(), self.m.clone(), self.v.clone(), self.step_count.clone(), self.rng.clone(),
-                     self.acc.clone(), [b.clone() for b in self.model.buffers()], self.gflat.clone()]
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                self._train_body(P, skip, part)
-            torch.cuda.current_stream().wait_stream(s)
-            torch.cuda.synchronize()
+    # ---- data-parallel step (one process per GPU) --------------------------------------------------------
+    ENC_STAGE_CUTS = (0, 39, 114, 261, 364)     # dn_net.hip Idx: parameter-table index where dense block b's stage begins (b = 0..3)
 
-            def restore():
-                with torch.no_grad():
-                    self.flat.copy_(state[0]); self.m.copy_(state[1]); self.v.copy_(state[2])
-                    self.step_count.copy_(state[3]); self.rng.copy_(state[4]); self.acc.copy_(state[5])
-                    for b, b0 in zip(self.model.buffers(), state[6]):
-                        b.copy_(b0)
-                    if part == "update":
-                        self.gflat.copy_(state[7])
-            restore()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._train_body(P, skip, part)
-            P.graphs[key] = g
-            restore()
-        P.graphs[key].replay()
+    def _buckets(self, P):
+        """Gradient buckets in the order the backward finalises them: the heads, then the DenseNet121 stages 3, 2, 1, 0 (each a
+        contiguous range of the flat buffer -- parameters are laid out in module order).  -> [[(offset, length), ...], ...]"""
+        if getattr(self, "_bucket_cache", None) is None:
+            offs, o = {}, 0
+            for q in self.params:
+                offs[id(q)] = (o, q.numel())
+                o += q.numel()
+
+            def ranges(ids):
+                out = []
+                for a, n in sorted(offs[i] for i in ids):
+                    if out and out[-1][0] + out[-1][1] == a:
+                        out[-1] = (out[-1][0], out[-1][1] + n)
+                    else:
+                        out.append((a, n))
+                return out
+            enc = self.prog["encoder"]
+            eids = [id(q) for q in enc.parameters()] if enc is not None else []
+            eset = set(eids)
+            hids = [id(q) for q in self.params if id(q) not in eset]
+            staged = enc is not None and not isinstance(enc, nn.Sequential)
+            if staged:
+                c = self.ENC_STAGE_CUTS
+                self._bucket_cache = (True, [ranges(hids)] + [ranges(eids[c[b]:c[b + 1]]) for b in (3, 2, 1, 0)])
+            else:
+                self._bucket_cache = (False, [ranges(hids + eids)])
+        return self._bucket_cache
+
+    def _ddp_sequence(self, P, global_cox):
+        """The step as a list of ("part", name) compute pieces (each one HIP graph) and communication points."""
+        staged, buckets = self._buckets(P)
+        seq = [("part", "fwd"), ("gather",), ("part", "coxheads")] if global_cox else [("part", "gradheads")]
+        if staged:
+            seq.append(("bucket", 0))
+            for k, b in enumerate((3, 2, 1, 0)):
+                seq += [("part", ("enc", b)), ("bucket", k + 1)]
+        else:
+            seq += [("part", ("enc", None)), ("bucket", 0)]
+        return seq + [("wait",)], buckets
+
+    def _ddp_step(self, P, world, global_cox, use_graph):
+        """Rank-local BatchNorm statistics.  The flat gradient buffer is all-reduced (SUM) bucket by bucket, each bucket launched as
+        soon as the backward stage that finalises it has been enqueued, so the collective of stage k runs beside the kernels of
+        stage k+1 (torch.distributed enqueues an async collective behind the current stream's work and runs it on its own
+        stream; the update waits for all of them).  Rank-local risk sets: gradients are averaged (1/world folded into the update
+        graph).  global_cox: risk sets over the world*B patients (all-gather of hazard/time/event/valid), gradients summed."""
+        from . import distributed as D
+        import torch.distributed as dist
+        seq, buckets = self._ddp_sequence(P, global_cox)
+        upd = ("update", 1.0 if global_cox else 1.0 / world)
+        if global_cox:
+            G = self._global_cox_buffers(P, world)
+            G["rank"] = dist.get_rank() if dist.is_initialized() else 0
+
+        def run(run_part):
+            works = []
+            for item in seq:
+                if item[0] == "part":
+                    run_part(item[1])
+                elif item[0] == "gather":
+                    D.all_gather_into(G["h"], P.buf["hz"][:, 0], world)
+                    D.all_gather_into(G["time"], P.time, world); D.all_gather_into(G["event"], P.event, world)
+                    D.all_gather_into(G["valid"], P.valid, world)
+                elif item[0] == "bucket":
+                    works.append(D.allreduce_ranges_async(self.gflat, buckets[item[1]], world))
+                else:
+                    for w in works:
+                        w()
+            run_part(upd)
+        if not use_graph:
+            run(lambda part: self._train_body(P, False, part))
+            return
+        key0 = ("ddp", global_cox, world)
+        if key0 not in P.graphs:
+            # the parts depend on each other through the workspace (statistic accumulators are zeroed by the first part only), so
+            # they are warmed up as ONE eager step, rolled back, and then captured without being executed
+            state = [self.flat.clone(), self.m.clone(), self.v.clone(), self.step_count.clone(), self.rng.clone(),
+                     self.acc.clone(), [b.clone() for b in self.model.buffers()]]
+            run(lambda part: self._train_body(P, False, part))
+            torch.cuda.synchronize()
+            with torch.no_grad():
+                self.flat.copy_(state[0]); self.m.copy_(state[1]); self.v.copy_(state[2])
+                self.step_count.copy_(state[3]); self.rng.copy_(state[4]); self.acc.copy_(state[5])
+                for b, b0 in zip(self.model.buffers(), state[6]):
+                    b.copy_(b0)
+            graphs = {}
+            for part in [it[1] for it in seq if it[0] == "part"] + [upd]:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._train_body(P, False, part)
+                graphs[part] = g
+            P.graphs[key0] = graphs
+        graphs = P.graphs[key0]
+        run(lambda part: graphs[part].replay())
+
+    def _sync_hook(self, P, world):
+        """mms_sync_fn (include/mmsurv.h) of a plan: all-reduce freshly written BatchNorm accumulator words over the ranks."""
+        if getattr(P, "sync_hook", None) is None:
+            from . import distributed as D
+            base0 = P.ws.data_ptr()
+            ws64 = P.ws[:P.ws.numel() // 8 * 8].view(torch.float64)
+
+            def hook(user, base, nrep, rstride, ncols, pstride, stream):
+                try:
+                    t = ws64.as_strided((nrep, 2, ncols), (rstride, pstride, 1), (base - base0) // 8)
+                    buf = t.contiguous()
+                    D.allreduce_sum_(buf, world)
+                    if buf.data_ptr() != t.data_ptr():
+                        t.copy_(buf)
+                    return 0
+                except Exception as e:      # never raise through the C frame
+                    print("mmsurv: SyncBN hook failed: %r" % (e,), flush=True)
+                    return -2
+            P.sync_hook = _lib.SYNC_FN(hook)
+        return P.sync_hook
+
+    def _ddp_step_syncbn(self, P, world):
+        """Exact single-process semantics for a global batch of world*B patients (SURVEY.md section 8e ii-iii), eager launches:
+          * encoder: every BatchNorm3d statistic (forward sums, backward sums) is all-reduced between the kernel that produces it
+            and the kernels that consume it (the drivers' hook);
+          * heads (BatchNorm1d over the batch, gate, Cox risk set): replicated -- the encoder features and the small per-patient
+            inputs are all-gathered and every rank runs the heads on the GLOBAL batch, then back-propagates its own patients'
+            feature gradient through its encoder;
+          * gradients: encoder weights hold rank-local partial sums -> SUM; head parameters and BatchNorm3d gamma/beta hold the
+            global value on every rank -> pre-scaled by 1/world so that the same SUM returns them; then clip + Adam."""
+        from . import distributed as D
+        import torch.distributed as dist
+        if not P.has_enc or P.fallback:
+            raise RuntimeError("sync_bn: the DenseNet121-3D imaging models only")
+        st = ops.stream()
+        lib, prog = self.lib, self.prog
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        B, (Dd, H, W) = P.B, P.dims
+        Pg = self.plan(world * B, P.dims, heads_only=True)
+        hook = self._sync_hook(P, world)
+        cc = prog["ct_cols"]
+        self.gflat.zero_(); self.sumsq.zero_()
+        feats = P.buf["feats"]
+        _lib.check(lib.mms_dn121_forward_sync(P.ws.data_ptr(), B, Dd, H, W, P.ct.data_ptr(), P.ptab, P.btab, feats[:, cc:].data_ptr(),
+                                              feats.stride(0), world, hook, None, st), "mms_dn121_forward_sync")
+
+        def gather(dst, src):
+            tmp = torch.empty(world * src.shape[0], *src.shape[1:], device=self.device)
+            D.all_gather_into(tmp.view(-1), src.contiguous().view(-1), world)
+            dst.copy_(tmp.view(dst.shape))
+        gather(Pg.buf["feats"][:, cc:cc + 128], feats[:, cc:cc + 128])
+        for name in ("rna", "clin"):
+            if name in P.buf:
+                gather(Pg.buf[name], P.buf[name])
+        if P.gate is not None:
+            gather(Pg.mask, P.mask)
+        if P.mix is not None:
+            gather(Pg.mask2, P.mask2)
+        gather(Pg.time, P.time); gather(Pg.event, P.event); gather(Pg.valid, P.valid)
+        self._forward(Pg, True)                                   # heads only (Pg.has_enc is False)
+        _lib.check(lib.mms_cox_fwd_bwd(ctypes.byref(Pg.cox), st), "mms_cox_fwd_bwd")
+        self._backward_heads(Pg)
+        P.dbuf["feats"][:, cc:cc + 128].copy_(Pg.dbuf["feats"][rank * B:(rank + 1) * B, cc:cc + 128])
+        self._backward_encoder(P, hook=hook)
+        if getattr(self, "_share", None) is None or self._share[0] != world:
+            sh = torch.full_like(self.gflat, 1.0 / world)        # heads + BatchNorm3d parameters: global value on every rank
+            o = 0
+            bn_ids = {id(q) for m in prog["encoder"].modules() if isinstance(m, nn.BatchNorm3d) for q in m.parameters()}
+            eids = {id(q) for q in prog["encoder"].parameters()}
+            for q in self.params:
+                if id(q) in eids and id(q) not in bn_ids:
+                    sh[o:o + q.numel()] = 1.0                    # conv / class_layers weights: rank-local partial sums
+                o += q.numel()
+            self._share = (world, sh)
+        self.gflat.mul_(self._share[1])
+        D.allreduce_sum_(self.gflat, world)
+        ad = Pg.adam
+        _lib.check(lib.mms_grad_sumsq(ctypes.byref(ad), st), "mms_grad_sumsq")
+        _lib.check(lib.mms_clip_adam(ctypes.byref(ad), st), "mms_clip_adam")
 
     def forward_eval(self, ct=None, rna=None, clinical=None, mask=None, use_graph=True):
         """Eval-mode forward -> (hazard [B] view of a static buffer, gate [B,3] or None)."""
