@@ -148,15 +148,13 @@ def roofline_block(B, dims, dev, group_sizes):
     dom = max(fam, key=lambda k: fam[k][0])
     t, f, n = fam[dom]
     traffic = None      # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)
-    for name in ("r02_pmc_conv2_traffic.json", "r01_pmc_conv3bwdw_traffic.json"):
-        try:
-            with open(os.path.join(ROOT, "profiles", name)) as fh:
-                j = json.load(fh)
-            traffic = j.get(dom, j).get("avg_hbm_bytes_per_launch") if isinstance(j.get(dom, j), dict) else None
-            if traffic is not None:
-                break
-        except (OSError, KeyError, ValueError, AttributeError):
-            pass
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_conv2_traffic.json")) as fh:
+            j = json.load(fh)
+        if tuple(j.get("sub_groups", ())) == tuple(group_sizes):          # the committed passes ran on this launch configuration
+            traffic = j[dom]["avg_hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError, TypeError):
+        pass
     return {"bound": "mfma", "kernel": _ROOF_NAMES[dom] + f"; 58 launches per lock-step step and sub-group, sub-groups of {'+'.join(map(str, group_sizes))} fold models per launch",
             "achieved": f / t / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": f / t / 1e12 / PEAK_FP32_MFMA_TFLOPS,
             "traffic": traffic, "avg_launch_us": t / n * 1e6, "avg_flops_per_launch": f / n,

@@ -429,9 +429,12 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
         int C = CTOT[b];
         const int M = P.M[b];
         const bool defer = batch_w && b > 0 && 2 * ng <= MMS_MAX_GROUP;
-        // blocks of <= 128 rows: norm1's backward rides in conv1_bwd_data's epilogue (Conv1BwdP.fuse_dx), no mms_bn_bwd_apply launch
+        // block 4 (<= 32 rows, one MFMA row tile): norm1's backward rides in conv1_bwd_data's epilogue (Conv1BwdP.fuse_dx), no
+        // mms_bn_bwd_apply launch.  (Measured at 128 rows -- block 3, 128 x 32 tiles -- the fused form is slower than the two
+        // launches it replaces: 25 us against 8.8 + 6.7 us, rocprofv3 kernel stats; MMS_FUSE_APPLY=128 selects it anyway.)
         const char* efa = getenv("MMS_FUSE_APPLY");
-        const bool fuse_apply = M <= 128 && !(efa && efa[0] == '0') && !sync;      // SyncBN: the sums leave the workgroup (all-reduce) before they are applied
+        const int fuse_rows = efa ? atoi(efa) : 32;
+        const bool fuse_apply = M <= fuse_rows && M <= 128 && !sync;      // SyncBN: the sums leave the workgroup (all-reduce) before they are applied
         for (int i = LAYERS[b] - 1; i >= 0; --i) {
             --l; C -= 32;
             const int ip = IDX.layer[l];

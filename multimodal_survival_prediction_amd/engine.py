@@ -517,6 +517,27 @@ class SurvivalEngine:
         else:
             P.valid.copy_(valid.reshape(-1).to(torch.float32), non_blocking=True)
 
+    def load_host_rows(self, P, hb):
+        """Batch named by data.HostBatchLoader: one asynchronous host -> device copy per patient row, straight from the pinned cohort
+        into this plan's static input buffers (what the reference's `.to(device)` per batch does, final_multimodal.py:244-247)."""
+        c, jl = hb["host"].c, hb["index"].tolist()
+        for r, q in enumerate(jl):
+            if P.has_enc:
+                P.ct[r].copy_(c["image"][q], non_blocking=True)
+            P.buf["rna"][r].copy_(c["rnaseq"][q], non_blocking=True)
+            if "clin" in P.buf:
+                P.buf["clin"][r].copy_(c["clinical"][q], non_blocking=True)
+            if P.gate is not None:
+                P.mask[r].copy_(c["mask"][q], non_blocking=True)
+            if P.mix is not None:
+                P.mask2[r].copy_(c["mask"][q, :P.mask2.shape[1]], non_blocking=True)
+        sc = hb["scal"]
+        P.time.copy_(sc[0], non_blocking=True); P.event.copy_(sc[1], non_blocking=True)
+        if hb.get("use_valid", True):
+            P.valid.copy_(sc[2], non_blocking=True)
+        else:
+            P.valid.fill_(1.0)
+
     def gather_block(self, P, cohort, idx_dev):
         """GatherP (include/mmsurv.h) that assembles this plan's batch from a device-resident cohort dict
         (data.make_cohort / cohort_to): image, rnaseq, clinical, mask, label[time, event] and, when present, a float

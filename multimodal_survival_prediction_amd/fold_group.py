@@ -199,14 +199,24 @@ class FoldGroupEngine:
         if len(batches) != len(members):
             raise ValueError("one batch per member")
         has_enc = self.engines[0].prog["encoder"] is not None
-        B = batches[0]["rna"].shape[0]
-        dims = tuple(batches[0]["ct"].shape[-3:]) if has_enc else None
-        for b in batches:
-            if b["rna"].shape[0] != B or (has_enc and tuple(b["ct"].shape[-3:]) != dims):
+        host = "host_batch" in batches[0]            # data.HostBatchLoader: rows copied host -> device by load_host_rows
+        if host:
+            B = len(batches[0]["host_batch"]["index"])
+            dims = tuple(batches[0]["host_batch"]["host"].c["image"].shape[-3:]) if has_enc else None
+            if any(len(b["host_batch"]["index"]) != B for b in batches):
                 raise ValueError("fold-group batches must share one shape; split ragged tails into their own step")
+        else:
+            B = batches[0]["rna"].shape[0]
+            dims = tuple(batches[0]["ct"].shape[-3:]) if has_enc else None
+            for b in batches:
+                if b["rna"].shape[0] != B or (has_enc and tuple(b["ct"].shape[-3:]) != dims):
+                    raise ValueError("fold-group batches must share one shape; split ragged tails into their own step")
         GP = self.plan(B, dims, members)
         for e, P, b in zip(GP.eng, GP.Ps, batches):
-            e.load_batch(P, **b)
+            if host:
+                e.load_host_rows(P, b["host_batch"])
+            else:
+                e.load_batch(P, **b)
         if not use_graph:
             self._train_body(GP, skip_if_unusable)
             return
