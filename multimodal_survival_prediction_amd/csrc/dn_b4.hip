@@ -1,0 +1,303 @@
+// Dense block 4 of DenseNet121-3D as ONE launch per pass (forward here) for launches with <= 16 rows per model
+// (batch 4 on 64x64x32 volumes: 4 samples x 2x2x1 voxels).
+//
+// Why: at 16 rows a dense layer is ~5 MFLOP, yet the per-layer launch sequence (conv1 with K-split fixup, conv2 taps, conv2
+// reduce) costs ~21 us of dependent-launch latency per layer and pass (profiles/r02_b_group*_step_breakdown.txt).  Here a
+// CLUSTER of 8 workgroups per model walks the 16 layers inside one launch.  Every workgroup keeps the block's whole activation
+// slab (16 x 1024 fp32 = 64 KB) and the batch statistics of its channels in LDS (100 KB in all); because all rows of the block sit in every
+// workgroup, work is split over OUTPUT CHANNELS / TAPS and never over rows, so each BatchNorm statistic is complete inside the
+// workgroup that needs it.  Per layer two hand-offs between the 8 workgroups (tools/micro/cluster_handoff.hip: ~2.1-2.4 us each):
+//   A. conv1 (norm1-relu-1x1x1 conv): workgroup w computes y1[:, 16w..16w+15] over the full K (v_mfma_f32_16x16x4_f32, K split
+//      over its 4 waves), its BatchNorm2 statistics, writes y1 + statistics for the backward, and PUBLISHES relu(bn2(y1)) (1 KB);
+//      all gather the 16 x 128 result.
+//   B. conv2 (3x3x3, pad 1): the LIVE taps (9 of 27 on a 2x2x1 grid) are dealt over the workgroups; each PUBLISHES its partial
+//      16 x 32 output (2 KB); all gather and add the 8 partials in fixed order (deterministic), append the 32 new channels to their
+//      LDS slab and compute their statistics; workgroup 0 also writes them to the global slab for the rest of the network.
+// Hand-off protocol (MI355X_MICROARCH.md, "Valid forms"): payload with agent-scope relaxed atomic stores (sc1 write-through), every
+// wave s_waitcnt vmcnt(0), workgroup barrier, ONE lane adds to the cluster's monotonic counter and polls it (sc1 loads + s_sleep),
+// workgroup barrier, payload read with agent-scope atomic loads.  The poll is BOUNDED: a workgroup that does not see its cluster
+// arrive within ~2^22 polls raises the error word and leaves, so the grid always drains.  All 8 x ng workgroups are resident at once
+// (<= 80 on 256 CUs); workgroups that start late only make the others wait.
+#include "dn_ops.h"
+
+namespace {
+
+constexpr int B4W = 8;            // workgroups per model
+constexpr int B4R = 16;           // rows (MFMA M)
+constexpr int B4P = 1028;         // LDS row pitch of the slab images (floats): 16 rows x 16 B apart -> conflict-free ds_read_b128
+constexpr int B4A2P = 132;
+
+// arrive: my published stores are acknowledged, then one lane signals.  wait: one lane polls (bounded), everybody learns the outcome.
+// Between the two the caller issues the NEXT phase's weight loads: they land while the cluster is being waited for.
+__device__ __forceinline__ void b4_arrive(unsigned* counter, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's published stores are acknowledged
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool b4_wait(unsigned* counter, unsigned* err, unsigned target, int tid, int* s_ok) {
+    if (tid == 0) {
+        int spins = 0, good = 1;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 22)) { good = 0; atomicExch(err, 1u); break; }
+        }
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) good = 0;
+        *s_ok = good;
+    }
+    __syncthreads();
+    return *s_ok != 0;
+}
+
+__global__ __launch_bounds__(256) void b4_fwd_kernel(const Grp<B4FwdP> grp) {
+    const B4FwdP& p = grp.p[blockIdx.z];
+    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, k4 = lane >> 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;                          // [16][B4P] raw slab (rows >= M stay zero)
+    float* mu = xs + B4R * B4P;                // [1024] batch mean of every slab channel (train)
+    float* rs = mu + 1024;                     // [1024] batch rstd
+    float* mn1 = rs + 1024;                    // [1024] norm1 of the current layer: mean | gamma * rstd | beta
+    float* sc1 = mn1 + 1024;
+    float* be1 = sc1 + 1024;
+    float* a2s = be1 + 1024;                   // [16][B4A2P] gathered relu(bn2(y1))
+    float* red = a2s + B4R * B4A2P;            // [4][256] cross-wave sums, then scratch
+    double* dred = (double*)(red + 1024);      // [2][16][32] column-statistic partials
+    float* c2 = (float*)(dred + 1024);         // [2][32]: mean | rstd of the channels being normalised
+    int* nbt = (int*)(c2 + 64);                // [27][16] neighbour row of (tap, row), -1 = zero padding
+    int* live = nbt + 27 * 16;                 // [0] = number of live taps, [1..] = their indices
+    __shared__ int s_ok;
+    const int M = p.M, C0 = p.C0, ld = p.ld;
+    const float inv_m = 1.0f / (float)M;
+
+    // ---- set-up: slab columns [0, C0) and their statistics, neighbour table, live taps ------------------------------------
+    for (int idx = tid; idx < B4R * ld; idx += 256) {
+        const int m = idx / ld, k = idx - m * ld;
+        xs[m * B4P + k] = (m < M && k < C0) ? p.slab[(size_t)m * ld + k] : 0.f;
+    }
+    if (p.train)
+        for (int k = tid; k < C0; k += 256) {
+            const double s = p.st_slab[k], q = p.st_slab[ld + k];
+            const double m_ = s * (double)inv_m;
+            double v = q * (double)inv_m - m_ * m_;
+            v = v > 0.0 ? v : 0.0;
+            mu[k] = (float)m_; rs[k] = 1.0f / sqrtf((float)v + p.eps);
+        }
+    for (int idx = tid; idx < 27 * B4R; idx += 256) {
+        const int tap = idx >> 4, m = idx & 15;
+        int nb = -1;
+        if (m < M) {
+            int d, h, x;
+            unpack_dhw(p.coords[m], d, h, x);
+            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+            const int nd = d + kd - 1, nh = h + kh - 1, nw = x + kw - 1;
+            if ((unsigned)nd < (unsigned)p.g.D && (unsigned)nh < (unsigned)p.g.H && (unsigned)nw < (unsigned)p.g.W)
+                nb = m + ((kd - 1) * p.g.H + (kh - 1)) * p.g.W + (kw - 1);
+        }
+        nbt[idx] = nb;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int n = 0;
+        for (int tap = 0; tap < 27; ++tap) {
+            bool any = false;
+            for (int m = 0; m < M; ++m) any = any || nbt[tap * 16 + m] >= 0;
+            if (any) live[1 + n++] = tap;
+        }
+        live[0] = n;
+    }
+    __syncthreads();
+    const int nlive = live[0];
+    const int n0 = 16 * w;                      // this workgroup's conv1 output channels
+    unsigned phase = 0;
+
+    // Weights never depend on activations: a layer's conv1 slice (<= 16 float4 per lane) and conv2 tap slices (16 float4 per lane)
+    // are loaded one phase AHEAD -- right after the registers' last use in the previous layer -- so their latency and the
+    // workgroup's ~100 KB of weight traffic per layer hide under the hand-offs.
+    const int nt = wave & 1, half = wave >> 1;
+    float4 wreg[16];
+    float4 treg[4][4];
+    int mytap[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int li = w + B4W * i; mytap[i] = li < nlive ? live[1 + li] : -1; }
+    auto load_w1 = [&](int l) __attribute__((always_inline)) {
+        const int C = C0 + 32 * l, nT = C >> 4;
+        const float* w1 = p.tab[l].w1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int t = wave + 4 * i;
+            wreg[i] = t < nT ? *(const float4*)(w1 + (size_t)(n0 + r16) * C + 16 * t + 4 * k4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto load_taps = [&](int l) __attribute__((always_inline)) {
+        const float* wpf = p.tab[l].wpf;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                treg[i][t] = mytap[i] >= 0 ? *(const float4*)(wpf + ((size_t)(16 * nt + r16) * 27 + mytap[i]) * 128 + 64 * half + 16 * t + 4 * k4)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    load_w1(0);
+    load_taps(0);
+
+#ifdef B4_TIMING
+    unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tl = wall_clock64();
+#define B4_T(i) do { if (tid == 0) { const unsigned long long n_ = wall_clock64(); tacc[i] += n_ - tl; tl = n_; } } while (0)
+#else
+#define B4_T(i)
+#endif
+    for (int l = 0; l < p.nlayers; ++l) {
+        const int C = C0 + 32 * l, nT = C >> 4;                 // K super-steps of 16 channels
+        const B4Layer L = p.tab[l];
+        B4_T(0);
+        // a. norm1 constants of this layer for the C input channels (train: the channels' batch statistics, cached since they were
+        //    produced; eval: this layer's running statistics); the transform itself rides in the MFMA loop's operand reads
+        for (int k = tid; k < C; k += 256) {
+            float m_, r_;
+            if (p.train) { m_ = mu[k]; r_ = rs[k]; } else { m_ = L.rm1[k]; r_ = 1.0f / sqrtf(L.rv1[k] + p.eps); }
+            mn1[k] = m_; sc1[k] = L.g1[k] * r_; be1[k] = L.b1[k];
+        }
+        __syncthreads();
+        B4_T(1);
+        // b. conv1: 16 rows x 16 channels, K split over the waves; A = relu(bn1(x)) built from the LDS slab on the fly
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float rowz = r16 < M ? 1.f : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int t = wave + 4 * i;
+            if (t < nT) {
+                const int k = 16 * t + 4 * k4;
+                const float4 x = *(const float4*)(xs + r16 * B4P + k), m4 = *(const float4*)(mn1 + k), s4 = *(const float4*)(sc1 + k),
+                             b4 = *(const float4*)(be1 + k);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rowz * fmaxf(bn_apply(x.x, m4.x, s4.x, b4.x), 0.f), wreg[i].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rowz * fmaxf(bn_apply(x.y, m4.y, s4.y, b4.y), 0.f), wreg[i].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rowz * fmaxf(bn_apply(x.z, m4.z, s4.z, b4.z), 0.f), wreg[i].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rowz * fmaxf(bn_apply(x.w, m4.w, s4.w, b4.w), 0.f), wreg[i].w, acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave * 256 + (4 * k4 + r) * 16 + r16] = acc[r];
+        __syncthreads();
+        const int row = tid >> 4, col = tid & 15;
+        const float y = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid];       // y1[row][n0 + col]
+        // c. BatchNorm2 statistics of the 16 channels (all rows are here), y1 + statistics saved for the backward
+        dred[row * 32 + col] = row < M ? (double)y : 0.0;
+        dred[512 + row * 32 + col] = row < M ? (double)y * (double)y : 0.0;
+        __syncthreads();
+        if (tid < 16) {
+            double s = 0, q = 0;
+            for (int m = 0; m < B4R; ++m) { s += dred[m * 32 + tid]; q += dred[512 + m * 32 + tid]; }
+            float m_, r_;
+            if (p.train) {
+                const double mm = s * (double)inv_m;
+                double v = q * (double)inv_m - mm * mm;
+                v = v > 0.0 ? v : 0.0;
+                m_ = (float)mm; r_ = 1.0f / sqrtf((float)v + p.eps);
+                L.st_y1[n0 + tid] = s; L.st_y1[128 + n0 + tid] = q;
+            } else {
+                m_ = L.rm2[n0 + tid]; r_ = 1.0f / sqrtf(L.rv2[n0 + tid] + p.eps);
+            }
+            c2[tid] = m_; c2[32 + tid] = r_;
+        }
+        __syncthreads();
+        if (row < M && p.train) L.y1[(size_t)row * 128 + n0 + col] = y;
+        {
+            const float a2 = row < M ? fmaxf(bn_apply(y, c2[col], L.g2[n0 + col] * c2[32 + col], L.b2[n0 + col]), 0.f) : 0.f;
+            pstore(p.xa + w * 256 + tid, a2);
+        }
+        // ---- hand-off A --------------------------------------------------------------------------------------------------
+        B4_T(2);
+        b4_arrive(p.counter, tid);
+        if (!b4_wait(p.counter, p.err, (++phase) * B4W, tid, &s_ok)) return;
+        {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = pload(p.xa + j * 256 + tid);
+            if (l + 1 < p.nlayers) load_w1(l + 1);    // next layer's conv1 weights: issued BEHIND the gather loads, ~5 us ahead of their use
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a2s[row * B4A2P + 16 * j + col] = v[j];
+        }
+        B4_T(3);
+        __syncthreads();
+        // e. conv2: this workgroup's live taps; wave = (output-channel tile nt, input-channel half)
+        f32x4 zc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (mytap[i] >= 0) {
+                const int nb = nbt[mytap[i] * 16 + r16];
+                const float* ar = a2s + (nb >= 0 ? nb : 0) * B4A2P + 64 * half + 4 * k4;
+                const float z = nb >= 0 ? 1.f : 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float4 av = *(const float4*)(ar + 16 * t);
+                    zc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x * z, treg[i][t].x, zc, 0, 0, 0);
+                    zc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y * z, treg[i][t].y, zc, 0, 0, 0);
+                    zc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z * z, treg[i][t].z, zc, 0, 0, 0);
+                    zc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w * z, treg[i][t].w, zc, 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave * 256 + (4 * k4 + r) * 16 + r16] = zc[r];      // [wave][row][co within the tile]
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {            // partial z[row][co]: co tile nt = j, halves summed (waves j and j + 2)
+            const float v = red[j * 256 + tid] + red[(j + 2) * 256 + tid];
+            pstore(p.xb + w * 512 + row * 32 + 16 * j + col, v);
+        }
+        // ---- hand-off B --------------------------------------------------------------------------------------------------
+        B4_T(4);
+        b4_arrive(p.counter, tid);
+        if (!b4_wait(p.counter, p.err, (++phase) * B4W, tid, &s_ok)) return;
+        B4_T(5);
+        float zv[2][8];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) zv[j][q] = pload(p.xb + q * 512 + tid + 256 * j);
+        if (l + 1 < p.nlayers) load_taps(l + 1);      // next layer's conv2 weights: behind the gather loads, ~6 us ahead of their use
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int e = tid + 256 * j, zr = e >> 5, co = e & 31;
+            const float (&v)[8] = zv[j];
+            float z = v[0];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) z += v[q];                    // fixed order: deterministic, identical in every workgroup
+            if (zr >= M) z = 0.f;
+            xs[zr * B4P + C + co] = z;
+            dred[zr * 32 + co] = (double)z; dred[512 + zr * 32 + co] = (double)z * (double)z;
+            if (w == 0 && zr < M) p.slab[(size_t)zr * ld + C + co] = z;
+        }
+        __syncthreads();
+        if (tid < 32 && p.train) {
+            double s = 0, q = 0;
+            for (int m = 0; m < B4R; ++m) { s += dred[m * 32 + tid]; q += dred[512 + m * 32 + tid]; }
+            const double mm = s * (double)inv_m;
+            double v = q * (double)inv_m - mm * mm;
+            v = v > 0.0 ? v : 0.0;
+            mu[C + tid] = (float)mm; rs[C + tid] = 1.0f / sqrtf((float)v + p.eps);
+            if (w == 0) { p.st_slab[C + tid] = s; p.st_slab[ld + C + tid] = q; }
+        }
+        __syncthreads();
+        B4_T(6);
+    }
+#ifdef B4_TIMING
+    if (tid == 0) for (int i = 0; i < 7; ++i) p.err[8 + 8 * w + i] = (unsigned)tacc[i];      // 100 MHz ticks summed over the layers, per workgroup
+#endif
+}
+
+}  // namespace
+
+extern "C" int mms_b4_fwd_group(const B4FwdP* pp, int ng, hipStream_t s) {
+    Grp<B4FwdP> a;
+    if (!grp_fill(a, pp, ng, 1)) return MMS_ERR_ARG;
+    for (int g = 0; g < ng; ++g) {
+        const B4FwdP& p = pp[g];
+        if (p.M < 1 || p.M > 16 || p.ld != 1024 || p.C0 % 32 != 0 || p.C0 + 32 * p.nlayers > p.ld || !p.tab || !p.slab || !p.xa || !p.xb ||
+            !p.counter || !p.err || !p.coords || (p.train && !p.st_slab) || p.M != pp->M || p.nlayers != pp->nlayers) return MMS_ERR_ARG;
+    }
+    constexpr int smem = (B4R * B4P + 5 * 1024 + B4R * B4A2P + 1024) * 4 + 1024 * 8 + 64 * 4 + (27 * 16 + 32) * 4;
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [&] { hipFuncSetAttribute((const void*)b4_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem); });
+    MMS_LAUNCH(b4_fwd_kernel, dim3(B4W, 1, ng), dim3(256), smem, s, a);
+    return mms_check_launch();
+}

@@ -37,6 +37,7 @@ struct Plan {
     size_t stats_begin, stats_end;
     size_t st_y0, st_slab[NB], st_y1[NLAYER];          // forward (sum | sumsq), each 2*C doubles
     size_t counters;                                   // split-fixup tickets (zeroed at init, re-armed by their users)
+    size_t b4_cnt, b4_err, b4_xa, b4_xb, b4_tab;       // block-4 persistent kernels (dn_b4.hip): counters (inside the per-step zeroed region), sticky error word, hand-off buffers, layer table
     size_t bb_y0, bb_y1[NLAYER], bb_in[NLAYER], bb_tr[3], bb_head;   // backward (s1 | s2)
     size_t total;
 };
@@ -101,8 +102,13 @@ bool make_plan(Plan& P, int B, int D, int H, int W) {
     for (int i = 0; i < NLAYER; ++i) P.bb_in[i] = take((size_t)P.R[blk_of[i]] * 2 * 1024 * 8);
     for (int i = 0; i < 3; ++i) P.bb_tr[i] = take((size_t)P.R[i] * 2 * 1024 * 8);
     P.bb_head = take((size_t)2 * 1024 * 8);
+    P.b4_cnt = take(256);
     P.stats_end = o;
     P.counters = take(4096 * 4);
+    P.b4_err = take(1024);
+    P.b4_xa = take((size_t)8 * 256 * 4);
+    P.b4_xb = take((size_t)8 * 512 * 4);
+    P.b4_tab = take(sizeof(B4Layer) * LAYERS[3]);
     P.total = o;
     return true;
 }
@@ -187,6 +193,7 @@ extern "C" int mms_dn121_region(int B, int D, int H, int W, const char* name, in
         return set(P.y1[index], (size_t)P.M[b] * 128 * 4);
     }
     if (!strcmp(name, "stats")) return set(P.stats_begin, P.stats_end - P.stats_begin);
+    if (!strcmp(name, "b4_err")) return set(P.b4_err, 1024);
     return MMS_ERR_ARG;
 }
 
@@ -220,6 +227,20 @@ static int dn121_init_impl(void* ws, int B, int D, int H, int W, const void* con
         else set_bn(IDX.bn5, P.st_slab[b], CTOT[b], CTOT[b], P.M[b], P.R[b]);
     }
     if (hipMemsetAsync(at<void>(ws, P.counters), 0, 4096 * 4, s) != hipSuccess) return MMS_ERR_LAUNCH;
+    if (hipMemsetAsync(at<void>(ws, P.b4_err), 0, 1024, s) != hipSuccess) return MMS_ERR_LAUNCH;
+    B4Layer b4[LAYERS[3]];
+    {
+        const int l0 = NLAYER - LAYERS[3];
+        for (int i = 0; i < LAYERS[3]; ++i) {
+            const int li = l0 + i, ip = IDX.layer[li], o1 = IDX.bn_layer1[li], o2 = IDX.bn_layer2[li];
+            b4[i] = B4Layer{(const float*)params[ip], (const float*)params[ip + 1], (const float*)params[ip + 2],
+                            (const float*)params[ip + 3], (const float*)params[ip + 4], at<float>(ws, P.wpf[li]), at<float>(ws, P.wpb[li]),
+                            (const float*)buffers[3 * o1], (const float*)buffers[3 * o1 + 1], (const float*)buffers[3 * o2], (const float*)buffers[3 * o2 + 1],
+                            at<float>(ws, P.y1[li]), at<double>(ws, P.st_y1[li])};
+        }
+    }
+    hipError_t e0 = hipMemcpyAsync(at<void>(ws, P.b4_tab), b4, sizeof(b4), hipMemcpyHostToDevice, s);
+    if (e0 != hipSuccess) return MMS_ERR_LAUNCH;
     hipError_t e1 = hipMemcpyAsync(at<void>(ws, P.tab_pack), pk, sizeof(pk), hipMemcpyHostToDevice, s);
     hipError_t e2 = hipMemcpyAsync(at<void>(ws, P.tab_bn), bn, sizeof(bn), hipMemcpyHostToDevice, s);
     hipError_t e3 = hipStreamSynchronize(s);   // pk/bn are stack arrays
@@ -312,9 +333,27 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
         TRY(mms_pool_fwd_group(pf, ng, s));
         SYNC(at<double>(cx[0].ws, P.st_slab[0]), P.R[0], 2 * CTOT[0], 64, CTOT[0]);
     }
+    // block 4 as ONE launch (dn_b4.hip) when its rows fit a single 16-row MFMA tile (batch 4 on 64x64x32 volumes); MMS_PERSIST_B4=0: off
+    const char* epb = getenv("MMS_PERSIST_B4");
+    const bool b4_one = P.M[3] <= 16 && P.R[3] == 1 && !dp.hook && dp.bn_world == 1 && !(epb && epb[0] == '0');
     int l = 0;
     for (int b = 0; b < NB; ++b) {
         int C = C0[b];
+        if (b == 3 && b4_one) {
+            B4FwdP q[MMS_MAX_GROUP];
+            void* regs[MMS_MAX_GROUP];
+            FOR_G {
+                const Ctx& c = cx[g];
+                q[g] = B4FwdP{at<B4Layer>(c.ws, P.b4_tab), LAYERS[3], C0[3], at<float>(c.ws, P.slab[3]), CTOT[3], at<double>(c.ws, P.st_slab[3]),
+                              at<int>(c.ws, P.coords[3]), P.g[3], P.M[3], train, 1e-5f, at<float>(c.ws, P.b4_xa), at<float>(c.ws, P.b4_xb),
+                              at<unsigned>(c.ws, P.b4_cnt), at<unsigned>(c.ws, P.b4_err)};
+                regs[g] = at<void>(c.ws, P.b4_cnt);
+            }
+            if (!train) TRY(mms_zero_regions_group(regs, ng, 256, s));      // (training: the statistics zero-fill above covers the counters)
+            TRY(mms_b4_fwd_group(q, ng, s));
+            l += LAYERS[3];
+            continue;
+        }
         for (int i = 0; i < LAYERS[b]; ++i, ++l, C += 32) {
             const int ip = IDX.layer[l];
             Conv1FwdP c1[MMS_MAX_GROUP];

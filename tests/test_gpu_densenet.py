@@ -145,3 +145,36 @@ def test_densenet_backward_flip_free(B, dims):
     print("flip-free grad parity: median %.2e; worst: %s" % (np.median(list(errs.values())),
                                                              ", ".join("%s %.2e" % (k, errs[k]) for k in order[:6])))
     assert errs[order[0]] <= 2e-4, (order[0], errs[order[0]])          # measured: worst tensor 1.0e-4 / 6.3e-5, median 1.4e-5
+
+
+@pytest.mark.parametrize("B,dims,train", [(4, (64, 64, 32), True), (3, (64, 64, 32), True), (2, (64, 64, 32), False), (8, (32, 32, 32), True),
+                                          (1, (64, 64, 64), True)])
+def test_block4_persistent_kernel_equals_per_layer_path(B, dims, train, monkeypatch):
+    """Dense block 4 as ONE launch (csrc/dn_b4.hip: cluster of 8 workgroups, LDS-resident slab, two in-launch hand-offs per layer) against
+    the per-layer launch sequence it replaces (MMS_PERSIST_B4=0), same weights and input: features, every saved activation the
+    backward reads (block-4 slab, y1 of its 16 layers), the BatchNorm statistics (through the running statistics) -- ragged row
+    counts (12, 8 rows), a 1x1x1 grid (one live tap) and the eval-mode forward included."""
+    ref, net = _make(4)
+    x = structured_volumes(B, dims, 21).to(DEV)
+    net.train(train)
+    outs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("MMS_PERSIST_B4", flag)
+        net.load_state_dict(ref.state_dict())            # same running statistics before each run
+        with torch.no_grad():
+            y = net(x)
+        torch.cuda.synchronize()
+        outs[flag] = dict(y=y.clone(), slab=net.workspace_region("slab", 3).clone(),
+                          y1=[net.workspace_region("y1", 42 + i).clone() for i in range(16)] if train else [],
+                          bufs=[b.clone() for b in net.buffers()])
+    a, b = outs["0"], outs["1"]
+    assert_close(b["y"], a["y"], 1e-5, "features")
+    assert_close(b["slab"], a["slab"], 1e-5, "block-4 slab")
+    for i, (u, v) in enumerate(zip(a["y1"], b["y1"])):
+        assert_close(v, u, 1e-5, "y1 of block-4 layer %d" % i)
+    for u, v in zip(a["bufs"], b["bufs"]):
+        if u.dtype == torch.float32:
+            assert_close(v, u, 1e-5, "running statistics")
+        else:
+            assert torch.equal(u, v)
+    assert int(net.workspace_region("b4_err", 0, torch.int32)[0]) == 0        # no hand-off timed out
