@@ -136,6 +136,19 @@ __global__ __launch_bounds__(256) void b4_fwd_kernel(const Grp<B4FwdP> grp) {
                 treg[i][t] = mytap[i] >= 0 ? *(const float4*)(wpf + ((size_t)(16 * nt + r16) * 27 + mytap[i]) * 128 + 64 * half + 16 * t + 4 * k4)
                                             : make_float4(0.f, 0.f, 0.f, 0.f);
     };
+    // norm1 parameters of the layer's C channels (<= 4 per thread): gamma | beta [| running mean | running var]
+    float cg[4], cb[4], cm[4], cv[4];
+    auto load_c1 = [&](int l) __attribute__((always_inline)) {
+        const int C = C0 + 32 * l;
+        const B4Layer& T = p.tab[l];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = tid + 256 * j, kk = k < C ? k : C - 1;
+            cg[j] = T.g1[kk]; cb[j] = T.b1[kk];
+            if (!p.train) { cm[j] = T.rm1[kk]; cv[j] = T.rv1[kk]; } else { cm[j] = 0.f; cv[j] = 1.f; }
+        }
+    };
+    load_c1(0);
     load_w1(0);
     load_taps(0);
 
@@ -151,10 +164,14 @@ __global__ __launch_bounds__(256) void b4_fwd_kernel(const Grp<B4FwdP> grp) {
         B4_T(0);
         // a. norm1 constants of this layer for the C input channels (train: the channels' batch statistics, cached since they were
         //    produced; eval: this layer's running statistics); the transform itself rides in the MFMA loop's operand reads
-        for (int k = tid; k < C; k += 256) {
-            float m_, r_;
-            if (p.train) { m_ = mu[k]; r_ = rs[k]; } else { m_ = L.rm1[k]; r_ = 1.0f / sqrtf(L.rv1[k] + p.eps); }
-            mn1[k] = m_; sc1[k] = L.g1[k] * r_; be1[k] = L.b1[k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = tid + 256 * j;
+            if (k < C) {
+                float m_, r_;
+                if (p.train) { m_ = mu[k]; r_ = rs[k]; } else { m_ = cm[j]; r_ = 1.0f / sqrtf(cv[j] + p.eps); }
+                mn1[k] = m_; sc1[k] = cg[j] * r_; be1[k] = cb[j];
+            }
         }
         __syncthreads();
         B4_T(1);
@@ -212,7 +229,8 @@ __global__ __launch_bounds__(256) void b4_fwd_kernel(const Grp<B4FwdP> grp) {
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = pload(p.xa + j * 256 + tid);
-            if (l + 1 < p.nlayers) load_w1(l + 1);    // next layer's conv1 weights: issued BEHIND the gather loads, ~5 us ahead of their use
+            asm volatile("" ::: "memory");            // keep the prefetch loads BEHIND the gather loads (vmcnt retires in issue order)
+            if (l + 1 < p.nlayers) { load_c1(l + 1); load_w1(l + 1); }    // next layer's norm1 parameters + conv1 weights, ~5 us ahead of their use
 #pragma unroll
             for (int j = 0; j < 8; ++j) a2s[row * B4A2P + 16 * j + col] = v[j];
         }
@@ -254,6 +272,7 @@ __global__ __launch_bounds__(256) void b4_fwd_kernel(const Grp<B4FwdP> grp) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int q = 0; q < 8; ++q) zv[j][q] = pload(p.xb + q * 512 + tid + 256 * j);
+        asm volatile("" ::: "memory");
         if (l + 1 < p.nlayers) load_taps(l + 1);      // next layer's conv2 weights: behind the gather loads, ~6 us ahead of their use
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
