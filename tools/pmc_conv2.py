@@ -34,14 +34,18 @@ def calls(rows, value):
     return out
 
 
+B4_ONE = True        # block 4's forward runs as one persistent launch (csrc/dn_b4.hip): bench.py's leg skips (fwd, block 4)
+
+
 def per_op(cs, groups):
     """mean per timed call, layer-weighted, pooled over the sub-group sizes (as bench.roofline_block pools them)"""
-    assert len(cs) == len(groups) * 4 * 3 * 23, (len(cs), len(groups))
+    combos = [(blk, op) for blk in range(4) for op in OPS if not (B4_ONE and blk == 3 and op == "fwd")]
+    assert len(cs) == len(groups) * len(combos) * 23, (len(cs), len(groups))
     acc = {op: [0.0, 0] for op in OPS}
     i = 0
     for _ in groups:
-        for blk in range(4):
-            for op in OPS:
+        for blk, op in combos:
+            if True:
                 seg = cs[i:i + 23]; i += 23
                 assert all(c[0] == op for c in seg), (op, seg[0][0])
                 acc[op][0] += sum(c[1] for c in seg[3:]) / 20.0 * LAYERS[blk]
@@ -69,8 +73,11 @@ def main():
            "sub_groups": groups}
     gavg = sum(groups) / len(groups)
     for op in OPS:
-        alg = 0.0
+        alg, nl = 0.0, 0
         for blk in range(4):
+            if B4_ONE and blk == 3 and op == "fwd":
+                continue
+            nl += LAYERS[blk]
             gd = [d // 4 >> blk for d in DIMS]
             M = B * gd[0] * gd[1] * gd[2]
             per_model = {"fwd": M * 128 * 4 + M * 32 * 4 + 27 * 32 * 128 * 4, "bwd_data": M * 32 * 4 + 2 * M * 128 * 4 + 27 * 32 * 128 * 4,
@@ -78,7 +85,7 @@ def main():
             alg += gavg * per_model * LAYERS[blk]
         out[op] = {"FETCH_SIZE_KB": round(fe[op], 1), "WRITE_SIZE_KB": round(wr[op], 1),
                    "avg_hbm_bytes_per_launch": round((2 * fe[op] + wr[op]) * 1024),
-                   "avg_algorithmic_bytes_per_launch": round(alg / sum(LAYERS))}
+                   "avg_algorithmic_bytes_per_launch": round(alg / nl)}
     print(json.dumps(out, indent=1))
 
 
