@@ -818,8 +818,20 @@ class SurvivalEngine:
         self.acc.zero_()
 
     def epoch_stats(self):
-        """-> dict(sum_loss, n_usable, sum_entropy, n_batches) (one device->host sync)."""
+        """-> dict(sum_loss, n_usable, sum_entropy, n_batches) (one device->host sync).  Also the place where the sticky time-out
+        word of the block-4 persistent kernel (csrc/dn_b4.hip) is checked: a cluster whose workgroups never became co-resident
+        (more than ~256 persistent workgroups in flight at once) leaves garbage and must not pass silently."""
         a = self.acc.tolist()
+        for P in self.plans.values():
+            if getattr(P, "has_enc", False) and not P.fallback:
+                if getattr(P, "b4_err", None) is None:
+                    off, nb = ctypes.c_size_t(0), ctypes.c_size_t(0)
+                    D, H, W = P.dims
+                    _lib.check(self.lib.mms_dn121_region(P.B, D, H, W, b"b4_err", 0, ctypes.byref(off), ctypes.byref(nb)), "mms_dn121_region")
+                    P.b4_err = P.ws[off.value:off.value + 4].view(torch.int32)
+                if int(P.b4_err.item()) != 0:
+                    raise RuntimeError("mmsurv: a hand-off of the block-4 persistent kernel timed out (too many persistent launches in "
+                                       "flight at once?); results of this epoch are invalid -- rerun with MMS_PERSIST_B4=0")
         return dict(sum_loss=a[0], n_usable=a[1], sum_entropy=a[2], n_batches=a[3])
 
 
