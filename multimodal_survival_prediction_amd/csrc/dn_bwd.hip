@@ -583,16 +583,30 @@ struct Conv1BwdDataOp {
         const float mu = ein[c], rs = ein[TN + c], ga = ein[2 * TN + c], be = ein[3 * TN + c];
         double s1 = 0, s2 = 0;
         const int rows = !active ? 0 : (p.M - m0_ < TM ? p.M - m0_ : TM);
-        if (k < p.K) {
+        constexpr int NI = TM / RG;               // rows per thread
+        float xv[NI], gv[NI];                     // (non-pool) this thread's x values and masked gradients, kept for the fused apply
+        if (!POOL) {
+            // every global load of the pass is issued before its first use: ONE memory round trip for the thread's NI rows
+            // (as a `for (r = rg; r < rows; r += RG)` loop the loads ran one after the other: 16 dependent trips at 128 rows)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int r = rg + i * RG;
+                xv[i] = (r < rows && k < p.K) ? p.x[(size_t)(m0_ + r) * p.ldx + k] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int r = rg + i * RG;
+                const bool ok = r < rows && k < p.K;
+                const float xh = (xv[i] - mu) * rs;
+                const float g = ok && fmaf(ga, xh, be) > 0.f ? Cs[r * (TN + 1) + c] : 0.f;
+                gv[i] = g;
+                if (ok && !p.fuse_dx) p.dbn[(size_t)(m0_ + r) * p.lddbn + k] = g;
+                if (ok) { s1 += g; s2 += (double)g * xh; }
+            }
+        } else if (k < p.K) {
             for (int r = rg; r < rows; r += RG) {
                 const float da = Cs[r * (TN + 1) + c];
-                if (!POOL) {
-                    const size_t m = m0_ + r;
-                    const float xh = (p.x[m * p.ldx + k] - mu) * rs;
-                    const float g = fmaf(ga, xh, be) > 0.f ? da : 0.f;
-                    if (!p.fuse_dx) p.dbn[m * p.lddbn + k] = g;
-                    s1 += g; s2 += (double)g * xh;
-                } else {
+                {
                     const int base = srcbase[r], HW = p.in.H * p.in.W, W = p.in.W;
                     const float d8 = da * 0.125f;
 #pragma unroll
@@ -617,13 +631,16 @@ struct Conv1BwdDataOp {
                 double a = 0, b = 0;
                 for (int g = 0; g < RG; ++g) { a += red[(g * 2) * TN + c]; b += red[(g * 2 + 1) * TN + c]; }
                 const float gr = ga * rs, m1 = (float)(a * (double)p.bn_in.inv_count), m2 = rs * (float)(b * (double)p.bn_in.inv_count);
-                for (int r = rg; r < rows; r += RG) {
-                    const size_t m = m0_ + r;
-                    const float x = p.x[m * p.ldx + k];
-                    const float g = fmaf(ga, (x - mu) * rs, be) > 0.f ? Cs[r * (TN + 1) + c] : 0.f;
-                    float* dst = p.fuse_dx + m * p.fuse_lddx + k;
-                    const float o = p.fuse_accumulate ? *dst : 0.f;
-                    *dst = o + gr * (g - m1 - (x - mu) * m2);
+                float ov[NI];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {            // the read half of the read-modify-write, all rows in flight together
+                    const int r = rg + i * RG;
+                    ov[i] = (r < rows && p.fuse_accumulate) ? p.fuse_dx[(size_t)(m0_ + r) * p.fuse_lddx + k] : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int r = rg + i * RG;
+                    if (r < rows) p.fuse_dx[(size_t)(m0_ + r) * p.fuse_lddx + k] = ov[i] + gr * (gv[i] - m1 - (xv[i] - mu) * m2);
                 }
                 if (rg == 0 && p.fuse_dgamma) { p.fuse_dgamma[k] += (float)b; p.fuse_dbeta[k] += (float)a; }
             }
