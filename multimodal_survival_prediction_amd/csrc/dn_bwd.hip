@@ -91,13 +91,22 @@ struct Conv3BwdDataOp {
         const float mu = ex[c], rstd = ex[128 + c], ga = ex[256 + c], be = ex[384 + c];
         double s1 = 0, s2 = 0;
         const int rows = !active ? 0 : (p.M - m0_ < TM ? p.M - m0_ : TM);
-        for (int r = rg; r < rows; r += 2) {
-            const size_t o = (size_t)(m0_ + r) * 128 + c;
-            const float xh = (p.y1[o] - mu) * rstd;
-            const float pre = fmaf(ga, xh, be);
-            const float g = pre > 0.f ? Cs[r * (TN + 1) + c] : 0.f;
-            p.dbn[o] = g;
-            s1 += g; s2 += (double)g * xh;
+        float yv[TM / 2];                          // this thread's TM/2 rows: every y1 load in flight before the first use
+#pragma unroll
+        for (int i = 0; i < TM / 2; ++i) {
+            const int r = rg + 2 * i;
+            yv[i] = r < rows ? p.y1[(size_t)(m0_ + r) * 128 + c] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < TM / 2; ++i) {
+            const int r = rg + 2 * i;
+            if (r < rows) {
+                const float xh = (yv[i] - mu) * rstd;
+                const float pre = fmaf(ga, xh, be);
+                const float g = pre > 0.f ? Cs[r * (TN + 1) + c] : 0.f;
+                p.dbn[(size_t)(m0_ + r) * 128 + c] = g;
+                s1 += g; s2 += (double)g * xh;
+            }
         }
         double* red = (double*)(ex + 544);     // [2][2][128], 8-byte aligned (544*4 = 2176)
         if (active) { red[(rg * 2 + 0) * 128 + c] = s1; red[(rg * 2 + 1) * 128 + c] = s2; }
@@ -817,17 +826,29 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const Grp<BnBwdApplyP
     const int c = 4 * q;
     const float4 mu = *(const float4*)&cm[0][c], gr = *(const float4*)&cm[1][c], m1 = *(const float4*)&cm[2][c], m2 = *(const float4*)&cm[3][c];
     const int r0 = blockIdx.x * rows, rend = r0 + rows < p.M ? r0 + rows : p.M;
-    for (int r = r0 + rl; r < rend; r += rpar) {
-        const size_t m = r;
-        const float4 g = *(const float4*)(p.dbn + m * p.lddbn + c0 + c);
-        const float4 x = *(const float4*)(p.x + m * p.ldx + c0 + c);
-        float4* dst = (float4*)(p.dx + m * p.lddx + c0 + c);
-        float4 o = p.accumulate ? *dst : make_float4(0, 0, 0, 0);
-        o.x += gr.x * (g.x - m1.x - (x.x - mu.x) * m2.x);
-        o.y += gr.y * (g.y - m1.y - (x.y - mu.y) * m2.y);
-        o.z += gr.z * (g.z - m1.z - (x.z - mu.z) * m2.z);
-        o.w += gr.w * (g.w - m1.w - (x.w - mu.w) * m2.w);
-        *dst = o;
+    // rows of this thread: r0 + rl + j * rpar; processed four at a time with all twelve loads issued before the first use
+    for (int rb = r0 + rl; rb < rend; rb += 4 * rpar) {
+        float4 g[4], x[4], o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = rb + j * rpar;
+            const size_t m = r < rend ? r : rb;
+            g[j] = *(const float4*)(p.dbn + m * p.lddbn + c0 + c);
+            x[j] = *(const float4*)(p.x + m * p.ldx + c0 + c);
+            o[j] = p.accumulate ? *(const float4*)(p.dx + m * p.lddx + c0 + c) : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = rb + j * rpar;
+            if (r < rend) {
+                float4 v = o[j];
+                v.x += gr.x * (g[j].x - m1.x - (x[j].x - mu.x) * m2.x);
+                v.y += gr.y * (g[j].y - m1.y - (x[j].y - mu.y) * m2.y);
+                v.z += gr.z * (g[j].z - m1.z - (x[j].z - mu.z) * m2.z);
+                v.w += gr.w * (g[j].w - m1.w - (x[j].w - mu.w) * m2.w);
+                *(float4*)(p.dx + (size_t)r * p.lddx + c0 + c) = v;
+            }
+        }
     }
 }
 
