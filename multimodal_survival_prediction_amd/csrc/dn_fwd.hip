@@ -285,15 +285,18 @@ __global__ __launch_bounds__(256) void conv3_fwd_reduce_kernel(const Grp<Conv3Fw
 // Workgroup = 64 rows x 32 output channels; 4 waves = 2 row tiles x 2 halves of the 128 input channels (summed through
 // LDS at the end); 27 taps x 32 MFMAs per wave.  LDS: window (64 + 2*17) x 132 floats + 2 weight tiles = 85.5 KB.
 // ------------------------------------------------------------------------------------------------------
-#define C3M_TM 64
+// Two tile heights: 64 rows (2 row tiles x 2 channel halves) when the launch has >= 512 such tiles, else 32 rows (1 row tile x 4
+// channel quarters, window 32 + 2(W+1) rows = 26 KB at W = 8): the block-1 launches of 2-3 fold models (512 / 768 tiles, 2-3 per CU).
 #define C3M_PITCH 132
 #define C3M_MAXHALO 17
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv3_fwd_mt_kernel(const Grp<Conv3FwdP> grp) {
+template <int C3M_TM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C3M_TM == 64 ? 1 : 3, C3M_TM == 64 ? 2 : 3))) void conv3_fwd_mt_kernel(const Grp<Conv3FwdP> grp) {
+    constexpr int RT = C3M_TM / 32, KS = 4 / RT, CW = 128 / KS, NQ = CW / 8;      // row tiles, channel splits, channels and float4 K-groups per wave
     const Conv3FwdP& p = grp.p[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* img = smem;                                               // [nrows][132]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kq = lane >> 5;
-    const int rt = wave >> 1, kh2 = wave & 1;
+    const int rt = wave / KS, kh2 = wave % KS;
     int bx = blockIdx.x;
     if ((gridDim.x & 7) == 0) bx = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);      // XCD-contiguous row ranges
     const int m0 = bx * C3M_TM;
@@ -316,11 +319,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     // lane (kq, co = li) needs W[co][tap][64*kh2 + 8q + 4kq .. +3], q = 0..7 -- 8 x 16 B per lane and tap.  No LDS tile,
     // hence no per-tap barrier: the window is read-only during a kd phase and the waves drift freely (the two waves that
     // share a channel half hit the same lines in L1).
-    const float* wlane = p.wp + (size_t)li * (27 * 128) + 64 * kh2 + 4 * kq;
-    float4 bA[8], bB[8];
-    auto bload = [&](float4 (&b)[8], int tap) __attribute__((always_inline)) {
+    const float* wlane = p.wp + (size_t)li * (27 * 128) + CW * kh2 + 4 * kq;
+    float4 bA[NQ], bB[NQ];
+    auto bload = [&](float4 (&b)[NQ], int tap) __attribute__((always_inline)) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) b[q] = *(const float4*)(wlane + tap * 128 + 8 * q);
+        for (int q = 0; q < NQ; ++q) b[q] = *(const float4*)(wlane + tap * 128 + 8 * q);
     };
     // window rows: loaded into registers ahead of the kd phase that needs them (wload), transformed + stored at its start (wstore)
     constexpr int NI = ((C3M_TM + 2 * C3M_MAXHALO) * 32 + 255) / 256;      // 13
@@ -349,18 +352,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             }
         }
     };
-    auto mma = [&](int tap, const float4 (&b)[8]) __attribute__((always_inline)) {
+    auto mma = [&](int tap, const float4 (&b)[NQ]) __attribute__((always_inline)) {
         const int kd = tap / 9, t9 = tap - 9 * kd, kh = t9 / 3, kw = t9 - 3 * kh;
         const unsigned sel = (1u << kd) | (8u << kh) | (64u << kw);
         const float mk = (m9 & sel) == sel ? 1.f : 0.f;
-        const float* ar = img + (rt * 32 + li + halo + (kh - 1) * W + (kw - 1)) * C3M_PITCH + 64 * kh2 + 4 * kq;
-        float4 a[8];
+        const float* ar = img + (rt * 32 + li + halo + (kh - 1) * W + (kw - 1)) * C3M_PITCH + CW * kh2 + 4 * kq;
+        float4 a[NQ];
 #ifdef C3M_NO_AREAD
 #pragma unroll
-        for (int q = 0; q < 8; ++q) a[q] = make_float4(mk, mk + q, mk * 2, 1.f);
+        for (int q = 0; q < NQ; ++q) a[q] = make_float4(mk, mk + q, mk * 2, 1.f);
 #else
 #pragma unroll
-        for (int q = 0; q < 8; ++q) a[q] = *(const float4*)(ar + 8 * q);
+        for (int q = 0; q < NQ; ++q) a[q] = *(const float4*)(ar + 8 * q);
 #endif
 #ifdef C3M_NO_MASK
 #define MK_(x) (x)
@@ -368,14 +371,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #define MK_(x) ((x) * mk)
 #endif
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {        // two accumulators: consecutive MFMAs never wait for each other's result
+        for (int q = 0; q < NQ; ++q) {        // two accumulators: consecutive MFMAs never wait for each other's result
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(MK_(a[q].x), b[q].x, acc, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(MK_(a[q].y), b[q].y, acc2, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(MK_(a[q].z), b[q].z, acc, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(MK_(a[q].w), b[q].w, acc2, 0, 0, 0);
         }
     };
-    auto step = [&](int tap, const float4 (&cur)[8], float4 (&nxt)[8]) __attribute__((always_inline)) {
+    auto step = [&](int tap, const float4 (&cur)[NQ], float4 (&nxt)[NQ]) __attribute__((always_inline)) {
         const int t9 = tap % 9;
 #ifndef C3M_NO_BLOAD
         if (tap + 1 < 27) bload(nxt, tap + 1);
@@ -400,11 +403,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
     __syncthreads();                                                 // window -> Cs alias
-    // ---- epilogue: add the two channel halves, write the 32 slab columns, batch statistics
+    // ---- epilogue: add the channel splits, write the 32 slab columns, batch statistics
     float* Cs = smem;                                                // [64][33], aliases the window
     const int crow = rt * 32 + 4 * kq;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < KS; ++h) {
         if (kh2 == h) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -417,13 +420,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     store_tile<C3M_TM, 32>(p.out, p.ldo, p.M, 32, m0, 0, Cs, tid);
     tile_col_stats<C3M_TM, 32>(stat_rep(p.osum, p.srep, p.sstride), stat_rep(p.osumsq, p.srep, p.sstride), p.M, 32, m0, 0, Cs, tid);
 }
-// Used when the launch has >= 512 of its 64-row tiles (2 per CU): with fewer, the 32-row tiles of the GEMM form fill the chip
-// better (measured: one model's block 1, 128 tiles: 50 us vs 40 us; ten models' block 2, 160 tiles: 52 vs 50 us).
-static inline bool conv3_mt_ok(int M, int ng, const Dims3& g) {
+// Tile height by how well the launch fills whole rounds of the chip: 32-row tiles run 3 workgroups per CU (768 per round), 64-row tiles
+// 2 per CU (512 per round).  Measured on block 1 (8192 rows per model), G models per launch, us per launch, per-tap GEMM form / 32 / 64:
+// G=1 36/31/48, G=2 51/44/50, G=3 77/57/73, G=4 105/85/80, G=5 116/90/112, G=8 188/145/145, G=10 223/172/180 -- the 32-row form unless the
+// 64-row tiles fill their rounds clearly better (G = 4).  Below MMS_CONV3_MT32_MIN 32-row tiles: the per-tap GEMM form (Conv3FwdOp).
+// MMS_CONV3_MT: 0 = never, 2 = 64-row form whenever it applies, 3 = 32-row form whenever it applies (tests); returns the tile height or 0.
+static inline int conv3_mt_tile(int M, int ng, const Dims3& g) {
     const char* e = getenv("MMS_CONV3_MT");
-    if (e && e[0] == '0') return false;
-    if (e && e[0] == '2') return M >= 1024 && g.W + 1 <= C3M_MAXHALO;      // force (tests)
-    return (long)((M + C3M_TM - 1) / C3M_TM) * ng >= 512 && g.W + 1 <= C3M_MAXHALO;
+    if (g.W + 1 > C3M_MAXHALO || (e && e[0] == '0')) return 0;
+    if (e && e[0] == '2') return M >= 1024 ? 64 : 0;
+    if (e && e[0] == '3') return M >= 64 ? 32 : 0;
+    static const int min32 = getenv("MMS_CONV3_MT32_MIN") ? atoi(getenv("MMS_CONV3_MT32_MIN")) : 256;
+    const long n32 = (long)((M + 31) / 32) * ng, n64 = (long)((M + 63) / 64) * ng;
+    if (M < 1024 || n32 < min32) return 0;
+    const double f32 = (double)n32 / (double)((n32 + 767) / 768 * 768), f64 = (double)n64 / (double)((n64 + 511) / 512 * 512);
+    return n64 >= 512 && f64 > f32 + 0.1 ? 64 : 32;
+}
+template <int TM>
+static int launch_conv3_fwd_mt(const Conv3FwdP* pp, int ng, hipStream_t s) {
+    const Conv3FwdP& p = *pp;
+    constexpr int smem_max = (TM + 2 * C3M_MAXHALO) * C3M_PITCH * (int)sizeof(float);
+    const int smem = (TM + 2 * (p.g.W + 1)) * C3M_PITCH * (int)sizeof(float);       // W = 8: 43 KB (64 rows) / 26 KB (32 rows)
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [&] { hipFuncSetAttribute((const void*)conv3_fwd_mt_kernel<TM>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_max); });
+    Grp<Conv3FwdP> a;
+    grp_fill(a, pp, ng, 1);
+    MMS_LAUNCH(conv3_fwd_mt_kernel<TM>, dim3((p.M + TM - 1) / TM, 1, ng), dim3(256), smem, s, a);
+    return mms_check_launch();
 }
 
 extern "C" int mms_conv3_fwd_group(const Conv3FwdP* pp, int ng, hipStream_t s) {
@@ -435,16 +458,7 @@ extern "C" int mms_conv3_fwd_group(const Conv3FwdP* pp, int ng, hipStream_t s) {
         if (q.M != p.M || q.ldo % 4 != 0 || q.g.D != p.g.D || q.g.H != p.g.H || q.g.W != p.g.W || (q.partial == nullptr) != (p.partial == nullptr) ||
             q.nsplit != p.nsplit) return MMS_ERR_ARG;
     }
-    if (!p.partial && conv3_mt_ok(p.M, ng, p.g)) {
-        constexpr int smem_max = (C3M_TM + 2 * C3M_MAXHALO) * C3M_PITCH * (int)sizeof(float);
-        int smem = (C3M_TM + 2 * (p.g.W + 1)) * C3M_PITCH * (int)sizeof(float);       // W = 8: 43 KB -> 3 workgroups per CU
-        static std::once_flag attr_once;
-        std::call_once(attr_once, [&] { hipFuncSetAttribute((const void*)conv3_fwd_mt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem_max); });
-        Grp<Conv3FwdP> a;
-        grp_fill(a, pp, ng, 1);
-        MMS_LAUNCH(conv3_fwd_mt_kernel, dim3((p.M + C3M_TM - 1) / C3M_TM, 1, ng), dim3(256), smem, s, a);
-        return mms_check_launch();
-    }
+    if (const int tm = p.partial ? 0 : conv3_mt_tile(p.M, ng, p.g)) return tm == 64 ? launch_conv3_fwd_mt<64>(pp, ng, s) : launch_conv3_fwd_mt<32>(pp, ng, s);
     if (p.partial) {
         if (p.nsplit < 1 || p.nsplit > 27) return MMS_ERR_ARG;
         const int tpw = (27 + p.nsplit - 1) / p.nsplit;

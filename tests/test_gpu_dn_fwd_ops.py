@@ -97,13 +97,14 @@ def test_transition_fwd(ops, B, dims, K):
     assert_close(os_, cl(ref).double().sum(0), 1e-4, "transition sum")
 
 
-# (M >= 1024 rows with W <= 16 and no tap split takes the multi-tap kernel conv3_fwd_mt_kernel: cases 1 and 6-8; 7 = ragged last tile)
+# (no tap split + W <= 16: MMS_CONV3_MT=2 takes the 64-row multi-tap kernel for M >= 1024 rows (cases 1 and 6-8; 7 = ragged last tile),
+# MMS_CONV3_MT=3 its 32-row form for every case with M >= 64 (ragged tiles, 2x2x1 and 5x3x2 grids included))
 @pytest.mark.parametrize("B,dims", [(4, (16, 16, 8)), (2, (8, 8, 4)), (4, (4, 4, 2)), (4, (2, 2, 1)), (3, (5, 3, 2)),
                                     (4, (8, 8, 4)), (3, (7, 7, 8)), (2, (8, 16, 16))])
 @pytest.mark.parametrize("train", [True, False])
-@pytest.mark.parametrize("split", [0, 27, 3, 5])
-def test_conv3_fwd(ops, B, dims, train, split, monkeypatch):
-    monkeypatch.setenv("MMS_CONV3_MT", "2")      # take the multi-tap kernel whenever the shape allows it (default: only for >= 512 tiles)
+@pytest.mark.parametrize("split,mt", [(0, "2"), (0, "3"), (27, "2"), (3, "2"), (5, "2")])
+def test_conv3_fwd(ops, B, dims, train, split, mt, monkeypatch):
+    monkeypatch.setenv("MMS_CONV3_MT", mt)      # take a multi-tap kernel whenever the shape allows it (default: by tile count)
     torch.manual_seed(2)
     M = B * dims[0] * dims[1] * dims[2]
     y1 = torch.randn(B, 128, *dims) + 0.1
