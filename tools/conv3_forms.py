@@ -17,7 +17,9 @@ def main():
     Gs = [int(a) for a in sys.argv[2:]] or [1, 2, 3, 5]
     dev = torch.device("cuda:0")
     lib, S = _lib.load_library(), _lib.structs()
-    gd, B = (16, 16, 8), 4
+    blk = int(os.environ.get("BLOCK", "0"))            # dense block whose grid the launch has (0: 16x16x8 ... 3: 2x2x1)
+    gd, B = (16 >> blk, 16 >> blk, 8 >> blk), 4
+    nsp = int(os.environ.get("NSPLIT", "0"))           # forward / backward-data: tap split (0 = none)
     M = B * gd[0] * gd[1] * gd[2]
     R = _stat_reps(M)
     gam, bet = torch.ones(128, device=dev), torch.zeros(128, device=dev)
@@ -35,16 +37,22 @@ def main():
             bst = torch.zeros(R, 2, 128, dtype=torch.float64, device=dev)
             dbn, dwp = torch.zeros(M, 128, device=dev), torch.zeros(27 * 32 * 128, device=dev)
             out, dz = slab[:, 64:96], dslab[:, 64:96]
-            keep.append((y1, bn, slab, dslab, ost, bst, dbn, dwp))
+            part = torch.zeros(nsp * M * 128, device=dev) if nsp else None
+            keep.append((y1, bn, slab, dslab, ost, bst, dbn, dwp, part))
             if op == "fwd":
                 ps.append(S["Conv3FwdP"](y1.data_ptr(), coords.data_ptr(), ops.dims3(gd), M, wpf.data_ptr(), out.data_ptr(), out.stride(0), bn,
-                                         ost[0, 0, 64:].data_ptr(), ost[0, 1, 64:].data_ptr(), None, 27, R, 2 * 256))
+                                         ost[0, 0, 64:].data_ptr(), ost[0, 1, 64:].data_ptr(), ops.ptr(part), nsp or 27, R, 2 * 256))
             elif op == "bwd_data":
                 ps.append(S["Conv3BwdDataP"](dz.data_ptr(), dz.stride(0), coords.data_ptr(), ops.dims3(gd), M, wpb.data_ptr(), y1.data_ptr(), bn,
-                                             dbn.data_ptr(), bst[0, 0].data_ptr(), bst[0, 1].data_ptr(), None, 27, R, 2 * 128))
+                                             dbn.data_ptr(), bst[0, 0].data_ptr(), bst[0, 1].data_ptr(), ops.ptr(part), nsp or 27, R, 2 * 128))
             else:
                 ps.append(S["Conv3BwdWP"](y1.data_ptr(), coords.data_ptr(), ops.dims3(gd), M, bn, dz.data_ptr(), dz.stride(0),
-                                          dwp.data_ptr(), _bwdw_msplit(M, G), 1))
+                                          dwp.data_ptr(), int(os.environ.get("MSPLIT", _bwdw_msplit(M, G))), 1))
+        if op == "bwd_weight":            # the driver's chunking per form (bench._bwdw_msplit reads the knob), unless MSPLIT overrides it
+            def chunk(form):
+                os.environ[env] = form
+                for q in ps:
+                    q.msplit = int(os.environ.get("MSPLIT", _bwdw_msplit(M, G)))
         name = {"fwd": "Conv3FwdP", "bwd_data": "Conv3BwdDataP", "bwd_weight": "Conv3BwdWP"}[op]
         fn = getattr(lib, "mms_conv3_%s_group" % op)
         arr = (S[name] * G)(*ps)
@@ -53,6 +61,9 @@ def main():
                 os.environ.pop(env, None)
             else:
                 os.environ[env] = form
+            if op == "bwd_weight":
+                chunk(form)
+                arr = (S[name] * G)(*ps)
             for _ in range(3):
                 _lib.check(fn(arr, G, ops.stream()), op)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -63,7 +74,8 @@ def main():
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / 20
             tf = G * 2.0 * M * 27 * 128 * 32 / us * 1e-6
-            print("%-10s G=%d %s=%-7s %7.1f us  %5.1f TFLOP/s  %4.1f %% of peak" % (op, G, env, form or "default", us, tf, tf / 157.3 * 100), flush=True)
+            print("%-10s G=%d %s=%-7s %7.1f us  %5.1f TFLOP/s  %4.1f %% of peak%s" % (op, G, env, form or "default", us, tf, tf / 157.3 * 100,
+                                                                                  "  (msplit %d)" % ps[0].msplit if op == "bwd_weight" else ""), flush=True)
 
 
 if __name__ == "__main__":
