@@ -236,7 +236,7 @@ static int dn121_init_impl(void* ws, int B, int D, int H, int W, const void* con
             b4[i] = B4Layer{(const float*)params[ip], (const float*)params[ip + 1], (const float*)params[ip + 2],
                             (const float*)params[ip + 3], (const float*)params[ip + 4], at<float>(ws, P.wpf[li]), at<float>(ws, P.wpb[li]),
                             (const float*)buffers[3 * o1], (const float*)buffers[3 * o1 + 1], (const float*)buffers[3 * o2], (const float*)buffers[3 * o2 + 1],
-                            at<float>(ws, P.y1[li]), at<double>(ws, P.st_y1[li])};
+                            at<float>(ws, P.y1[li]), at<double>(ws, P.st_y1[li]), at<float>(ws, P.dbn_mid_l[li]), at<double>(ws, P.bb_y1[li])};
         }
     }
     hipError_t e0 = hipMemcpyAsync(at<void>(ws, P.b4_tab), b4, sizeof(b4), hipMemcpyHostToDevice, s);
@@ -474,6 +474,24 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
         const char* efa = getenv("MMS_FUSE_APPLY");
         const int fuse_rows = efa ? atoi(efa) : 32;
         const bool fuse_apply = M <= fuse_rows && M <= 128 && !sync;      // SyncBN: the sums leave the workgroup (all-reduce) before they are applied
+        // block 4 with <= 16 rows: the whole data path of the block's backward as ONE launch (dn_b4.hip); the loop below then only queues
+        // the layers' weight-gradient members.  MMS_PERSIST_B4: 0 = off (both passes), 1 = forward only; default both.
+        const char* epb = getenv("MMS_PERSIST_B4");
+        const bool b4_bwd = b == 3 && M <= 16 && P.R[3] == 1 && !sync && dp.bn_world == 1 && defer && fuse_apply && !(epb && (epb[0] == '0' || epb[0] == '1'));
+        if (b4_bwd) {
+            B4BwdP q[MMS_MAX_GROUP];
+            FOR_G {
+                const Ctx& c = cx[g];
+                q[g] = B4BwdP{at<B4Layer>(c.ws, P.b4_tab), LAYERS[3], C0[3], at<float>(c.ws, P.slab[3]), at<float>(c.ws, P.dslab[3]), CTOT[3],
+                              at<double>(c.ws, P.st_slab[3]), at<int>(c.ws, P.coords[3]), P.g[3], M, 1e-5f, at<float>(c.ws, P.b4_xa),
+                              at<unsigned>(c.ws, P.b4_cnt) + 32, at<unsigned>(c.ws, P.b4_err), {}, {}};
+                for (int i = 0; i < LAYERS[3]; ++i) {
+                    const int ip = IDX.layer[NLAYER - LAYERS[3] + i];
+                    q[g].dg1[i] = (float*)c.grd[ip]; q[g].db1[i] = (float*)c.grd[ip + 1];
+                }
+            }
+            TRY(mms_b4_bwd_group(q, ng, s));
+        }
         for (int i = LAYERS[b] - 1; i >= 0; --i) {
             --l; C -= 32;
             const int ip = IDX.layer[l];
@@ -528,8 +546,10 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
                 if (hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) return MMS_ERR_LAUNCH;
                 side_pending = false;
             }
-            TRY(mms_conv3_bwd_data_group(bd, ng, s));
-            SYNC(at<double>(cx[0].ws, P.bb_y1[l]), P.R[b], 2 * 128, 128, 128);
+            if (!b4_bwd) {
+                TRY(mms_conv3_bwd_data_group(bd, ng, s));
+                SYNC(at<double>(cx[0].ws, P.bb_y1[l]), P.R[b], 2 * 128, 128, 128);
+            }
             if (defer) {
                 if (nq + ng > MMS_MAX_GROUP) TRY(flush_w());
                 FOR_G { bwq[nq] = bw[g]; c1q[nq] = c1[g]; ++nq; }
@@ -544,6 +564,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
                     side_pending = true;
                 }
             }
+            if (b4_bwd) continue;
             TRY(mms_conv1_bwd_data_group(c1, ng, s));
             SYNC(at<double>(cx[0].ws, P.bb_in[l]), P.R[b], 2 * 1024, C, 1024);
             if (!fuse_apply) TRY(mms_bn_bwd_apply_group(ap, ng, s));

@@ -15,6 +15,7 @@ struct B4Layer {               // device table entry, one per dense layer of blo
     const float *g2, *b2, *wpf, *wpb;          // norm2 gamma / beta [128], packed conv2 weights [32][27][128] / [128][27][32]
     const float *rm1, *rv1, *rm2, *rv2;        // running statistics (eval-mode forward)
     float* y1; double* st_y1;                  // pre-BatchNorm2 activations [M][128] and their (sum | sumsq) [2][128], saved for the backward
+    float* dmid; double* bb_y1;                // backward: masked gradient at norm2's output [M][128] and its BatchNorm-backward sums (s1 | s2) [2][128]
 };
 struct B4FwdP {
     const B4Layer* tab; int nlayers; int C0;   // 16 layers, 512 input channels
@@ -26,3 +27,15 @@ struct B4FwdP {
     unsigned* counter; unsigned* err;          // counter: zero on entry; err: sticky time-out flag
 };
 extern "C" int mms_b4_fwd_group(const B4FwdP* pp, int ng, hipStream_t s);
+struct B4BwdP {                // the data path of block 4's backward (dslab -> norm2/conv2 -> norm1/conv1 -> dslab, layer 15 .. 0) as one launch
+    const B4Layer* tab; int nlayers; int C0;
+    const float* slab; float* dslab; int ld;   // saved activations / their gradient [M][ld = 1024]; on entry dslab holds d(loss)/d(slab) from norm5,
+                                               // on exit columns [0, C0) are the block input's gradient and [C_l, C_l + 32) layer l's final dz
+    const double* st_slab;                     // (sum | sumsq) [2][ld] of the slab channels, one replica
+    const int* coords; Dims3 g; int M;         // M <= 16 rows
+    float eps;
+    float* xa;                                 // hand-off buffer [8][256]
+    unsigned* counter; unsigned* err;          // counter: zero on entry (its own word); err: sticky time-out flag
+    float* dg1[16]; float* db1[16];            // norm1 gamma / beta gradients of the layers (accumulated into)
+};
+extern "C" int mms_b4_bwd_group(const B4BwdP* pp, int ng, hipStream_t s);
