@@ -77,7 +77,8 @@ def measure_conv2_family(B, dims, device, G, reps=20):
     events on the launch stream (torch's current stream), launched exactly as the step launches it: one launch carries the G
     models of a sub-group, shape by shape (the four dense blocks) with the driver's own split factors, weighted by the layer
     counts.  Algorithmic FLOPs per launch of any of the three = G * 2 * M * 27 * 128 * 32.  (Block 4's forward launches do not exist in
-    the step when the block runs as one persistent launch, csrc/dn_b4.hip: they are then left out of the forward op's average.)
+    the step when the block runs as one persistent launch per pass, csrc/dn_b4.hip: they are then left out of the forward / backward-data
+    ops' averages; its weight-gradient launches remain.)
     -> {op: (avg seconds per launch, avg FLOPs per launch, launches per step)}"""
     from multimodal_survival_prediction_amd import _lib, ops
     lib, S = _lib.load_library(), _lib.structs()
@@ -85,6 +86,7 @@ def measure_conv2_family(B, dims, device, G, reps=20):
     gam, bet = torch.ones(128, device=device), torch.zeros(128, device=device)
     tot = {k: [0.0, 0.0, 0] for k in ("fwd", "bwd_data", "bwd_weight")}
     b4_one = B * (D // 32) * (H // 32) * (W // 32) <= 16 and os.environ.get("MMS_PERSIST_B4", "1") != "0"
+    b4_bwd = b4_one and os.environ.get("MMS_PERSIST_B4", "2") not in ("0", "1")        # block 4's backward data path is one launch too
     w = torch.randn(32, 128, 3, 3, 3, device=device) * 0.03
     wpf, wpb = ops.pack_conv3(w)
     for i, (layers, _) in enumerate(BLOCKS):
@@ -118,7 +120,7 @@ def measure_conv2_family(B, dims, device, G, reps=20):
                 "bwd_data": ((S["Conv3BwdDataP"] * G)(*bd), lib.mms_conv3_bwd_data_group),
                 "bwd_weight": ((S["Conv3BwdWP"] * G)(*bw), lib.mms_conv3_bwd_weight_group)}
         for op, (arr, fn) in arrs.items():
-            if op == "fwd" and i == 3 and b4_one:
+            if i == 3 and ((op == "fwd" and b4_one) or (op == "bwd_data" and b4_bwd)):
                 continue
             for _ in range(3):
                 _lib.check(fn(arr, G, ops.stream()), op)

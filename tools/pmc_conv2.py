@@ -34,12 +34,12 @@ def calls(rows, value):
     return out
 
 
-B4_ONE = True        # block 4's forward runs as one persistent launch (csrc/dn_b4.hip): bench.py's leg skips (fwd, block 4)
+B4_ONE = True        # block 4's forward and backward data path run as one persistent launch each (csrc/dn_b4.hip): bench.py's leg skips (fwd | bwd_data, block 4)
 
 
 def per_op(cs, groups):
     """mean per timed call, layer-weighted, pooled over the sub-group sizes (as bench.roofline_block pools them)"""
-    combos = [(blk, op) for blk in range(4) for op in OPS if not (B4_ONE and blk == 3 and op == "fwd")]
+    combos = [(blk, op) for blk in range(4) for op in OPS if not (B4_ONE and blk == 3 and op in ("fwd", "bwd_data"))]
     assert len(cs) == len(groups) * len(combos) * 23, (len(cs), len(groups))
     acc = {op: [0.0, 0] for op in OPS}
     i = 0
@@ -75,7 +75,7 @@ def main():
     for op in OPS:
         alg, nl = 0.0, 0
         for blk in range(4):
-            if B4_ONE and blk == 3 and op == "fwd":
+            if B4_ONE and blk == 3 and op in ("fwd", "bwd_data"):
                 continue
             nl += LAYERS[blk]
             gd = [d // 4 >> blk for d in DIMS]
