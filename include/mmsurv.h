@@ -373,15 +373,19 @@ typedef struct MixP {
     float* dbias[4];
 } MixP;
 
-/* Batch assembly from a device-resident cohort (the DataLoader collate of R/scripts/training/final_multimodal.py:228-236
- * when the tensors already live in HBM): row idx[b] of each source array -> row b of its destination, all sources of
- * all models of a fold group in ONE launch. */
+/* Batch assembly (the DataLoader collate + `.to(device)` of R/scripts/training/final_multimodal.py:228-247): row idx[b] of each
+ * source array -> row b of its destination, all sources of all models of a fold group in ONE launch.  The sources live in HBM
+ * (device-resident cohort) or in PINNED HOST memory (hipHostMalloc / torch pin_memory: the kernel then reads the rows over PCIe --
+ * the host-to-device copy of the batch IS this launch).  present[i] != NULL: per-patient availability flag of source i's modality
+ * (the cohort's mask column; R/scripts/training/partial_modality_training.py:96-141 yields all-zero tensors for a missing modality):
+ * rows whose flag is 0 are zero-filled without being read (4 of 5 CT rows of BASELINE config 3's cohort). */
 typedef struct GatherP {
     const long long* idx; int B;    // [B] patient indices (device)
     int nsrc;                       // sources used (<= 8)
     const float* src[8]; float* dst[8];
     int src_ld[8]; int dst_ld[8];   // row pitches in floats
     int width[8];                   // floats copied per row
+    const float* present[8]; int present_ld[8];   // optional availability flag of row r: present[i][r * present_ld[i]]
 } GatherP;
 
 /* ---- ABI self-description ---- */

@@ -605,10 +605,20 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const Grp<GatherP> grp
         const float* src = p.src[s] + (size_t)row * p.src_ld[s];
         float* dst = p.dst[s] + (size_t)b * p.dst_ld[s];
         const int w = p.width[s];
+        const bool absent = p.present[s] && p.present[s][(size_t)row * p.present_ld[s]] == 0.f;     // all-zero row by contract: not read
         if ((w & 3) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
-            for (int i = t0; i < (w >> 2); i += stride) ((float4*)dst)[i] = ((const float4*)src)[i];
+            if (absent) { for (int i = t0; i < (w >> 2); i += stride) ((float4*)dst)[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+            else {
+                int i = t0;
+                for (; i + 3 * stride < (w >> 2); i += 4 * stride) {        // four 16-B loads in flight per thread (host-resident rows: PCIe latency)
+                    const float4 a = ((const float4*)src)[i], b = ((const float4*)src)[i + stride], c = ((const float4*)src)[i + 2 * stride],
+                                 d = ((const float4*)src)[i + 3 * stride];
+                    ((float4*)dst)[i] = a; ((float4*)dst)[i + stride] = b; ((float4*)dst)[i + 2 * stride] = c; ((float4*)dst)[i + 3 * stride] = d;
+                }
+                for (; i < (w >> 2); i += stride) ((float4*)dst)[i] = ((const float4*)src)[i];
+            }
         } else {
-            for (int i = t0; i < w; i += stride) dst[i] = src[i];
+            for (int i = t0; i < w; i += stride) dst[i] = absent ? 0.f : src[i];
         }
     }
 }

@@ -63,6 +63,13 @@ def cohort_to(cohort, device):
     return {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in cohort.items()}
 
 
+def cohort_pin(cohort):
+    """The cohort in PINNED host memory (the reference's situation: data on the host, `.to(device)` per batch,
+    final_multimodal.py:228-247).  A lazy BatchLoader over it names its batches by index exactly as over a device-resident cohort;
+    the consumer's gather launch then reads the patients' rows over PCIe -- the batch's host-to-device copy is that one launch."""
+    return {k: (v.pin_memory() if isinstance(v, torch.Tensor) else v) for k, v in cohort.items()}
+
+
 def gather_view(cohort, with_valid):
     """The dict the fused batch gather (FoldGroupEngine.train_step_indexed) reads: the cohort itself plus, when the style masks
     unlabeled patients out of the loss, a float `valid` column = has_survival.  One object per (cohort, with_valid), so that all
@@ -72,6 +79,8 @@ def gather_view(cohort, with_valid):
         v = {k: t for k, t in cohort.items() if not k.startswith("_gather_view_") and k != "valid"}
         if with_valid:
             v["valid"] = cohort["has_survival"].to(torch.float32)
+            if cohort["label"].is_pinned():
+                v["valid"] = v["valid"].pin_memory()
         cohort[key] = v
     return cohort[key]
 
@@ -115,47 +124,3 @@ def kfold_indices(n, n_splits, seed=42):
     """sklearn KFold(n_splits, shuffle=True, random_state=seed).split(range(n)) (final_multimodal.py:316)."""
     from sklearn.model_selection import KFold
     return list(KFold(n_splits=n_splits, shuffle=True, random_state=seed).split(np.arange(n)))
-
-
-class HostBatchLoader:
-    """The reference's situation (final_multimodal.py:228-247: host-side DataLoader collate, `.to(device)` per batch): the cohort
-    lives in PINNED host memory and a batch is only NAMED here -- dict(index=[B] patient indices, host=<this loader>, scal=pinned
-    [3][B] time/event/valid, has_survival=[...]); the consumer (SurvivalEngine.load_host_rows) issues one asynchronous PCIe copy per
-    patient row straight from the pinned cohort into the step graph's static input buffers, so the collate is done by the DMA
-    engine and overlaps the previous step's kernels.  (Collating on the CPU first is slow here: CPU reads of pinned memory run at
-    ~1 GB/s on this platform -- 2 ms per 2 MB batch.)  The small scalar staging slot is reused only after the event recorded behind
-    its copies completed."""
-
-    def __init__(self, cohort_pinned, indices, batch_size, shuffle=False, seed=0, device="cuda", depth=8):
-        self.c, self.idx, self.bs, self.shuffle = cohort_pinned, torch.as_tensor(indices), batch_size, shuffle
-        self.gen = torch.Generator().manual_seed(seed)
-        self.device = device
-        lab = cohort_pinned["label"]
-        self.hs = cohort_pinned["has_survival"].tolist()
-        self.scal_src = torch.stack([lab[:, 0], lab[:, 1], cohort_pinned["has_survival"].to(torch.float32)]).clone()   # pageable: fast CPU reads
-        self.ring = [torch.empty(3, batch_size).pin_memory() for _ in range(depth)]
-        self.events = [None] * depth
-
-    def __len__(self):
-        return (len(self.idx) + self.bs - 1) // self.bs
-
-    def __iter__(self):
-        idx = self.idx[torch.randperm(len(self.idx), generator=self.gen)] if self.shuffle else self.idx
-        slot, prev = 0, None
-        for i in range(0, len(idx), self.bs):
-            if prev is not None:                     # the consumer has enqueued its copies of the previous batch by now
-                ev = torch.cuda.Event()
-                ev.record()
-                self.events[prev] = ev
-            if self.events[slot] is not None:
-                self.events[slot].synchronize()
-            j = idx[i:i + self.bs]
-            n = len(j)
-            torch.index_select(self.scal_src, 1, j, out=self.ring[slot][:, :n])
-            b = dict(index=j, host=self, scal=self.ring[slot][:, :n], has_survival=[self.hs[int(q)] for q in j])
-            prev, slot = slot, (slot + 1) % len(self.ring)
-            yield b
-        if prev is not None:
-            ev = torch.cuda.Event()
-            ev.record()
-            self.events[prev] = ev

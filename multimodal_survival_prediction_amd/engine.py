@@ -517,36 +517,27 @@ class SurvivalEngine:
         else:
             P.valid.copy_(valid.reshape(-1).to(torch.float32), non_blocking=True)
 
-    def load_host_rows(self, P, hb):
-        """Batch named by data.HostBatchLoader: one asynchronous host -> device copy per patient row, straight from the pinned cohort
-        into this plan's static input buffers (what the reference's `.to(device)` per batch does, final_multimodal.py:244-247)."""
-        c, jl = hb["host"].c, hb["index"].tolist()
-        for r, q in enumerate(jl):
-            if P.has_enc:
-                P.ct[r].copy_(c["image"][q], non_blocking=True)
-            P.buf["rna"][r].copy_(c["rnaseq"][q], non_blocking=True)
-            if "clin" in P.buf:
-                P.buf["clin"][r].copy_(c["clinical"][q], non_blocking=True)
-            if P.gate is not None:
-                P.mask[r].copy_(c["mask"][q], non_blocking=True)
-            if P.mix is not None:
-                P.mask2[r].copy_(c["mask"][q, :P.mask2.shape[1]], non_blocking=True)
-        sc = hb["scal"]
-        P.time.copy_(sc[0], non_blocking=True); P.event.copy_(sc[1], non_blocking=True)
-        if hb.get("use_valid", True):
-            P.valid.copy_(sc[2], non_blocking=True)
-        else:
-            P.valid.fill_(1.0)
-
     def gather_block(self, P, cohort, idx_dev):
-        """GatherP (include/mmsurv.h) that assembles this plan's batch from a device-resident cohort dict
-        (data.make_cohort / cohort_to): image, rnaseq, clinical, mask, label[time, event] and, when present, a float
-        per-patient `valid` column.  idx_dev: [B] int64 device tensor that the caller refills before each launch."""
+        """GatherP (include/mmsurv.h) that assembles this plan's batch from a cohort dict (data.make_cohort) that lives in HBM
+        (data.cohort_to) or in pinned host memory (data.cohort_pin: the gather launch then reads the rows over PCIe): image, rnaseq,
+        clinical, mask, label[time, event] and, when present, a float per-patient `valid` column.  idx_dev: [B] int64 device tensor
+        that the caller refills before each launch.  With a modality mask in the cohort, image / rnaseq rows of patients without that
+        modality are zero-filled instead of read -- after checking once that they are all-zero in the cohort, as the reference's
+        dataset makes them (partial_modality_training.py:96-141)."""
         G = _S()["GatherP"]()
         G.idx, G.B = idx_dev.data_ptr(), P.B
-        srcs = [(cohort["rnaseq"], P.buf["rna"], None)]
+        flags = {}
+        if "mask" in cohort:
+            chk = cohort.setdefault("_absent_rows_zero", {})
+            for j, key in enumerate(("image", "rnaseq")):
+                if key not in chk:
+                    gone = cohort["mask"][:, j] == 0
+                    chk[key] = bool((cohort[key][gone] == 0).all()) if bool(gone.any()) else True
+                if chk[key]:
+                    flags[key] = cohort["mask"][:, j:]
+        srcs = [(cohort["rnaseq"], P.buf["rna"], None, flags.get("rnaseq"))]
         if P.has_enc:
-            srcs.append((cohort["image"].view(cohort["image"].shape[0], -1), P.ct.view(P.B, -1), None))
+            srcs.append((cohort["image"].view(cohort["image"].shape[0], -1), P.ct.view(P.B, -1), None, flags.get("image")))
         if "clin" in P.buf:
             srcs.append((cohort["clinical"], P.buf["clin"], None))
         if P.gate is not None:
@@ -559,12 +550,15 @@ class SurvivalEngine:
         if "valid" in cohort:
             srcs.append((cohort["valid"].view(-1, 1), P.valid.view(P.B, 1), 1))
         G.nsrc = len(srcs)
-        for i, (a, b, w) in enumerate(srcs):
-            if a.dtype != torch.float32 or not a.is_cuda:
-                raise TypeError("gather sources must be fp32 device tensors")
+        for i, src in enumerate(srcs):
+            a, b, w, flag = src if len(src) == 4 else src + (None,)
+            if a.dtype != torch.float32 or not (a.is_cuda or a.is_pinned()):
+                raise TypeError("gather sources must be fp32 tensors in device or pinned host memory")
             G.src[i], G.dst[i] = a.data_ptr(), b.data_ptr()
             G.src_ld[i], G.dst_ld[i] = a.stride(0), b.stride(0)
             G.width[i] = w if w is not None else a.shape[1]
+            if flag is not None:
+                G.present[i], G.present_ld[i] = flag.data_ptr(), flag.stride(0)
         return G
 
     def train_step(self, ct=None, rna=None, clinical=None, mask=None, time=None, event=None, valid=None, skip_if_unusable=True,

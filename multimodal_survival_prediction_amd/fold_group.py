@@ -199,32 +199,22 @@ class FoldGroupEngine:
         if len(batches) != len(members):
             raise ValueError("one batch per member")
         has_enc = self.engines[0].prog["encoder"] is not None
-        host = "host_batch" in batches[0]            # data.HostBatchLoader: rows copied host -> device by load_host_rows
-        if host:
-            B = len(batches[0]["host_batch"]["index"])
-            dims = tuple(batches[0]["host_batch"]["host"].c["image"].shape[-3:]) if has_enc else None
-            if any(len(b["host_batch"]["index"]) != B for b in batches):
+        B = batches[0]["rna"].shape[0]
+        dims = tuple(batches[0]["ct"].shape[-3:]) if has_enc else None
+        for b in batches:
+            if b["rna"].shape[0] != B or (has_enc and tuple(b["ct"].shape[-3:]) != dims):
                 raise ValueError("fold-group batches must share one shape; split ragged tails into their own step")
-        else:
-            B = batches[0]["rna"].shape[0]
-            dims = tuple(batches[0]["ct"].shape[-3:]) if has_enc else None
-            for b in batches:
-                if b["rna"].shape[0] != B or (has_enc and tuple(b["ct"].shape[-3:]) != dims):
-                    raise ValueError("fold-group batches must share one shape; split ragged tails into their own step")
         GP = self.plan(B, dims, members)
         for e, P, b in zip(GP.eng, GP.Ps, batches):
-            if host:
-                e.load_host_rows(P, b["host_batch"])
-            else:
-                e.load_batch(P, **b)
+            e.load_batch(P, **b)
         if not use_graph:
             self._train_body(GP, skip_if_unusable)
             return
         self._graph(GP, ("train", bool(skip_if_unusable)), lambda: self._train_body(GP, skip_if_unusable)).replay()
 
     def train_step_indexed(self, cohort, indices, members=None, skip_if_unusable=True, use_graph=True):
-        """Same step with the batches named by patient indices into a DEVICE-resident cohort (data.cohort_to):
-        indices: [len(members)][B] integer array-like (host).  The batch assembly of the whole group is one small
+        """Same step with the batches named by patient indices into a cohort that lives in HBM (data.cohort_to) or in pinned host
+        memory (data.cohort_pin: the gather launch reads the rows over PCIe): indices: [len(members)][B] integer array-like (host).  The batch assembly of the whole group is one small
         host-to-device copy of the indices plus ONE gather launch (mms_gather_rows_group) instead of ~10 torch
         indexing/copy kernels per member."""
         members = tuple(range(len(self.engines))) if members is None else tuple(members)

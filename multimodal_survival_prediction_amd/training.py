@@ -277,11 +277,6 @@ def _train_kwargs(style, batch):
         return dict(ct=batch['image'], rna=batch['rnaseq'], clinical=batch['clinical'], time=label[:, 0], event=label[:, 1])
     if style == "rnaseq":
         return dict(rna=batch['rnaseq'], time=batch['time'].reshape(-1), event=batch['event'].reshape(-1))
-    if "host" in batch:          # data.HostBatchLoader: the batch is named; the engine copies its rows host -> device itself
-        if style in ("simple", "flexible") and sum(bool(x) for x in batch["has_survival"]) < 2:
-            return None
-        batch["use_valid"] = style != "final"
-        return dict(host_batch=batch)
     valid = torch.as_tensor(batch['has_survival'], dtype=torch.float32)
     if style == "partial":
         label = batch['label']
@@ -343,7 +338,7 @@ def train_epoch_lockstep(group, loaders, style, members=None, concurrent=1):
         for g, batch in pos.items():
             kw = _train_kwargs(style, batch)
             if kw is not None:
-                n = len(kw["host_batch"]["index"]) if "host_batch" in kw else int(kw["rna"].shape[0])
+                n = int(kw["rna"].shape[0])
                 by_size.setdefault(n, []).append((g, kw))
         for items in by_size.values():           # a ragged last batch forms its own (sub-)group step
             group.train_step([kw for _, kw in items], members=tuple(g for g, _ in items),

@@ -192,6 +192,33 @@ def test_lockstep_epoch_matches_oracle_loops(lr):
             assert vgot[f][0] == pytest.approx(vwant[0], rel=1e-4) and abs(vgot[f][1] - vwant[1]) <= 1e-6
 
 
+def test_lockstep_epoch_from_pinned_host_cohort_matches_device_cohort():
+    """The host-resident data path (data.cohort_pin: the gather launch reads the batch rows over PCIe and zero-fills the rows of
+    missing modalities instead of reading them) must assemble exactly the batches of the device-resident path: same models, same
+    splits (ragged tail, unlabelled patients, missing CT / RNA-seq), one lock-step epoch at lr = 0 (so that run-to-run summation
+    order of the weight-gradient atomics cannot enter): returned losses and BatchNorm running statistics agree to 1e-6."""
+    from multimodal_survival_prediction_amd import data, training
+    from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
+    cohort = _cohort()
+    assert float((cohort["mask"][:, 0] == 0).sum()) > 0 and float((cohort["mask"][:, 1] == 0).sum()) > 0      # the zero-fill branch is exercised
+    splits = [np.arange(22), np.concatenate([np.arange(4, 22), np.arange(0, 2)])]
+    outs = []
+    for place in (lambda c: data.cohort_to(c, DEV), data.cohort_pin):
+        src = place(dict(cohort))
+        pairs = [_pair("PartialModalityNet", 21), _pair("PartialModalityNet", 22)]
+        group = FoldGroupEngine([p[1] for p in pairs], lr=0.0, weight_decay=1e-4, adamw=False, gate_entropy_weight=0.01)
+        tl = [data.BatchLoader(src, s, 4, shuffle=False, lazy=True, with_valid=True) for s in splits]
+        got = training.train_epoch_lockstep(group, tl, "partial")
+        torch.cuda.synchronize()
+        outs.append((got, [[q.detach().clone() for q in p[1].buffers() if q.dtype == torch.float32] for p in pairs]))
+    (la, ba), (lb, bb) = outs
+    for x, y in zip(la, lb):
+        assert x[0] == pytest.approx(y[0], rel=1e-6) and x[1] == pytest.approx(y[1], rel=1e-6), (la, lb)
+    for ma, mb in zip(ba, bb):
+        for a, b in zip(ma, mb):
+            assert_close(b, a, 1e-6, "running statistics")
+
+
 def test_config1_simple_fusion_ct_stubbed():
     """BASELINE config 1: simple_fusion.py, 88 synthetic complete patients, CT encoder input stubbed to zero volumes (RNA-seq heads do
     the work), batch 4, fold 1 of 3: one epoch of the HIP train_epoch + validate against the oracle loops (dropout off)."""
