@@ -238,7 +238,7 @@ def run_config3(args, world, rank, dev):
         tr = [np.concatenate([survival[f[0]], non_survival]) for f in folds]          # partial_modality_training.py:508-513
         va = [survival[f[1]] for f in folds]
         return ([data.BatchLoader(cohort, t, B, shuffle=True, seed=random_state + k, lazy=True, with_valid=True) for k, t in enumerate(tr)],
-                [data.BatchLoader(cohort, v, B, shuffle=False) for v in va], tr, folds)
+                [data.BatchLoader(cohort, v, B, shuffle=False, lazy=True, with_valid=True) for v in va], tr, folds)
 
     rep = rank                                                     # N > 1: rank r = repetition r of the K-fold CV
     train_loaders, val_loaders, train_sets, folds = cv_loaders(42 + rep)

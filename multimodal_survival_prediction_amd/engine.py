@@ -140,6 +140,7 @@ class SurvivalEngine:
         self.dropout_masks = {}      # parity mode: {lin index: [B, K] multiplicative mask}
         # device-side epoch accumulators: [sum loss*usable, n usable, sum entropy, n batches]
         self.acc = torch.zeros(4, device=self.device)
+        self.acc_eval = torch.zeros(4, device=self.device)      # validation: [sum of batch losses, usable batches, -, batches]
         model._mms_engine = self
 
     # ---- parameters ------------------------------------------------------------------------------
@@ -283,6 +284,10 @@ class SurvivalEngine:
         hz = P.buf["hz"]
         P.cox = _S()["CoxP"](hz.data_ptr(), 1, P.time.data_ptr(), P.event.data_ptr(), P.valid.data_ptr(), B, 1.0,
                              P.lse.data_ptr(), P.dbuf["hz"].data_ptr(), 1, P.cox_out.data_ptr(), self.tie_mode, P.tie_frac.data_ptr())
+        # validation: the batch's Cox value only (no gradient), (loss | usable) kept per batch for validate_*'s bookkeeping
+        P.cox_eval_out = torch.zeros(2, device=self.device)
+        P.cox_eval = _S()["CoxP"](hz.data_ptr(), 1, P.time.data_ptr(), P.event.data_ptr(), P.valid.data_ptr(), B, 1.0,
+                                  P.lse.data_ptr(), None, 1, P.cox_eval_out.data_ptr(), self.tie_mode, P.tie_frac.data_ptr())
         book = dict(acc=self.acc, cox_out=P.cox_out, entropy=self.entropy, rng=self.rng)   # per-step bookkeeping, in-kernel
         P.adam = ops.adam_params(self.flat, self.gflat, self.m, self.v, self.hyper, self.sumsq, self.step_count,
                                  None, self.adamw, **book)

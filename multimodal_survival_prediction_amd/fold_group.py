@@ -102,6 +102,7 @@ class FoldGroupEngine:
         GP.lin_bwd = [_arr([P.lin_bwd[i] for P in Ps]) for i in range(nl)]
         GP.gate = _arr([P.gate for P in Ps]) if Ps[0].gate is not None else None
         GP.cox = _arr([P.cox for P in Ps])
+        GP.cox_eval = _arr([P.cox_eval for P in Ps])
         GP.adam = {True: _arr([P.adam_skip for P in Ps]), False: _arr([P.adam for P in Ps])}
         GP.graphs = {}
         # zeroing: the whole group's buffers when the group is complete and contiguous, else per member
@@ -164,13 +165,13 @@ class FoldGroupEngine:
     # ---- state snapshot around graph warm-up ---------------------------------------------------------
     def _snapshot(self, eng):
         return [[e.flat.clone(), e.m.clone(), e.v.clone(), e.step_count.clone(), e.rng.clone(), e.acc.clone(),
-                 [b.clone() for b in e.model.buffers()]] for e in eng]
+                 [b.clone() for b in e.model.buffers()], e.acc_eval.clone()] for e in eng]
 
     def _restore(self, eng, snap):
         with torch.no_grad():
             for e, s in zip(eng, snap):
                 e.flat.copy_(s[0]); e.m.copy_(s[1]); e.v.copy_(s[2]); e.step_count.copy_(s[3]); e.rng.copy_(s[4])
-                e.acc.copy_(s[5])
+                e.acc.copy_(s[5]); e.acc_eval.copy_(s[7])
                 for b, b0 in zip(e.model.buffers(), s[6]):
                     b.copy_(b0)
 
@@ -212,18 +213,9 @@ class FoldGroupEngine:
             return
         self._graph(GP, ("train", bool(skip_if_unusable)), lambda: self._train_body(GP, skip_if_unusable)).replay()
 
-    def train_step_indexed(self, cohort, indices, members=None, skip_if_unusable=True, use_graph=True):
-        """Same step with the batches named by patient indices into a cohort that lives in HBM (data.cohort_to) or in pinned host
-        memory (data.cohort_pin: the gather launch reads the rows over PCIe): indices: [len(members)][B] integer array-like (host).  The batch assembly of the whole group is one small
-        host-to-device copy of the indices plus ONE gather launch (mms_gather_rows_group) instead of ~10 torch
-        indexing/copy kernels per member."""
-        members = tuple(range(len(self.engines))) if members is None else tuple(members)
-        idx = torch.as_tensor(indices, dtype=torch.int64)
-        if idx.dim() != 2 or idx.shape[0] != len(members):
-            raise ValueError("indices must be [len(members)][B]")
-        B = idx.shape[1]
-        dims = tuple(cohort["image"].shape[-3:]) if self.engines[0].prog["encoder"] is not None else None
-        GP = self.plan(B, dims, members)
+    def _gather_indexed(self, GP, cohort, idx):
+        """Index copy (pinned ring -> device) + the ONE gather launch that assembles the group's batches in the plans' input buffers."""
+        members, B = GP.members, GP.B
         key = id(cohort)
         cache = GP.__dict__.setdefault("gather", {})
         if key not in cache:
@@ -248,10 +240,46 @@ class FoldGroupEngine:
         ev.record()
         pin["evs"][k] = ev
         _lib.check(self.lib.mms_gather_rows_group(blocks, GP.ng, ops.stream()), "mms_gather_rows_group")
+
+    def train_step_indexed(self, cohort, indices, members=None, skip_if_unusable=True, use_graph=True):
+        """Same step with the batches named by patient indices into a cohort that lives in HBM (data.cohort_to) or in pinned host
+        memory (data.cohort_pin: the gather launch reads the rows over PCIe): indices: [len(members)][B] integer array-like (host).  The batch assembly of the whole group is one small
+        host-to-device copy of the indices plus ONE gather launch (mms_gather_rows_group) instead of ~10 torch
+        indexing/copy kernels per member."""
+        members = tuple(range(len(self.engines))) if members is None else tuple(members)
+        idx = torch.as_tensor(indices, dtype=torch.int64)
+        if idx.dim() != 2 or idx.shape[0] != len(members):
+            raise ValueError("indices must be [len(members)][B]")
+        B = idx.shape[1]
+        dims = tuple(cohort["image"].shape[-3:]) if self.engines[0].prog["encoder"] is not None else None
+        GP = self.plan(B, dims, members)
+        self._gather_indexed(GP, cohort, idx)
         if not use_graph:
             self._train_body(GP, skip_if_unusable)
             return
         self._graph(GP, ("train", bool(skip_if_unusable)), lambda: self._train_body(GP, skip_if_unusable)).replay()
+
+    def _eval_loss_body(self, GP):
+        """Eval-mode forward of every member + the Cox value of its batch (no gradient) + the validation accumulators."""
+        self._forward(GP, False)
+        _lib.check(self.lib.mms_cox_fwd_bwd_group(GP.cox_eval, GP.ng, ops.stream()), "mms_cox_fwd_bwd_group")
+        for e, P in zip(GP.eng, GP.Ps):
+            e.acc_eval[:2] += P.cox_eval_out         # (the loss is 0 when the batch is unusable)
+            e.acc_eval[3] += 1.0
+
+    def eval_loss_step_indexed(self, cohort, indices, members=None):
+        """validate_*'s step with the batches named by patient indices (as train_step_indexed): gather + ONE graph (eval-mode forward,
+        Cox value of each member's batch, accumulators SurvivalEngine.acc_eval).  -> per member (hazard [B], (loss | usable) [2]):
+        views of static buffers, valid until the next step of this plan."""
+        members = tuple(range(len(self.engines))) if members is None else tuple(members)
+        idx = torch.as_tensor(indices, dtype=torch.int64)
+        if idx.dim() != 2 or idx.shape[0] != len(members):
+            raise ValueError("indices must be [len(members)][B]")
+        dims = tuple(cohort["image"].shape[-3:]) if self.engines[0].prog["encoder"] is not None else None
+        GP = self.plan(idx.shape[1], dims, members)
+        self._gather_indexed(GP, cohort, idx)
+        self._graph(GP, "evalloss", lambda: self._eval_loss_body(GP)).replay()
+        return [(P.buf["hz"][:, 0], P.cox_eval_out) for P in GP.Ps]
 
     def forward_eval(self, batches, members=None, use_graph=True):
         """Eval-mode forward of every member -> list of (hazard [B] view, gate [B,3] or None) per member."""

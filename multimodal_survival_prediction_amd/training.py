@@ -390,10 +390,67 @@ def train_epoch_lockstep(group, loaders, style, members=None, concurrent=1):
     return out
 
 
+def _validate_lockstep_named(group, loaders, style, members):
+    """validate_final / validate_partial over lazily NAMED batches (data.BatchLoader(lazy=True), cohort in HBM or pinned host memory):
+    per lock-step position one gather launch + one graph (eval-mode forwards, the batches' Cox values, device-side accumulators); the
+    hazards stay on the device and the host is synchronised ONCE, at the end (the reference and the eager path sync per batch).
+    Bookkeeping as the reference's loops: final -- every batch counts, loss 0 when it has no event (final_multimodal.py:268-305);
+    partial -- a batch counts, and its labelled patients enter the C-index, only when >= 2 of them are labelled and one has an event
+    (partial_modality_training.py:438-485)."""
+    dev = group.device
+    for g in members:
+        group.engines[g].model.eval()
+        group.engines[g].acc_eval.zero_()
+    n_rows = {g: len(ld.idx) for g, ld in zip(members, loaders)}
+    n_bat = {g: len(ld) for g, ld in zip(members, loaders)}
+    hz = {g: torch.zeros(n_rows[g], device=dev) for g in members}
+    flags = {g: torch.zeros(max(n_bat[g], 1), 2, device=dev) for g in members}
+    order = {g: [] for g in members}          # (patient indices, labelled flags) of the batches in the order they were evaluated
+    off = {g: 0 for g in members}
+    for pos in _lockstep(loaders, members):
+        by = {}
+        for g, b in pos.items():
+            by.setdefault((len(b["index"]), id(b["gather"])), []).append((g, b))
+        for items in by.values():
+            outs = group.eval_loss_step_indexed(items[0][1]["gather"], torch.stack([torch.as_tensor(b["index"]) for _, b in items]),
+                                                members=tuple(g for g, _ in items))
+            for (g, b), (h, lf) in zip(items, outs):
+                n = len(b["index"])
+                hz[g][off[g]:off[g] + n].copy_(h)
+                flags[g][len(order[g])].copy_(lf)
+                order[g].append((torch.as_tensor(b["index"]), torch.as_tensor(b["has_survival"], dtype=torch.bool)))
+                off[g] += n
+    torch.cuda.synchronize()
+    out = []
+    for g, ld in zip(members, loaders):
+        a = group.engines[g].acc_eval.tolist()
+        if not order[g]:
+            out.append((0, 0.5))
+            continue
+        lab = ld.c["label"]
+        idx = torch.cat([i for i, _ in order[g]])
+        if style == "final":
+            keep = torch.ones(len(idx), dtype=torch.bool)
+            avg = a[0] / a[3] if a[3] > 0 else 0
+        else:
+            usable = flags[g][:len(order[g]), 1].cpu() > 0
+            keep = torch.cat([m & bool(u) for (_, m), u in zip(order[g], usable)])
+            avg = a[0] / a[1] if a[1] > 0 else 0
+        if not bool(keep.any()):
+            out.append((0, 0.5))
+            continue
+        sel = idx[keep].to(lab.device)
+        H, T, E = hz[g][keep.to(dev)], lab[sel, 0].to(dev), lab[sel, 1].to(dev)
+        out.append((avg, losses.calculate_cindex(H, E, T)))
+    return out
+
+
 def validate_lockstep(group, loaders, style, device, members=None):
     """validate_<style> of the folds `members`, their eval forwards issued as fold-group launches.
     -> per member (val_loss, c_index)."""
     members = tuple(range(len(group))) if members is None else tuple(members)
+    if style in ("final", "partial") and all(getattr(ld, "lazy", False) for ld in loaders):
+        return _validate_lockstep_named(group, loaders, style, members)
     acc = {g: dict(total=0.0, nb=0, hs=[], ts=[], es=[]) for g in members}
     for g in members:
         group.engines[g].model.eval()

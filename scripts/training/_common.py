@@ -67,11 +67,12 @@ def cv_lockstep(style, models, loaders, group_kw, num_epochs, patience, make_sch
     from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
     from multimodal_survival_prediction_amd.training import FusedOptimizer, train_epoch_lockstep, validate_lockstep
     group = FoldGroupEngine(models, **group_kw)
-    for tl, _ in loaders:                      # device-resident cohort: name the training batches, let the group gather them
-        if env_int("MMS_LAZY_BATCHES", 1) and tl.c["image"].is_cuda:
-            tl.lazy = True
-            tl.view = data_mod().gather_view(tl.c, with_valid=(style != "final"))
-            tl.hs_cpu = tl.c["has_survival"].cpu().tolist()
+    for tl, vl in loaders:                     # cohort in HBM (or pinned host memory): name the batches, let the group gather them
+        for ld in ((tl, vl) if style in ("final", "partial") else (tl,)):      # (validate_lockstep's named-batch path: final / partial)
+            if env_int("MMS_LAZY_BATCHES", 1) and (ld.c["image"].is_cuda or ld.c["image"].is_pinned()):
+                ld.lazy = True
+                ld.view = data_mod().gather_view(ld.c, with_valid=(style != "final"))
+                ld.hs_cpu = ld.c["has_survival"].cpu().tolist()
     opts = [FusedOptimizer(m, lr=group_kw.get("lr", 1e-4), weight_decay=group_kw.get("weight_decay", 1e-4)) for m in models]
     scheds = [make_scheduler(o) for o in opts]
     takes_metric = [len(inspect.signature(s.step).parameters) > 0 for s in scheds]

@@ -219,6 +219,31 @@ def test_lockstep_epoch_from_pinned_host_cohort_matches_device_cohort():
             assert_close(b, a, 1e-6, "running statistics")
 
 
+@pytest.mark.parametrize("style,cls", [("partial", "PartialModalityNet"), ("final", "MultiModalSurvivalNet")])
+def test_validate_lockstep_named_batches_match_eager_path(style, cls):
+    """validate_lockstep over lazily NAMED batches (one gather + one graph per lock-step position, Cox values and accumulators on the
+    device, one host sync at the end) against its eager path (batches materialised, per-batch losses through losses.cox_loss with a
+    host sync each -- the path compared with oracle/loops.py above): (avg_loss, c_index) of two fold models on a validation split with
+    an unlabelled patient, a batch without events, a single-labelled batch and a ragged tail."""
+    from multimodal_survival_prediction_amd import data, training
+    from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
+    cohort = _cohort()
+    dev_cohort = data.cohort_to(cohort, DEV)
+    pairs = [_pair(cls, 41), _pair(cls, 42)]
+    group = FoldGroupEngine([p[1] for p in pairs], lr=0.0, weight_decay=1e-4, adamw=False, gate_entropy_weight=0.01)
+    splits = [np.arange(22, cohort["n"]), np.arange(20, cohort["n"] - 1)]
+    wv = style != "final"
+    eager = training.validate_lockstep(group, [data.BatchLoader(dev_cohort, s, 4, shuffle=False) for s in splits], style, DEV)
+    named = training.validate_lockstep(group, [data.BatchLoader(dev_cohort, s, 4, shuffle=False, lazy=True, with_valid=wv) for s in splits],
+                                       style, DEV)
+    again = training.validate_lockstep(group, [data.BatchLoader(dev_cohort, s, 4, shuffle=False, lazy=True, with_valid=wv) for s in splits],
+                                       style, DEV)          # replayed graphs, accumulators reset
+    print(style, "eager", eager, "named", named)
+    for e, n, a in zip(eager, named, again):
+        assert n[0] == pytest.approx(e[0], rel=1e-5, abs=1e-7) and abs(n[1] - e[1]) <= 1e-6
+        assert a[0] == pytest.approx(n[0], rel=1e-6, abs=1e-7) and abs(a[1] - n[1]) <= 1e-6
+
+
 def test_config1_simple_fusion_ct_stubbed():
     """BASELINE config 1: simple_fusion.py, 88 synthetic complete patients, CT encoder input stubbed to zero volumes (RNA-seq heads do
     the work), batch 4, fold 1 of 3: one epoch of the HIP train_epoch + validate against the oracle loops (dropout off)."""
