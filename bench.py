@@ -302,8 +302,8 @@ def run_config3(args, world, rank, dev):
     dt1, _ = timed(lambda: chain(n1))
     dt1 /= n1
     # validation (reported separately): validate_lockstep over the K validation splits
-    validate_lockstep(group, val_loaders, "partial", dev)
-    dtv, val = timed(lambda: validate_lockstep(group, val_loaders, "partial", dev))
+    validate_lockstep(group, val_loaders, "partial", dev, concurrent=conc)
+    dtv, val = timed(lambda: validate_lockstep(group, val_loaders, "partial", dev, concurrent=conc))
     n_val = sum(len(l.idx) for l in val_loaders)
     for e_ in group.engines:
         e_.model.train()

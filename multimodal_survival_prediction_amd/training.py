@@ -344,38 +344,8 @@ def train_epoch_lockstep(group, loaders, style, members=None, concurrent=1):
             group.train_step([kw for _, kw in items], members=tuple(g for g, _ in items),
                              skip_if_unusable=_SKIP_UNUSABLE[style])
 
-    if concurrent <= 1 or len(members) < 4:
-        for pos in _lockstep(loaders, members):
-            advance(pos)
-    else:
-        nsub = min(int(concurrent), len(members))
-        streams = group.__dict__.setdefault("_side_streams", [])
-        while len(streams) < nsub:
-            streams.append(torch.cuda.Stream(device=group.device))
-        # fixed, contiguous sub-groups of near-equal size (5 folds on 2 streams: 3 + 2; on 3 streams: 2 + 2 + 1)
-        base, extra = divmod(len(members), nsub)
-        cuts, o = [], 0
-        for h in range(nsub):
-            n = base + (1 if h < extra else 0)
-            cuts.append((members[o:o + n], loaders[o:o + n]))
-            o += n
-        cur = torch.cuda.current_stream()
-        for s in streams[:nsub]:
-            s.wait_stream(cur)
-        its = [_lockstep(ld, mem) for mem, ld in cuts]
-        live = [True] * nsub
-        while any(live):
-            for h in range(nsub):
-                if not live[h]:
-                    continue
-                with torch.cuda.stream(streams[h]):
-                    pos = next(its[h], None)         # the loaders gather their batches on this stream
-                    if pos is None:
-                        live[h] = False
-                    else:
-                        advance(pos)
-        for s in streams[:nsub]:
-            cur.wait_stream(s)
+    _run_subgroups(group, loaders, members, concurrent, advance)
+    if concurrent > 1 and len(members) >= 4:
         torch.cuda.synchronize()
     out = []
     for g in members:
@@ -390,7 +360,43 @@ def train_epoch_lockstep(group, loaders, style, members=None, concurrent=1):
     return out
 
 
-def _validate_lockstep_named(group, loaders, style, members):
+def _run_subgroups(group, loaders, members, concurrent, advance):
+    """Lock-step iteration of the members' loaders: as one group, or (concurrent = n >= 2 and >= 4 members) as n fixed, contiguous
+    sub-groups of near-equal size, each stepping on its own HIP stream (5 folds on 2 streams: 3 + 2)."""
+    if concurrent <= 1 or len(members) < 4:
+        for pos in _lockstep(loaders, members):
+            advance(pos)
+        return
+    nsub = min(int(concurrent), len(members))
+    streams = group.__dict__.setdefault("_side_streams", [])
+    while len(streams) < nsub:
+        streams.append(torch.cuda.Stream(device=group.device))
+    base, extra = divmod(len(members), nsub)
+    cuts, o = [], 0
+    for h in range(nsub):
+        n = base + (1 if h < extra else 0)
+        cuts.append((members[o:o + n], loaders[o:o + n]))
+        o += n
+    cur = torch.cuda.current_stream()
+    for s in streams[:nsub]:
+        s.wait_stream(cur)
+    its = [_lockstep(ld, mem) for mem, ld in cuts]
+    live = [True] * nsub
+    while any(live):
+        for h in range(nsub):
+            if not live[h]:
+                continue
+            with torch.cuda.stream(streams[h]):
+                pos = next(its[h], None)         # the loaders gather their batches on this stream
+                if pos is None:
+                    live[h] = False
+                else:
+                    advance(pos)
+    for s in streams[:nsub]:
+        cur.wait_stream(s)
+
+
+def _validate_lockstep_named(group, loaders, style, members, concurrent=1):
     """validate_final / validate_partial over lazily NAMED batches (data.BatchLoader(lazy=True), cohort in HBM or pinned host memory):
     per lock-step position one gather launch + one graph (eval-mode forwards, the batches' Cox values, device-side accumulators); the
     hazards stay on the device and the host is synchronised ONCE, at the end (the reference and the eager path sync per batch).
@@ -407,7 +413,7 @@ def _validate_lockstep_named(group, loaders, style, members):
     flags = {g: torch.zeros(max(n_bat[g], 1), 2, device=dev) for g in members}
     order = {g: [] for g in members}          # (patient indices, labelled flags) of the batches in the order they were evaluated
     off = {g: 0 for g in members}
-    for pos in _lockstep(loaders, members):
+    def advance(pos):
         by = {}
         for g, b in pos.items():
             by.setdefault((len(b["index"]), id(b["gather"])), []).append((g, b))
@@ -420,6 +426,8 @@ def _validate_lockstep_named(group, loaders, style, members):
                 flags[g][len(order[g])].copy_(lf)
                 order[g].append((torch.as_tensor(b["index"]), torch.as_tensor(b["has_survival"], dtype=torch.bool)))
                 off[g] += n
+
+    _run_subgroups(group, loaders, members, concurrent, advance)
     torch.cuda.synchronize()
     out = []
     for g, ld in zip(members, loaders):
@@ -445,12 +453,13 @@ def _validate_lockstep_named(group, loaders, style, members):
     return out
 
 
-def validate_lockstep(group, loaders, style, device, members=None):
+def validate_lockstep(group, loaders, style, device, members=None, concurrent=1):
     """validate_<style> of the folds `members`, their eval forwards issued as fold-group launches.
-    -> per member (val_loss, c_index)."""
+    -> per member (val_loss, c_index).  Loaders that NAME their batches (final / partial styles) take _validate_lockstep_named;
+    concurrent = n: as train_epoch_lockstep, n sub-groups on n HIP streams (that path only)."""
     members = tuple(range(len(group))) if members is None else tuple(members)
     if style in ("final", "partial") and all(getattr(ld, "lazy", False) for ld in loaders):
-        return _validate_lockstep_named(group, loaders, style, members)
+        return _validate_lockstep_named(group, loaders, style, members, concurrent)
     acc = {g: dict(total=0.0, nb=0, hs=[], ts=[], es=[]) for g in members}
     for g in members:
         group.engines[g].model.eval()

@@ -244,6 +244,24 @@ def test_validate_lockstep_named_batches_match_eager_path(style, cls):
         assert a[0] == pytest.approx(n[0], rel=1e-6, abs=1e-7) and abs(a[1] - n[1]) <= 1e-6
 
 
+def test_validate_lockstep_sub_group_streams():
+    """Four fold models: validate_lockstep over named batches as one group and as 2 + 2 sub-groups on two HIP streams give the same
+    (avg_loss, c_index) -- different ragged tails per fold, so the sub-groups' positions and plans differ."""
+    from multimodal_survival_prediction_amd import data, training
+    from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
+    cohort = _cohort()
+    dev_cohort = data.cohort_to(cohort, DEV)
+    pairs = [_pair("PartialModalityNet", 50 + i) for i in range(4)]
+    group = FoldGroupEngine([p[1] for p in pairs], lr=0.0, weight_decay=1e-4, adamw=False, gate_entropy_weight=0.01)
+    n = cohort["n"]
+    splits = [np.arange(22, n), np.arange(20, n - 1), np.arange(18, n), np.arange(21, n - 2)]
+    mk = lambda: [data.BatchLoader(dev_cohort, s, 4, shuffle=False, lazy=True, with_valid=True) for s in splits]
+    one = training.validate_lockstep(group, mk(), "partial", DEV)
+    two = training.validate_lockstep(group, mk(), "partial", DEV, concurrent=2)
+    for a, b in zip(one, two):
+        assert b[0] == pytest.approx(a[0], rel=1e-6, abs=1e-7) and abs(b[1] - a[1]) <= 1e-6, (one, two)
+
+
 def test_config1_simple_fusion_ct_stubbed():
     """BASELINE config 1: simple_fusion.py, 88 synthetic complete patients, CT encoder input stubbed to zero volumes (RNA-seq heads do
     the work), batch 4, fold 1 of 3: one epoch of the HIP train_epoch + validate against the oracle loops (dropout off)."""
