@@ -381,8 +381,8 @@ def run_many(args, cohort, train_sets, B, dev, timed, models, FoldGroupEngine):
             t = torch.as_tensor(train_sets[(f * G + g) % len(train_sets)])
             orders.append(t[torch.randperm(len(t), generator=gen)])
         groups.append(FoldGroupEngine(ms, lr=1e-4, weight_decay=1e-4, adamw=False, gate_entropy_weight=0.01))
-        streams.append(torch.cuda.Stream(device=dev))
-    from multimodal_survival_prediction_amd import data
+    from multimodal_survival_prediction_amd import data, ops
+    streams = ops.worker_streams(dev, F)                 # the process-wide streams the K-fold epoch's sub-groups stepped on
     view = data.gather_view(cohort, True)
 
     def run(n):
@@ -502,7 +502,8 @@ def run_config2(args, world, rank, dev):
             engines.extend(groups[-1].engines)
         else:
             engines.append(FusedOptimizer(ms[0], lr=1e-4, weight_decay=1e-4, adamw=False).engine)
-        streams.append(torch.cuda.Stream(device=dev))
+    from multimodal_survival_prediction_amd import ops as _ops
+    streams = _ops.worker_streams(dev, F)
     gb = B * world if ddp else B                                  # patients per step handled by one model
 
     def batch_of(m, k):

@@ -204,3 +204,20 @@ def adam_params(p_, g, m, v, hyper, sumsq, step, skip_flag=None, adamw=False, ac
                 rng=None):
     return _S()["AdamP"](ptr(p_), ptr(g), ptr(m), ptr(v), p_.numel(), ptr(hyper), ptr(sumsq), ptr(step), ptr(skip_flag),
                          1 if adamw else 0, ptr(acc), ptr(cox_out), ptr(entropy), ptr(rng))
+
+
+_WORKER_STREAMS = {}
+
+
+def worker_streams(device, n):
+    """The process-wide HIP streams that concurrent fold (sub-)groups step on: created once, in a fixed order, and shared by every
+    consumer (training epoch, validation pass, the benchmark's legs).  HIP multiplexes streams onto a few hardware queues in the order
+    they were first created/used, so side streams created later in a process (after graph-capture warm-up streams, per-engine streams ...)
+    can end up sharing a queue: measured on the 2 x 10-model leg of bench.py -- 3550 vs 2740 patients/s depending only on how many
+    streams the legs before it had created.  One early, fixed set keeps the mapping the same for the whole run."""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    lst = _WORKER_STREAMS.setdefault(key, [])
+    while len(lst) < n:
+        lst.append(torch.cuda.Stream(device=device))
+    return lst[:n]

@@ -9,7 +9,7 @@ Batch-skipping rules, loss averaging and return values follow each script exactl
 """
 import torch
 
-from . import losses
+from . import losses, ops
 from .engine import engine_of
 
 
@@ -368,9 +368,7 @@ def _run_subgroups(group, loaders, members, concurrent, advance):
             advance(pos)
         return
     nsub = min(int(concurrent), len(members))
-    streams = group.__dict__.setdefault("_side_streams", [])
-    while len(streams) < nsub:
-        streams.append(torch.cuda.Stream(device=group.device))
+    streams = ops.worker_streams(group.device, nsub)
     base, extra = divmod(len(members), nsub)
     cuts, o = [], 0
     for h in range(nsub):
