@@ -46,8 +46,8 @@ BLOCKS = ((6, 64), (12, 128), (24, 256), (16, 512))     # (layers, first-layer i
 
 # ---- roofline leg: the dense-layer 3x3x3 convolution family, timed live ------------------------------------------------
 def _stat_reps(M):                 # dn_net.hip make_plan: statistic-accumulator replicas of a level
-    r = 1
-    while r < 8 and M // (2 * r) >= 2048:
+    r, rows = 1, int(os.environ.get("MMS_STAT_REP_ROWS", "8192"))
+    while r < 8 and M // (2 * r) >= rows:
         r *= 2
     return r
 

@@ -53,7 +53,12 @@ bool make_plan(Plan& P, int B, int D, int H, int W) {
     for (int b = 1; b < NB; ++b) P.g[b] = Dims3{P.g[b - 1].D / 2, P.g[b - 1].H / 2, P.g[b - 1].W / 2};
     P.M0 = B * P.g0.D * P.g0.H * P.g0.W;
     for (int b = 0; b < NB; ++b) P.M[b] = B * P.g[b].D * P.g[b].H * P.g[b].W;
-    auto reps = [](int M) { int r = 1; while (r < 8 && M / (2 * r) >= 2048) r *= 2; return r; };   // 16384 rows -> 8, <= 2048 rows -> 1
+    // statistic-accumulator replicas of a level: one per MMS_STAT_REP_ROWS rows (default 8192), at most 8 -- 65536 rows (the stem; block 1
+    // of 128x128x64 volumes) -> 8, block 1 of 64x64x32 volumes (8192 rows) -> 1.  Replicas relieve the producers' fp64 atomics but every
+    // consumer workgroup re-adds them in its prologue: measured on the K = 5 epoch, one replica per 2048 rows (block 1: 4) 2283-2296
+    // patients/s, per 512 rows 2170, per 4096 / 8192 rows or a single replica everywhere 2322-2325.
+    static const int rep_rows = getenv("MMS_STAT_REP_ROWS") ? atoi(getenv("MMS_STAT_REP_ROWS")) : 8192;
+    auto reps = [](int M) { int r = 1; while (r < 8 && M / (2 * r) >= rep_rows) r *= 2; return r; };
     P.R0 = reps(P.M0);
     for (int b = 0; b < NB; ++b) P.R[b] = reps(P.M[b]);
     size_t o = 0;
