@@ -52,7 +52,9 @@ def _stat_reps(M):                 # dn_net.hip make_plan: statistic-accumulator
     return r
 
 
-def _conv3_nsplit(M, ng):          # dn_net.hip conv3_nsplit (scratch assumed large enough)
+def _conv3_nsplit(M, ng, gd):      # dn_net.hip conv3_nsplit (scratch assumed large enough)
+    if os.environ.get("MMS_CONV3_SMALL", "") != "0" and 16 + 2 * (gd[1] * gd[2] + gd[2] + 1) <= 120:
+        return 1                   # dn_ops.h mms_conv3_small_jn: the all-tap 16-row kernels of dn_c3s.hip, no tap split
     target = int(os.environ.get("MMS_SPLIT_WGS", "0")) or (256 if ng > 1 else 864)
     tiles = ((M + 31) // 32) * ng
     if tiles >= 256 and tiles >= target:
@@ -93,7 +95,7 @@ def measure_conv2_family(B, dims, device, G, reps=20):
         gd = (D // 4 >> i, H // 4 >> i, W // 4 >> i)
         M = B * gd[0] * gd[1] * gd[2]
         R = _stat_reps(M)
-        ns = _conv3_nsplit(M, G)
+        ns = _conv3_nsplit(M, G, gd)
         coords = ops.init_coords(B, gd, device)
         keep, fw, bd, bw = [], [], [], []
         for _ in range(G):
@@ -136,8 +138,8 @@ def measure_conv2_family(B, dims, device, G, reps=20):
     return {op: (t / n, f / n, n) for op, (t, f, n) in tot.items()}
 
 
-_ROOF_NAMES = {"fwd": "mms_conv3_fwd_group = conv3_fwd_mt_kernel / tile_gemm_kernel<Conv3FwdOp> (+ conv3_fwd_reduce_kernel)",
-               "bwd_data": "mms_conv3_bwd_data_group = tile_gemm_kernel<Conv3BwdDataOp> (+ conv3_bwd_data_reduce_kernel)",
+_ROOF_NAMES = {"fwd": "mms_conv3_fwd_group = conv3_fwd_mt_kernel (block 1) / conv3s_fwd_kernel (blocks 2-4)",
+               "bwd_data": "mms_conv3_bwd_data_group = tile_gemm_kernel<Conv3BwdDataOp> (block 1) / conv3s_bwd_data_kernel (blocks 2-4)",
                "bwd_weight": "mms_conv3_bwd_weight_group = conv3_bwdw_mt_kernel / tile_gemm_kernel<Conv3BwdWOp>"}
 
 

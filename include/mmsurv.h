@@ -40,7 +40,9 @@ extern "C" {
 typedef struct Dims3 { int D; int H; int W; } Dims3;
 
 /* BatchNorm parameter source. train=1: batch statistics from the fp64 accumulators; train=0: running stats.
- * (torch BatchNorm3d/1d, eps 1e-5, momentum 0.1: R/scripts/training/final_multimodal.py:77-96; MONAI norm="batch") */
+ * (torch BatchNorm3d/1d, eps 1e-5, momentum 0.1: R/scripts/training/final_multimodal.py:77-96; MONAI norm="batch")
+ * The 3x3x3-convolution entry points (mms_conv3_fwd*, mms_conv3_bwd_weight*) read the block with 16-byte vector loads: every array
+ * they use (and rep_stride * 8 when nrep > 1) must be 16-byte aligned, else MMS_ERR_ARG. */
 typedef struct BnSrc {
     const double* sum;     /* [C] batch sum      (train) */
     const double* sumsq;   /* [C] batch sum x^2  (train) */

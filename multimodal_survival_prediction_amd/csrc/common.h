@@ -73,6 +73,43 @@ __device__ __forceinline__ void bn_mean_rstd(const BnSrc& b, int c, float& mean,
     }
 }
 
+// BatchNorm constants of the 4 consecutive channels c .. c+3 (c % 4 == 0) as (mean, gamma*rstd, beta).  A thread's four bn_mean_rstd
+// calls compile to four SERIAL memory round trips (the replica loop's control flow separates them); here the six vector loads are
+// issued together: one round trip.  All six arrays must be 16-byte aligned (mms_bn_aligned16: checked by the launchers).
+__device__ __forceinline__ void bn_consts4(const BnSrc& b, int c, float (&mean)[4], float (&sc)[4], float (&beta)[4]) {
+    const float4 g = *(const float4*)(b.gamma + c), be = *(const float4*)(b.beta + c);
+    float4 mu4, rs4;
+    if (b.train) {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        d2 s01 = *(const d2*)(b.sum + c), s23 = *(const d2*)(b.sum + c + 2);
+        d2 q01 = *(const d2*)(b.sumsq + c), q23 = *(const d2*)(b.sumsq + c + 2);
+        for (int r = 1; r < b.nrep; ++r) {
+            const size_t o = (size_t)r * b.rep_stride + c;
+            s01 += *(const d2*)(b.sum + o); s23 += *(const d2*)(b.sum + o + 2);
+            q01 += *(const d2*)(b.sumsq + o); q23 += *(const d2*)(b.sumsq + o + 2);
+        }
+        const double ic = (double)b.inv_count;
+        const double m0 = s01.x * ic, m1 = s01.y * ic, m2 = s23.x * ic, m3 = s23.y * ic;
+        const double v0 = q01.x * ic - m0 * m0, v1 = q01.y * ic - m1 * m1, v2 = q23.x * ic - m2 * m2, v3 = q23.y * ic - m3 * m3;
+        mu4 = make_float4((float)m0, (float)m1, (float)m2, (float)m3);
+        rs4 = make_float4(1.0f / sqrtf((float)(v0 > 0.0 ? v0 : 0.0) + b.eps), 1.0f / sqrtf((float)(v1 > 0.0 ? v1 : 0.0) + b.eps),
+                          1.0f / sqrtf((float)(v2 > 0.0 ? v2 : 0.0) + b.eps), 1.0f / sqrtf((float)(v3 > 0.0 ? v3 : 0.0) + b.eps));
+    } else {
+        const float4 rv = *(const float4*)(b.rvar + c);
+        mu4 = *(const float4*)(b.rmean + c);
+        rs4 = make_float4(1.0f / sqrtf(rv.x + b.eps), 1.0f / sqrtf(rv.y + b.eps), 1.0f / sqrtf(rv.z + b.eps), 1.0f / sqrtf(rv.w + b.eps));
+    }
+    mean[0] = mu4.x; mean[1] = mu4.y; mean[2] = mu4.z; mean[3] = mu4.w;
+    sc[0] = g.x * rs4.x; sc[1] = g.y * rs4.y; sc[2] = g.z * rs4.z; sc[3] = g.w * rs4.w;
+    beta[0] = be.x; beta[1] = be.y; beta[2] = be.z; beta[3] = be.w;
+}
+// host-side check for the kernels that read BatchNorm parameter blocks with 16-byte vector loads (bn_consts4)
+static inline bool mms_bn_aligned16(const BnSrc& b) {
+    const uintptr_t a = b.train ? ((uintptr_t)b.sum | (uintptr_t)b.sumsq | (uintptr_t)((size_t)b.rep_stride * 8 * (b.nrep > 1)))
+                                : ((uintptr_t)b.rmean | (uintptr_t)b.rvar);
+    return ((a | (uintptr_t)b.gamma | (uintptr_t)b.beta) & 15) == 0;
+}
+
 // BN constants of channels tid, tid+256, ... (< C <= 256*NJ) into LDS arrays; all global loads are issued before any
 // dependent math so a workgroup pays ONE memory round trip for its constants instead of NJ serialized ones.
 template <int NJ>

@@ -210,6 +210,7 @@ extern "C" int mms_conv3_bwd_data_group(const Conv3BwdDataP* pp, int ng, hipStre
         else MMS_LAUNCH(conv3_bwd_data_reduce_kernel, dim3((p.M + 3) / 4, 1, ng), dim3(256), 0, s, a);
         return mms_check_launch();
     }
+    if (mms_conv3_small_jn(p.M, ng, p.g)) return mms_c3s_bwd_data(pp, ng, s);      // small grids: 16-row tiles, all taps, no reduce launch
     return launch_tile_gemm<Conv3BwdDataOp<false>>(pp, ng, dim3((p.M + 31) / 32, 1, 1), s);
 }
 MMS_SINGLE(mms_conv3_bwd_data, Conv3BwdDataP)
@@ -244,12 +245,7 @@ struct Conv3BwdWOp {
     }
     __device__ void setup(const Params& p, int, int, int z, float* extra, int tid) {
         const int c0 = (tid & 31) * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float mu, rstd;
-            bn_mean_rstd(p.bn, c0 + j, mu, rstd);
-            mean[j] = mu; sc[j] = p.bn.gamma[c0 + j] * rstd; beta[j] = p.bn.beta[c0 + j];
-        }
+        bn_consts4(p.bn, c0, mean, sc, beta);
         tap = z % 27;
         const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
         sel = (1u << kd) | (8u << kh) | (64u << kw);
@@ -399,12 +395,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     if (mb >= me) return;
     const int c0 = (tid & 31) * 4;
     float mean[4], sc[4], beta[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float mu, rstd;
-        bn_mean_rstd(p.bn, c0 + j, mu, rstd);
-        mean[j] = mu; sc[j] = p.bn.gamma[c0 + j] * rstd; beta[j] = p.bn.beta[c0 + j];
-    }
+    bn_consts4(p.bn, c0, mean, sc, beta);
     // zero padding: the (kd, kh) part of a row's tap validity is common to the three taps and is folded into the staged dz
     // row; the kw part (kw = 1 is always valid) is a per-row factor pair read next to the dz fragment
     for (int j = tid; j < mc; j += 256) {
@@ -531,6 +522,7 @@ extern "C" int mms_conv3_bwd_weight_group(const Conv3BwdWP* pp, int ng, hipStrea
     const Conv3BwdWP& p = *pp;
     if (p.M <= 0 || p.msplit <= 0 || p.lddz % 4 != 0) return MMS_ERR_ARG;
     if ((((p.M + p.msplit - 1) / p.msplit + 31) & ~31) > 1024) return MMS_ERR_ARG;    // row chunk must fit the LDS mask table
+    for (int g = 0; g < ng; ++g) if (!mms_bn_aligned16(pp[g].bn)) return MMS_ERR_ARG;   // BatchNorm blocks are read with 16-byte vector loads
     for (int g = 1; g < ng; ++g) {
         const Conv3BwdWP& q = pp[g];
         if (q.M != p.M || q.msplit != p.msplit || q.lddz % 4 != 0 || q.g.D != p.g.D || q.g.H != p.g.H || q.g.W != p.g.W ||

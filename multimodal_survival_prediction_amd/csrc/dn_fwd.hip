@@ -192,12 +192,7 @@ struct Conv3FwdOp {
     __device__ void setup(const Params& p, int m0, int, int, float*, int tid) {
         p_nsplit = p.nsplit > 0 ? p.nsplit : 27;
         const int c0 = (tid & 31) * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float mu, rstd;
-            bn_mean_rstd(p.bn, c0 + j, mu, rstd);
-            mean[j] = mu; sc[j] = p.bn.gamma[c0 + j] * rstd; beta[j] = p.bn.beta[c0 + j];
-        }
+        bn_consts4(p.bn, c0, mean, sc, beta);
         ry = make_rsrc(p.y1, (unsigned)p.M * 512u);
         rw = make_rsrc(p.wp, 32u * 27u * 128u * 4u);
 #pragma unroll
@@ -303,12 +298,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C3M_TM == 6
     const int W = p.g.W, HW = p.g.H * p.g.W, halo = W + 1, nrows = C3M_TM + 2 * halo;
     const int c4 = (tid & 31) * 4;
     float mean[4], sc[4], beta[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float mu, rstd;
-        bn_mean_rstd(p.bn, c4 + j, mu, rstd);
-        mean[j] = mu; sc[j] = p.bn.gamma[c4 + j] * rstd; beta[j] = p.bn.beta[c4 + j];
-    }
+    bn_consts4(p.bn, c4, mean, sc, beta);
     const int myrow = m0 + rt * 32 + li;
     const unsigned m9 = myrow < p.M ? tap_mask9(p.coords[myrow], p.g, false) : 0u;
     f32x16 acc, acc2;
@@ -458,7 +448,9 @@ extern "C" int mms_conv3_fwd_group(const Conv3FwdP* pp, int ng, hipStream_t s) {
         if (q.M != p.M || q.ldo % 4 != 0 || q.g.D != p.g.D || q.g.H != p.g.H || q.g.W != p.g.W || (q.partial == nullptr) != (p.partial == nullptr) ||
             q.nsplit != p.nsplit) return MMS_ERR_ARG;
     }
+    for (int g = 0; g < ng; ++g) if (!mms_bn_aligned16(pp[g].bn)) return MMS_ERR_ARG;   // BatchNorm blocks are read with 16-byte vector loads
     if (const int tm = p.partial ? 0 : conv3_mt_tile(p.M, ng, p.g)) return tm == 64 ? launch_conv3_fwd_mt<64>(pp, ng, s) : launch_conv3_fwd_mt<32>(pp, ng, s);
+    if (!p.partial && mms_conv3_small_jn(p.M, ng, p.g)) return mms_c3s_fwd(pp, ng, s);      // small grids: 16-row tiles, all taps, no reduce launch
     if (p.partial) {
         if (p.nsplit < 1 || p.nsplit > 27) return MMS_ERR_ARG;
         const int tpw = (27 + p.nsplit - 1) / p.nsplit;

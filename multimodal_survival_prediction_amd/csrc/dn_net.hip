@@ -273,7 +273,8 @@ static int split_target(int ng) {     // measured: 864 for one model (27-way spl
     const int v = e ? atoi(e) : 0;
     return v > 0 ? v : (ng > 1 ? 256 : 864);
 }
-static int conv3_nsplit(int M, int ng, long cap_rows) {
+static int conv3_nsplit(int M, int ng, long cap_rows, const Dims3& g) {
+    if (mms_conv3_small_jn(M, ng, g)) return 1;       // small grids: the all-tap kernels of dn_c3s.hip (no tap split, no reduce launch)
     const long tiles = (long)((M + 31) / 32) * ng;
     if (tiles >= 256 && tiles >= split_target(ng)) return 1;
     long ns = (split_target(ng) + tiles - 1) / tiles;
@@ -363,7 +364,7 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
             const int ip = IDX.layer[l];
             Conv1FwdP c1[MMS_MAX_GROUP];
             Conv3FwdP c3[MMS_MAX_GROUP];
-            const int ns3 = conv3_nsplit(P.M[b], ng, P.partial_rows);
+            const int ns3 = conv3_nsplit(P.M[b], ng, P.partial_rows, P.g[b]);
             // conv1 at small M is a chain of dependent K-steps on a handful of workgroups: one K-step per workgroup instead
             int ks1 = 1;
             if (conv1_ksplit_on() && (long)((P.M[b] + 31) / 32) * 4 * ng <= 128 && C >= 256 && (long)((C + 127) / 128) * P.M[b] <= P.partial_rows)
@@ -504,7 +505,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
             Conv3BwdWP bw[MMS_MAX_GROUP];
             Conv1BwdP c1[MMS_MAX_GROUP];
             BnBwdApplyP ap[MMS_MAX_GROUP];
-            const int ns3 = conv3_nsplit(M, ng, P.partial_rows);
+            const int ns3 = conv3_nsplit(M, ng, P.partial_rows, P.g[b]);
             // rows per weight-gradient workgroup: every chunk flushes 27 x 16 KB of fp32 atomics, so groups (which bring their own
             // parallelism) take chunks twice as long -- half the fabric writes (PMC WRITE_SIZE) for the same FLOPs
             const int ngw = defer ? MMS_MAX_GROUP / ng * ng : ng;        // (model, layer) members per weight-gradient launch

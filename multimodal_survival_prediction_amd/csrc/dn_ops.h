@@ -1,6 +1,7 @@
 // Parameter blocks live in the public C header.
 #pragma once
 #include "common.h"
+#include <stdlib.h>
 
 // Launch-shape rule shared by the weight-gradient launcher (dn_bwd.hip) and the network driver (dn_net.hip): the multi-tap conv3
 // weight-gradient kernel holds 3 workgroups per CU; it only pays when its grid fills >= 90 % of a whole number of such rounds.
@@ -8,6 +9,24 @@ static inline bool mms_conv3w_mt_fills(long workgroups) {
     const long slots = 3 * 256, rounds = (workgroups + slots - 1) / slots;
     return workgroups > 0 && workgroups * 10 >= rounds * slots * 9;
 }
+
+// Small-grid 3x3x3 convolution kernels (dn_c3s.hip): a workgroup owns 16 voxel rows and all 27 taps, the rows' whole neighbourhood
+// [m0 - halo, m0 + 16 + halo), halo = H*W + W + 1, staged in LDS once -- no tap split, no reduce launch.  Applies when that window fits
+// (dense blocks 2-4 of 64x64x32 volumes, blocks 3-4 of 128x128x64 volumes).  Returns 0 (not applicable / MMS_CONV3_SMALL=0) or the
+// number of 16-column output tiles per wave: 2, or 1 (output channels split over blockIdx.y) when the launch has few row tiles
+// (MMS_CONV3_SMALL=1 / 2 force that number: tests).
+#define MMS_C3S_MAXROWS 120
+static inline int mms_conv3_small_jn(int M, int ng, const Dims3& g) {
+    const char* e = getenv("MMS_CONV3_SMALL");
+    if ((e && e[0] == '0') || M <= 0) return 0;
+    const long halo = (long)g.H * g.W + g.W + 1;
+    if (16 + 2 * halo > MMS_C3S_MAXROWS) return 0;
+    if (e && (e[0] == '1' || e[0] == '2')) return e[0] - '0';
+    const long tiles = (long)((M + 15) / 16) * ng;
+    return tiles > 128 ? 2 : 1;
+}
+int mms_c3s_fwd(const Conv3FwdP* pp, int ng, hipStream_t s);
+int mms_c3s_bwd_data(const Conv3BwdDataP* pp, int ng, hipStream_t s);
 
 // ---- dense block 4 as one launch per pass (dn_b4.hip); internal to the network drivers ------------------------------------------
 struct B4Layer {               // device table entry, one per dense layer of block 4 (built by mms_dn121_init)

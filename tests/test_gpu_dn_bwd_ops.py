@@ -25,9 +25,13 @@ def _d(t):
                                               (2, (16, 16, 8), 224, 256, 16),
                                               # shapes that take the multi-tap forward kernel in the layer's forward: ragged last tile, W = 16
                                               (3, (7, 7, 8), 64, 256, 4), (2, (8, 16, 16), 96, 256, 8)])
-@pytest.mark.parametrize("split", [0, 27, 3])
-def test_dense_layer_backward(ops, B, dims, C, Ctot, ms, split, monkeypatch):
+# small: MMS_CONV3_SMALL for the unsplit conv2 launches (None = default: the all-tap 16-row kernels of dn_c3s.hip on every grid here whose
+# neighbourhood window fits -- all but 16x16x8, 7x7x8, 8x16x16; "0" = tile-GEMM form; "1" / "2" = one / two 16-column tiles per wave)
+@pytest.mark.parametrize("split,small", [(0, None), (0, "0"), (0, "1"), (0, "2"), (27, None), (3, None)])
+def test_dense_layer_backward(ops, B, dims, C, Ctot, ms, split, small, monkeypatch):
     """One _DenseLayer: norm1-relu-conv1-norm2-relu-conv2 + cat; gradient w.r.t. every parameter and the input slab."""
+    if small is not None:
+        monkeypatch.setenv("MMS_CONV3_SMALL", small)
     torch.manual_seed(0)
     M = B * dims[0] * dims[1] * dims[2]
     x = (torch.randn(B, C, *dims) * 1.3 + 0.2).requires_grad_(True)

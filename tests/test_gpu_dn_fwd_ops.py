@@ -102,9 +102,13 @@ def test_transition_fwd(ops, B, dims, K):
 @pytest.mark.parametrize("B,dims", [(4, (16, 16, 8)), (2, (8, 8, 4)), (4, (4, 4, 2)), (4, (2, 2, 1)), (3, (5, 3, 2)),
                                     (4, (8, 8, 4)), (3, (7, 7, 8)), (2, (8, 16, 16))])
 @pytest.mark.parametrize("train", [True, False])
-@pytest.mark.parametrize("split,mt", [(0, "2"), (0, "3"), (27, "2"), (3, "2"), (5, "2")])
-def test_conv3_fwd(ops, B, dims, train, split, mt, monkeypatch):
+# small: MMS_CONV3_SMALL -- None = default (the all-tap 16-row kernels of dn_c3s.hip wherever the rows' neighbourhood window fits: every grid
+# here except 16x16x8, 7x7x8, 8x16x16), "0" = off (tile-GEMM form), "1" / "2" = force one / two 16-column output tiles per wave
+@pytest.mark.parametrize("split,mt,small", [(0, "2", None), (0, "2", "0"), (0, "2", "1"), (0, "2", "2"), (0, "3", None), (27, "2", None), (3, "2", None), (5, "2", None)])
+def test_conv3_fwd(ops, B, dims, train, split, mt, small, monkeypatch):
     monkeypatch.setenv("MMS_CONV3_MT", mt)      # take a multi-tap kernel whenever the shape allows it (default: by tile count)
+    if small is not None:
+        monkeypatch.setenv("MMS_CONV3_SMALL", small)
     torch.manual_seed(2)
     M = B * dims[0] * dims[1] * dims[2]
     y1 = torch.randn(B, 128, *dims) + 0.1
