@@ -91,11 +91,13 @@ def measure_conv2_family(B, dims, device, G, reps=20):
     b4_bwd = b4_one and os.environ.get("MMS_PERSIST_B4", "2") not in ("0", "1")        # block 4's backward data path is one launch too
     w = torch.randn(32, 128, 3, 3, 3, device=device) * 0.03
     wpf, wpb = ops.pack_conv3(w)
+    wff, wfb = ops.pack_conv3_frag(w)
     for i, (layers, _) in enumerate(BLOCKS):
         gd = (D // 4 >> i, H // 4 >> i, W // 4 >> i)
         M = B * gd[0] * gd[1] * gd[2]
         R = _stat_reps(M)
         ns = _conv3_nsplit(M, G, gd)
+        frag = i < 3 and os.environ.get("MMS_CONV3_SMALL", "") != "0" and 16 + 2 * (gd[1] * gd[2] + gd[2] + 1) <= 120      # dn_net.hip conv3_frag_block
         coords = ops.init_coords(B, gd, device)
         keep, fw, bd, bw = [], [], [], []
         for _ in range(G):
@@ -111,10 +113,10 @@ def measure_conv2_family(B, dims, device, G, reps=20):
             dwp = torch.zeros(27 * 32 * 128, device=device)
             out, dz = slab[:, 64:96], dslab[:, 64:96]
             keep.append((y1, s, q, slab, dslab, ost, bst, dbn, part, dwp))
-            f = S["Conv3FwdP"](y1.data_ptr(), coords.data_ptr(), ops.dims3(gd), M, wpf.data_ptr(), out.data_ptr(), out.stride(0), bn,
-                               ost[0, 0, 64:].data_ptr(), ost[0, 1, 64:].data_ptr(), ops.ptr(part), ns, R, 2 * 256)
-            d = S["Conv3BwdDataP"](dz.data_ptr(), dz.stride(0), coords.data_ptr(), ops.dims3(gd), M, wpb.data_ptr(), y1.data_ptr(), bn,
-                                   dbn.data_ptr(), bst[0, 0].data_ptr(), bst[0, 1].data_ptr(), ops.ptr(part), ns, R, 2 * 128)
+            f = S["Conv3FwdP"](y1.data_ptr(), coords.data_ptr(), ops.dims3(gd), M, (wff if frag else wpf).data_ptr(), out.data_ptr(), out.stride(0), bn,
+                               ost[0, 0, 64:].data_ptr(), ost[0, 1, 64:].data_ptr(), ops.ptr(part), ns, R, 2 * 256, 1 if frag else 0)
+            d = S["Conv3BwdDataP"](dz.data_ptr(), dz.stride(0), coords.data_ptr(), ops.dims3(gd), M, (wfb if frag else wpb).data_ptr(), y1.data_ptr(), bn,
+                                   dbn.data_ptr(), bst[0, 0].data_ptr(), bst[0, 1].data_ptr(), ops.ptr(part), ns, R, 2 * 128, 1 if frag else 0)
             g_ = S["Conv3BwdWP"](y1.data_ptr(), coords.data_ptr(), ops.dims3(gd), M, bn, dz.data_ptr(), dz.stride(0),
                                  dwp.data_ptr(), _bwdw_msplit(M, G), 1)
             fw.append(f); bd.append(d); bw.append(g_)

@@ -91,6 +91,9 @@ typedef struct Conv3FwdP {
                                     // then a reduce kernel sums them, writes the slab columns and the statistics
     int nsplit;                     // 1..27 (used when partial != null); workgroup z handles taps [z*ceil(27/nsplit), ...)
     int srep; int sstride;          // statistic-accumulator replicas written by this op: workgroup x adds to replica x % srep (stride in doubles)
+    int wfrag;                      // 1: wp is in MFMA-fragment order [tap][cin/32][(cin/16)%2][cout/16][lane = ((cin/4)%4)*16 + cout%16][cin%4]
+                                    // (mms_pack_conv3_frag): every weight load of the small-grid kernel is one contiguous 1 KB per wave.
+                                    // Only with partial == null on grids that kernel takes (H*W + W + 1 <= 52), else MMS_ERR_ARG
 } Conv3FwdP;
 
 // ---- conv0: Conv3d(1,64,k7,s2,p3,no bias) -------------------------------------------------------------
@@ -145,6 +148,7 @@ typedef struct Conv3BwdDataP {
     float* partial;                 // optional scratch [nsplit][M][128]: tap split as in Conv3FwdP
     int nsplit;
     int srep; int sstride;          // statistic-accumulator replicas written by this op: workgroup x adds to replica x % srep (stride in doubles)
+    int wfrag;                      // 1: wpb is in MFMA-fragment order [tap][cin/16][cout/16][lane = ((cout/4)%4)*16 + cin%16][cout%4] (mms_pack_conv3_frag); as Conv3FwdP.wfrag
 } Conv3BwdDataP;
 
 // conv3 backward-weight: dW[cout][cin][tap] += sum_m relu(bn(y1))[nbr(m,tap)][cin] * dz[m][cout]
@@ -412,6 +416,7 @@ int mms_pool_bwd(const PoolBwdP* p, hipStream_t s);              /* pool0 + relu
 int mms_conv0_bwd_weight(const Conv0BwdWP* p, hipStream_t s);    /* norm0 backward + conv0 wrt weight */
 int mms_unpack_conv3_grads(const void* table_host, int nlayers, hipStream_t s);   /* host array of {scratch [27][32][128], dw canonical}, <= 64 layers */
 int mms_pack_conv3(const float* w, float* wpf, float* wpb, hipStream_t s);
+int mms_pack_conv3_frag(const float* w, float* wff, float* wfb, hipStream_t s);   /* canonical [32][128][27] -> the two MFMA-fragment orders (Conv3FwdP.wfrag / Conv3BwdDataP.wfrag) */
 int mms_pack_conv3_table(const void* table_dev, int nlayers, hipStream_t s);
 int mms_bn_running_update(const void* table_dev, int n, float momentum, hipStream_t s);
 
@@ -513,6 +518,7 @@ int mms_head_bwd_group(const HeadBwdP* p, int ng, hipStream_t s);
 int mms_pool_bwd_group(const PoolBwdP* p, int ng, hipStream_t s);
 int mms_conv0_bwd_weight_group(const Conv0BwdWP* p, int ng, hipStream_t s);
 int mms_pack_conv3_table_group(const void* const* tables_dev, int ng, int nlayers, hipStream_t s);
+int mms_pack_conv3_table_group_ex(const void* const* tables_dev, int ng, int nlayers, uint64_t fragmask, hipStream_t s);   /* bit l set: layer l's two packs in MFMA-fragment order */
 int mms_bn_running_update_group(const void* const* tables_dev, int ng, int n, float momentum, hipStream_t s);
 int mms_missing_mix_fwd_group(const MixP* p, int ng, hipStream_t s);
 int mms_missing_mix_bwd_group(const MixP* p, int ng, hipStream_t s);

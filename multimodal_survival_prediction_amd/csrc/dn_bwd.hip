@@ -200,6 +200,8 @@ extern "C" int mms_conv3_bwd_data_group(const Conv3BwdDataP* pp, int ng, hipStre
         if (q.M != p.M || q.lddz % 4 != 0 || q.g.D != p.g.D || q.g.H != p.g.H || q.g.W != p.g.W ||
             (q.partial == nullptr) != (p.partial == nullptr) || q.nsplit != p.nsplit) return MMS_ERR_ARG;
     }
+    for (int g = 1; g < ng; ++g) if (pp[g].wfrag != p.wfrag) return MMS_ERR_ARG;
+    if (p.wfrag) return (!p.partial && mms_conv3_small_jn(p.M, ng, p.g)) ? mms_c3s_bwd_data(pp, ng, s) : MMS_ERR_ARG;   // fragment-ordered weights: the small-grid kernel only
     if (p.partial) {
         if (p.nsplit < 1 || p.nsplit > 27 || (p.nsplit - 1) * ((27 + p.nsplit - 1) / p.nsplit) >= 27) return MMS_ERR_ARG;
         int rc = launch_tile_gemm<Conv3BwdDataOp<true>>(pp, ng, dim3((p.M + 31) / 32, 1, p.nsplit), s);

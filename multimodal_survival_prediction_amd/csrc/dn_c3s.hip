@@ -9,7 +9,9 @@
 //     ReLU, i.e. the transform runs once per element instead of once per tap -- and every tap reads its A operand from a shifted slot;
 //   * v_mfma_f32_16x16x4_f32 (16-row tiles: twice the workgroups of the 32-row forms), operands as float4 of 4 consecutive k per lane
 //     (element e of lane (i, h) is k = 16q + 4h + e for both operands, so MFMA e sums k in {e, 4+e, 8+e, 12+e} of the group);
-//   * the weight operand goes from L2 straight into the MFMA register layout through a register ring 6-9 taps deep;
+//   * the weight operand goes from L2 straight into the MFMA register layout through a register ring 6-9 taps deep; with the weights
+//     packed in fragment order (wfrag: what the network driver does for these layers) each of those loads is one contiguous 1 KB per wave --
+//     from the classic [co][tap][cin] pack a wave instruction gathers 64 separate 16-byte pieces and the launch is bound by the texture path;
 //   * zero padding = a 0/1 factor per (row, tap) on the A registers, from the row's 9-bit tap-validity mask;
 //   * forward: the 4 waves split the 128 input channels and are summed through LDS; backward-data: they split the 128 output
 //     (= conv input) channels, nothing to sum.  With few row tiles in the launch the output channels are split over blockIdx.y too (JN = 1).
@@ -36,6 +38,21 @@ constexpr int C3S_NI = (MMS_C3S_MAXROWS + 7) / 8;
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// -DC3S_TIMING (tools/c3s_timing.py): shader-clock stamps of the kernel's phases, one record of 8 words per workgroup
+#ifdef C3S_TIMING
+__device__ unsigned long long* c3s_ts_buf = nullptr;
+#define C3S_TS_DECL unsigned long long ts_[6] = {0, 0, 0, 0, 0, 0}
+#define C3S_STAMP(i) do { asm volatile("" ::: "memory"); ts_[i] = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); } while (0)
+#define C3S_STAMPW(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); ts_[i] = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); } while (0)
+#define C3S_TS_FLUSH() do { if (threadIdx.x == 0 && c3s_ts_buf) { unsigned long long* o = c3s_ts_buf + 8 * (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)); \
+    for (int i_ = 0; i_ < 6; ++i_) o[i_] = ts_[i_]; } } while (0)
+#else
+#define C3S_TS_DECL
+#define C3S_STAMP(i)
+#define C3S_STAMPW(i)
+#define C3S_TS_FLUSH()
+#endif
+
 // Weight stream: one CU cannot hide an L2/MALL round trip (~1600 cycles with every workgroup of the launch asking for the same
 // lines) behind one tap's MFMAs (256-512 cycles), and left alone the compiler sinks each tap's loads next to their use (measured:
 // 0.8 us per tap, fully exposed -- 21.8 us per block-3 launch).  The taps' weights therefore sit in a register RING of D taps filled
@@ -44,36 +61,80 @@ constexpr int C3S_NI = (MMS_C3S_MAXROWS + 7) / 8;
 // ALU, MFMA and LDS instructions may cross it, global loads may not)
 #define C3S_PIN() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0x38F); } while (0)
 
+// Shared tap loop: A fragments of tap t+1 are read from LDS before tap t's MFMAs (the pins keep LDS reads where they are written, so the
+// prefetch is explicit), the MFMAs rotate over the 2 JN accumulators (a dependent v_mfma_f32_16x16x4_f32 issues every 40 cycles, an
+// independent one every 32), tap t + D's weights are requested right behind tap t's MFMAs.  SIGN = +1 forward, -1 backward-data (mirrored taps).
+#define C3S_TAP_LOOP(SIGN, PITCH)                                                                                                     \
+    f32x4 acc[JN][2];                                                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < JN; ++j) _Pragma("unroll") for (int q = 0; q < 2; ++q) acc[j][q] = f32x4{0.f, 0.f, 0.f, 0.f}; \
+    float4 an[2];                                                                                                                     \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q) an[q] = *(const float4*)(arow + (SIGN) * (-HW - W - 1) * (PITCH) + 16 * q);           \
+    _Pragma("unroll") for (int t = 0; t < 27; ++t) {                                                                                  \
+        const int kd = t / 9, kh = (t / 3) % 3, kw = t % 3;                                                                           \
+        const unsigned sel = (1u << kd) | (8u << kh) | (64u << kw);                                                                   \
+        const float mk = (m9 & sel) == sel ? 1.f : 0.f;                                                                               \
+        float4 a[2];                                                                                                                  \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q) a[q] = make_float4(an[q].x * mk, an[q].y * mk, an[q].z * mk, an[q].w * mk);     \
+        if (t + 1 < 27) {                                                                                                             \
+            const int t1 = t + 1, off1 = (t1 / 9 - 1) * HW + ((t1 / 3) % 3 - 1) * W + (t1 % 3 - 1);                                   \
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) an[q] = *(const float4*)(arow + (SIGN) * off1 * (PITCH) + 16 * q);          \
+        }                                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);      /* tap t's MFMAs stay BEHIND the LDS reads of tap t + 1 (they cover their latency) */  \
+        const float4 (&bt)[JN][2] = b[t % D];                                                                                         \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q) _Pragma("unroll") for (int j = 0; j < JN; ++j) acc[j][q] = MFMA16(a[q].x, bt[j][q].x, acc[j][q]); \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q) _Pragma("unroll") for (int j = 0; j < JN; ++j) acc[j][q] = MFMA16(a[q].y, bt[j][q].y, acc[j][q]); \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q) _Pragma("unroll") for (int j = 0; j < JN; ++j) acc[j][q] = MFMA16(a[q].z, bt[j][q].z, acc[j][q]); \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q) _Pragma("unroll") for (int j = 0; j < JN; ++j) acc[j][q] = MFMA16(a[q].w, bt[j][q].w, acc[j][q]); \
+        asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);                                                             \
+        if (t + D < 27) bload(b[t % D], t + D);                                                                                       \
+        asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);                                                             \
+    }
+
 // ---- forward: out[m][co] = sum_tap sum_cin relu(bn2(y1))[m + off(tap)][cin] * W[co][tap][cin] --------------------------------------
-template <int JN, int D>
+template <int JN, int D, bool FRAG>
 __global__ __launch_bounds__(256) void conv3s_fwd_kernel(const Grp<Conv3FwdP> grp) {
+    // every kernel argument the prologue needs, read ONCE into registers: left as references into the kernarg segment the compiler
+    // re-loads them (s_load + wait) inside each predicated load below -- 30 serial scalar round trips, 3.3 us before the first MFMA
     const Conv3FwdP& p = grp.p[blockIdx.z];
+    const float* __restrict__ y1 = p.y1;
+    const float* __restrict__ wp = p.wp;
+    const int* __restrict__ coords = p.coords;
+    const int M = p.M;
+    const Dims3 g = p.g;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, h = lane >> 4;
     const int m0 = blockIdx.x * C3S_TM, co0 = JN == 1 ? 16 * (int)blockIdx.y : 0;
-    const int W = p.g.W, HW = p.g.H * p.g.W, halo = HW + W + 1, nrows = C3S_TM + 2 * halo;
+    const int W = g.W, HW = g.H * g.W, halo = HW + W + 1, nrows = C3S_TM + 2 * halo;
+    C3S_TS_DECL;
+    C3S_STAMP(0);
 
-    // window rows (raw y1) -> registers
+    // window rows (raw y1) -> registers: branch-free, from clamped (always valid) addresses; rows outside [0, M) are zeroed when staged
     const int c4 = (tid & 31) * 4;
     float4 wv[C3S_NI];
     unsigned wok = 0;
 #pragma unroll
     for (int i = 0; i < C3S_NI; ++i) {
-        const int s = (tid >> 5) + 8 * i, src = m0 - halo + s;
-        const bool ok = s < nrows && src >= 0 && src < p.M;
-        wok |= (ok ? 1u : 0u) << i;
-        wv[i] = ok ? *(const float4*)(p.y1 + (size_t)src * 128 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (8 * i < nrows) {                 // workgroup-uniform
+            const int s = (tid >> 5) + 8 * i, src = m0 - halo + s;
+            wok |= ((s < nrows && src >= 0 && src < M) ? 1u : 0u) << i;
+            const int sc_ = src < 0 ? 0 : (src < M ? src : M - 1);
+            wv[i] = *(const float4*)(y1 + (size_t)sc_ * 128 + c4);
+        }
     }
     const int myrow = m0 + li;
-    const int mycoord = p.coords[myrow < p.M ? myrow : m0];
+    const int mycoord = coords[myrow < M ? myrow : M - 1];
     // the first D taps' weights, behind the window in the memory queue (vmcnt retires in order: the window is needed first)
-    const float* wlane = p.wp + (size_t)(co0 + li) * (27 * 128) + 32 * wave + 4 * h;
+    // classic pack [co][tap][cin]: a wave instruction gathers 64 separate 16-byte pieces (16 rows x 64 B); fragment order: one contiguous 1 KB
+    const float* wlane = FRAG ? wp + (size_t)wave * 1024 + (co0 >> 4) * 256 + lane * 4
+                              : wp + (size_t)(co0 + li) * (27 * 128) + 32 * wave + 4 * h;
     float4 b[D][JN][2];
     auto bload = [&](float4 (&bt)[JN][2], int tap) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < JN; ++j)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) bt[j][q] = *(const float4*)(wlane + (size_t)j * 16 * (27 * 128) + tap * 128 + 16 * q);
+            for (int q = 0; q < 2; ++q)
+                bt[j][q] = FRAG ? *(const float4*)(wlane + tap * 4096 + q * 512 + j * 256)
+                                : *(const float4*)(wlane + (size_t)j * 16 * (27 * 128) + tap * 128 + 16 * q);
     };
     C3S_PIN();
 #pragma unroll
@@ -82,11 +143,12 @@ __global__ __launch_bounds__(256) void conv3s_fwd_kernel(const Grp<Conv3FwdP> gr
     // BatchNorm2 constants of this thread's 4 channels; transform -> LDS
     float mean[4], sc[4], beta[4];
     bn_consts4(p.bn, c4, mean, sc, beta);
-    const unsigned m9 = myrow < p.M ? c3s_mask9(mycoord, p.g, false) : 0u;
+    C3S_STAMPW(1);
+    const unsigned m9 = myrow < M ? c3s_mask9(mycoord, g, false) : 0u;
 #pragma unroll
     for (int i = 0; i < C3S_NI; ++i) {
         const int s = (tid >> 5) + 8 * i;
-        if (s < nrows) {
+        if (8 * i < nrows && s < nrows) {
             const float z = (wok >> i) & 1u ? 1.f : 0.f;
             *(float4*)&smem[s * C3S_FP + c4] =
                 make_float4(z * fmaxf(bn_apply(wv[i].x, mean[0], sc[0], beta[0]), 0.f), z * fmaxf(bn_apply(wv[i].y, mean[1], sc[1], beta[1]), 0.f),
@@ -94,43 +156,11 @@ __global__ __launch_bounds__(256) void conv3s_fwd_kernel(const Grp<Conv3FwdP> gr
         }
     }
     __syncthreads();
+    C3S_STAMP(2);
 
-    f32x4 acc[JN][2];
-#pragma unroll
-    for (int j = 0; j < JN; ++j)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) acc[j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* arow = smem + (li + halo) * C3S_FP + 32 * wave + 4 * h;
-    auto mma = [&](int tap, const float4 (&bt)[JN][2]) __attribute__((always_inline)) {
-        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-        const unsigned sel = (1u << kd) | (8u << kh) | (64u << kw);
-        const float mk = (m9 & sel) == sel ? 1.f : 0.f;
-        const float* ar = arow + ((kd - 1) * HW + (kh - 1) * W + (kw - 1)) * C3S_FP;
-        float4 a[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            a[q] = *(const float4*)(ar + 16 * q);
-            a[q].x *= mk; a[q].y *= mk; a[q].z *= mk; a[q].w *= mk;
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-#pragma unroll
-            for (int j = 0; j < JN; ++j) acc[j][q] = MFMA16(a[q].x, bt[j][q].x, acc[j][q]);
-#pragma unroll
-            for (int j = 0; j < JN; ++j) acc[j][q] = MFMA16(a[q].y, bt[j][q].y, acc[j][q]);
-#pragma unroll
-            for (int j = 0; j < JN; ++j) acc[j][q] = MFMA16(a[q].z, bt[j][q].z, acc[j][q]);
-#pragma unroll
-            for (int j = 0; j < JN; ++j) acc[j][q] = MFMA16(a[q].w, bt[j][q].w, acc[j][q]);
-        }
-    };
-#pragma unroll
-    for (int t = 0; t < 27; ++t) {
-        mma(t, b[t % D]);
-        C3S_PIN();
-        if (t + D < 27) bload(b[t % D], t + D);
-        C3S_PIN();
-    }
+    C3S_TAP_LOOP(1, C3S_FP)
+    C3S_STAMP(3);
     __syncthreads();                                      // the window is dead: Cs aliases it
     // ---- epilogue: add the four channel quarters, write the slab columns, batch statistics
     constexpr int NC = 16 * JN, CP = NC + 1;
@@ -153,7 +183,8 @@ __global__ __launch_bounds__(256) void conv3s_fwd_kernel(const Grp<Conv3FwdP> gr
             s += v; q2 += (double)v * v;
         }
     }
-    if (p.osum == nullptr) return;
+    C3S_STAMP(4);
+    if (p.osum == nullptr) { C3S_TS_FLUSH(); return; }
     red[rg * NC + c] = s; red[(NRG + rg) * NC + c] = q2;
     __syncthreads();
     if (tid < NC) {
@@ -163,36 +194,52 @@ __global__ __launch_bounds__(256) void conv3s_fwd_kernel(const Grp<Conv3FwdP> gr
         atomicAdd(&stat_rep(p.osum, p.srep, p.sstride)[co0 + tid], a);
         atomicAdd(&stat_rep(p.osumsq, p.srep, p.sstride)[co0 + tid], b);
     }
+    C3S_STAMPW(5);
+    C3S_TS_FLUSH();
 }
 
 // ---- backward-data: dbn2[m][cin] = [a2 > 0] * sum_tap sum_co dz[m - off(tap)][co] * W[cin][tap][co]; BatchNorm2-backward sums -------
-template <int JN, int D>
+template <int JN, int D, bool FRAG>
 __global__ __launch_bounds__(256) void conv3s_bwd_data_kernel(const Grp<Conv3BwdDataP> grp) {
     const Conv3BwdDataP& p = grp.p[blockIdx.z];
+    const float* __restrict__ dz = p.dz;               // kernel arguments read once (see conv3s_fwd_kernel)
+    const float* __restrict__ wpb = p.wpb;
+    const float* __restrict__ y1 = p.y1;
+    const int* __restrict__ coords = p.coords;
+    const int M = p.M, lddz = p.lddz;
+    const Dims3 g = p.g;
+    const BnSrc bn = p.bn;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, h = lane >> 4;
     const int m0 = blockIdx.x * C3S_TM;
     const int cin0 = (JN == 1 ? 64 * (int)blockIdx.y : 0) + 16 * JN * wave;      // this wave's first output column
-    const int W = p.g.W, HW = p.g.H * p.g.W, halo = HW + W + 1, nrows = C3S_TM + 2 * halo;
+    const int W = g.W, HW = g.H * g.W, halo = HW + W + 1, nrows = C3S_TM + 2 * halo;
 
-    // dz window: 8 threads per row (32 channels), 32 rows per pass
+    // dz window: 8 threads per row (32 channels), 32 rows per pass; clamped addresses, rows outside [0, M) zeroed when staged
     constexpr int NP = (MMS_C3S_MAXROWS + 31) / 32;
     float4 wv[NP];
+    unsigned wok = 0;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int s = (tid >> 3) + 32 * i, src = m0 - halo + s;
-        const bool ok = s < nrows && src >= 0 && src < p.M;
-        wv[i] = ok ? *(const float4*)(p.dz + (size_t)src * p.lddz + (tid & 7) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (32 * i < nrows) {
+            const int s = (tid >> 3) + 32 * i, src = m0 - halo + s;
+            wok |= ((s < nrows && src >= 0 && src < M) ? 1u : 0u) << i;
+            const int sc_ = src < 0 ? 0 : (src < M ? src : M - 1);
+            wv[i] = *(const float4*)(dz + (size_t)sc_ * lddz + (tid & 7) * 4);
+        }
     }
     const int myrow = m0 + li;
-    const int mycoord = p.coords[myrow < p.M ? myrow : m0];
-    const float* wlane = p.wpb + (size_t)(cin0 + li) * (27 * 32) + 4 * h;
+    const int mycoord = coords[myrow < M ? myrow : M - 1];
+    const float* wlane = FRAG ? wpb + (size_t)(cin0 >> 4) * 512 + lane * 4
+                              : wpb + (size_t)(cin0 + li) * (27 * 32) + 4 * h;
     float4 b[D][JN][2];
     auto bload = [&](float4 (&bt)[JN][2], int tap) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < JN; ++j)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) bt[j][q] = *(const float4*)(wlane + (size_t)j * 16 * (27 * 32) + tap * 32 + 16 * q);
+            for (int q = 0; q < 2; ++q)
+                bt[j][q] = FRAG ? *(const float4*)(wlane + tap * 4096 + j * 512 + q * 256)
+                                : *(const float4*)(wlane + (size_t)j * 16 * (27 * 32) + tap * 32 + 16 * q);
     };
     C3S_PIN();
 #pragma unroll
@@ -207,64 +254,33 @@ __global__ __launch_bounds__(256) void conv3s_bwd_data_kernel(const Grp<Conv3Bwd
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = m0 + 4 * h + r;
-            yv[j][r] = m < p.M ? p.y1[(size_t)m * 128 + c] : 0.f;
+            yv[j][r] = y1[(size_t)(m < M ? m : M - 1) * 128 + c];
         }
-        bs[j] = p.bn.sum[c]; bq[j] = p.bn.sumsq[c];
-        ga[j] = p.bn.gamma[c]; be[j] = p.bn.beta[c];
+        bs[j] = bn.sum[c]; bq[j] = bn.sumsq[c];
+        ga[j] = bn.gamma[c]; be[j] = bn.beta[c];
     }
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
         const int c = cin0 + 16 * j + li;
-        for (int r = 1; r < p.bn.nrep; ++r) { bs[j] += p.bn.sum[c + (size_t)r * p.bn.rep_stride]; bq[j] += p.bn.sumsq[c + (size_t)r * p.bn.rep_stride]; }
-        const double m = bs[j] * (double)p.bn.inv_count;
-        double v = bq[j] * (double)p.bn.inv_count - m * m;
+        for (int r = 1; r < bn.nrep; ++r) { bs[j] += bn.sum[c + (size_t)r * bn.rep_stride]; bq[j] += bn.sumsq[c + (size_t)r * bn.rep_stride]; }
+        const double m = bs[j] * (double)bn.inv_count;
+        double v = bq[j] * (double)bn.inv_count - m * m;
         v = v > 0.0 ? v : 0.0;
-        mu[j] = (float)m; rstd[j] = 1.0f / sqrtf((float)v + p.bn.eps);
+        mu[j] = (float)m; rstd[j] = 1.0f / sqrtf((float)v + bn.eps);
     }
-    const unsigned m9 = myrow < p.M ? c3s_mask9(mycoord, p.g, true) : 0u;
+    const unsigned m9 = myrow < M ? c3s_mask9(mycoord, g, true) : 0u;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int s = (tid >> 3) + 32 * i;
-        if (s < nrows) *(float4*)&smem[s * C3S_BP + (tid & 7) * 4] = wv[i];
+        if (32 * i < nrows && s < nrows) {
+            const float z = (wok >> i) & 1u ? 1.f : 0.f;
+            *(float4*)&smem[s * C3S_BP + (tid & 7) * 4] = make_float4(z * wv[i].x, z * wv[i].y, z * wv[i].z, z * wv[i].w);
+        }
     }
     __syncthreads();
 
-    f32x4 acc[JN][2];
-#pragma unroll
-    for (int j = 0; j < JN; ++j)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) acc[j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* arow = smem + (li + halo) * C3S_BP + 4 * h;
-    auto mma = [&](int tap, const float4 (&bt)[JN][2]) __attribute__((always_inline)) {
-        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-        const unsigned sel = (1u << kd) | (8u << kh) | (64u << kw);
-        const float mk = (m9 & sel) == sel ? 1.f : 0.f;
-        const float* ar = arow - ((kd - 1) * HW + (kh - 1) * W + (kw - 1)) * C3S_BP;
-        float4 a[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            a[q] = *(const float4*)(ar + 16 * q);
-            a[q].x *= mk; a[q].y *= mk; a[q].z *= mk; a[q].w *= mk;
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-#pragma unroll
-            for (int j = 0; j < JN; ++j) acc[j][q] = MFMA16(a[q].x, bt[j][q].x, acc[j][q]);
-#pragma unroll
-            for (int j = 0; j < JN; ++j) acc[j][q] = MFMA16(a[q].y, bt[j][q].y, acc[j][q]);
-#pragma unroll
-            for (int j = 0; j < JN; ++j) acc[j][q] = MFMA16(a[q].z, bt[j][q].z, acc[j][q]);
-#pragma unroll
-            for (int j = 0; j < JN; ++j) acc[j][q] = MFMA16(a[q].w, bt[j][q].w, acc[j][q]);
-        }
-    };
-#pragma unroll
-    for (int t = 0; t < 27; ++t) {
-        mma(t, b[t % D]);
-        C3S_PIN();
-        if (t + D < 27) bload(b[t % D], t + D);
-        C3S_PIN();
-    }
+    C3S_TAP_LOOP(-1, C3S_BP)
     // ---- epilogue (wave-local: column = cin0 + 16 j + li, rows 4h .. 4h+3): relu2 mask, dbn2, the two BatchNorm-backward sums
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
@@ -289,39 +305,46 @@ __global__ __launch_bounds__(256) void conv3s_bwd_data_kernel(const Grp<Conv3Bwd
     }
 }
 
-template <int JN, int D>
+template <int JN, int D, bool FRAG>
 int launch_fwd(const Conv3FwdP* pp, int ng, hipStream_t s) {
     const Conv3FwdP& p = *pp;
     const int nrows = C3S_TM + 2 * (p.g.H * p.g.W + p.g.W + 1);
     int smem = nrows * C3S_FP * (int)sizeof(float);
     if (smem < 12800) smem = 12800;                                  // the epilogue's 4 x 16 x 33 floats + 2 x 8 x 32 doubles alias the window
     static std::once_flag attr_once;
-    std::call_once(attr_once, [] { hipFuncSetAttribute((const void*)(void (*)(const Grp<Conv3FwdP>))conv3s_fwd_kernel<JN, D>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    std::call_once(attr_once, [] { hipFuncSetAttribute((const void*)(void (*)(const Grp<Conv3FwdP>))conv3s_fwd_kernel<JN, D, FRAG>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                        MMS_C3S_MAXROWS * C3S_FP * (int)sizeof(float)); });
     Grp<Conv3FwdP> a;
     grp_fill(a, pp, ng, 1);
-    const auto kern = conv3s_fwd_kernel<JN, D>;
+    const auto kern = conv3s_fwd_kernel<JN, D, FRAG>;
     MMS_LAUNCH(kern, dim3((p.M + C3S_TM - 1) / C3S_TM, 2 / JN, ng), dim3(256), smem, s, a);
     return mms_check_launch();
 }
-template <int JN, int D>
+template <int JN, int D, bool FRAG>
 int launch_bwd(const Conv3BwdDataP* pp, int ng, hipStream_t s) {
     const Conv3BwdDataP& p = *pp;
     const int nrows = C3S_TM + 2 * (p.g.H * p.g.W + p.g.W + 1);
     const int smem = nrows * C3S_BP * (int)sizeof(float);
     Grp<Conv3BwdDataP> a;
     grp_fill(a, pp, ng, 1);
-    const auto kern = conv3s_bwd_data_kernel<JN, D>;
+    const auto kern = conv3s_bwd_data_kernel<JN, D, FRAG>;
     MMS_LAUNCH(kern, dim3((p.M + C3S_TM - 1) / C3S_TM, 2 / JN, ng), dim3(256), smem, s, a);
     return mms_check_launch();
 }
 
 }  // namespace
 
+#ifdef C3S_TIMING
+extern "C" int mms_c3s_timing_buffer(void* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(c3s_ts_buf), &buf, sizeof(buf)) == hipSuccess ? MMS_OK : MMS_ERR_LAUNCH; }
+#endif
 // Driver-internal launchers (argument checks are the callers': mms_conv3_fwd_group / mms_conv3_bwd_data_group).
 int mms_c3s_fwd(const Conv3FwdP* pp, int ng, hipStream_t s) {
-    return mms_conv3_small_jn(pp->M, ng, pp->g) == 2 ? launch_fwd<2, 6>(pp, ng, s) : launch_fwd<1, 9>(pp, ng, s);
+    const bool two = mms_conv3_small_jn(pp->M, ng, pp->g) == 2;
+    if (pp->wfrag) return two ? launch_fwd<2, 6, true>(pp, ng, s) : launch_fwd<1, 9, true>(pp, ng, s);
+    return two ? launch_fwd<2, 6, false>(pp, ng, s) : launch_fwd<1, 9, false>(pp, ng, s);
 }
 int mms_c3s_bwd_data(const Conv3BwdDataP* pp, int ng, hipStream_t s) {
-    return mms_conv3_small_jn(pp->M, ng, pp->g) == 2 ? launch_bwd<2, 6>(pp, ng, s) : launch_bwd<1, 9>(pp, ng, s);
+    const bool two = mms_conv3_small_jn(pp->M, ng, pp->g) == 2;
+    if (pp->wfrag) return two ? launch_bwd<2, 6, true>(pp, ng, s) : launch_bwd<1, 9, true>(pp, ng, s);
+    return two ? launch_bwd<2, 6, false>(pp, ng, s) : launch_bwd<1, 9, false>(pp, ng, s);
 }

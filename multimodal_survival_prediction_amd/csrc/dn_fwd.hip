@@ -448,7 +448,8 @@ extern "C" int mms_conv3_fwd_group(const Conv3FwdP* pp, int ng, hipStream_t s) {
         if (q.M != p.M || q.ldo % 4 != 0 || q.g.D != p.g.D || q.g.H != p.g.H || q.g.W != p.g.W || (q.partial == nullptr) != (p.partial == nullptr) ||
             q.nsplit != p.nsplit) return MMS_ERR_ARG;
     }
-    for (int g = 0; g < ng; ++g) if (!mms_bn_aligned16(pp[g].bn)) return MMS_ERR_ARG;   // BatchNorm blocks are read with 16-byte vector loads
+    for (int g = 0; g < ng; ++g) if (!mms_bn_aligned16(pp[g].bn) || pp[g].wfrag != p.wfrag) return MMS_ERR_ARG;   // BatchNorm blocks are read with 16-byte vector loads
+    if (p.wfrag) return (!p.partial && mms_conv3_small_jn(p.M, ng, p.g)) ? mms_c3s_fwd(pp, ng, s) : MMS_ERR_ARG;       // fragment-ordered weights: the small-grid kernel only
     if (const int tm = p.partial ? 0 : conv3_mt_tile(p.M, ng, p.g)) return tm == 64 ? launch_conv3_fwd_mt<64>(pp, ng, s) : launch_conv3_fwd_mt<32>(pp, ng, s);
     if (!p.partial && mms_conv3_small_jn(p.M, ng, p.g)) return mms_c3s_fwd(pp, ng, s);      // small grids: 16-row tiles, all taps, no reduce launch
     if (p.partial) {
@@ -798,13 +799,32 @@ extern "C" int mms_pack_conv3(const float* w, float* wpf, float* wpb, hipStream_
     return mms_check_launch();
 }
 
+// single layer, MFMA-fragment orders (tests / tools; the step uses the table kernel below)
+__global__ void pack_conv3_frag_kernel(const float* __restrict__ w, float* __restrict__ wff, float* __restrict__ wfb) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;      // over the canonical [cout][cin][tap]
+    if (idx >= 32 * 128 * 27) return;
+    const int tap = idx % 27, cin = (idx / 27) & 127, co = idx / (27 * 128);
+    const float v = w[idx];
+    wff[(((((size_t)tap * 4 + (cin >> 5)) * 2 + ((cin >> 4) & 1)) * 2 + (co >> 4)) * 64 + ((cin >> 2) & 3) * 16 + (co & 15)) * 4 + (cin & 3)] = v;
+    wfb[((((size_t)tap * 8 + (cin >> 4)) * 2 + (co >> 4)) * 64 + ((co >> 2) & 3) * 16 + (cin & 15)) * 4 + (co & 3)] = v;
+}
+extern "C" int mms_pack_conv3_frag(const float* w, float* wff, float* wfb, hipStream_t s) {
+    if (!w || !wff || !wfb) return MMS_ERR_ARG;
+    MMS_LAUNCH(pack_conv3_frag_kernel, dim3(32 * 27 * 128 / 256), dim3(256), 0, s, w, wff, wfb);
+    return mms_check_launch();
+}
+
 // batched variant over device tables of layer pointers (one launch per forward, all models of the fold group).
 // One workgroup = (model, layer, 32 input channels): the [32 co][32 cin][27] slice is staged in LDS (odd strides: every
 // phase is bank-conflict free) so that the canonical reads (1728-B runs), the backward pack (the slice is one contiguous
 // 110 KB run of wpb) and the forward pack (128-B runs = whole cache lines) are all coalesced.
 struct TabPtrs { const void* t[MMS_MAX_GROUP]; };
 #define PACK_CO_STRIDE 865      // 32 * 27 + 1
-__global__ __launch_bounds__(256) void pack_conv3_table_kernel(const TabPtrs tabs) {
+// fragmask bit l: layer l's packs in MFMA-fragment order (consumed by the small-grid kernels of dn_c3s.hip, whose weight loads are then one
+// contiguous 1 KB per wave instruction instead of 64 separate 16-byte pieces):
+//   forward  [tap][cin/32][(cin/16)%2][co/16][lane = ((cin/4)%4)*16 + co%16][cin%4]
+//   backward [tap][cin/16][co/16][lane = ((co/4)%4)*16 + cin%16][co%4]
+__global__ __launch_bounds__(256) void pack_conv3_table_kernel(const TabPtrs tabs, uint64_t fragmask) {
     extern __shared__ float t[];         // [32 co][PACK_CO_STRIDE]: element (co, cin_l, tap) at co * 865 + cin_l * 27 + tap
     const PackEntry e = ((const PackEntry*)tabs.t[blockIdx.z])[blockIdx.y];
     const int cin0 = blockIdx.x * 32;
@@ -813,6 +833,19 @@ __global__ __launch_bounds__(256) void pack_conv3_table_kernel(const TabPtrs tab
         t[co * PACK_CO_STRIDE + r] = e.w[((size_t)co * 128 + cin0) * 27 + r];
     }
     __syncthreads();
+    if ((fragmask >> blockIdx.y) & 1ull) {
+        for (int idx = threadIdx.x; idx < 32 * 864; idx += 256) {        // backward: this slice = cin tiles 2x, 2x+1 -> 4 KB runs per tap
+            const int el = idx & 3, lane = (idx >> 2) & 63, q = (idx >> 8) & 1, ntl = (idx >> 9) & 1, tap = idx >> 10;
+            const int cin_l = 16 * ntl + (lane & 15), co = 16 * q + 4 * (lane >> 4) + el;
+            e.wpb[((((size_t)tap * 8 + 2 * blockIdx.x + ntl) * 2 + q) * 64 + lane) * 4 + el] = t[co * PACK_CO_STRIDE + cin_l * 27 + tap];
+        }
+        for (int idx = threadIdx.x; idx < 32 * 864; idx += 256) {        // forward: this slice = channel quarter x -> 4 KB runs per tap
+            const int el = idx & 3, lane = (idx >> 2) & 63, j = (idx >> 8) & 1, q = (idx >> 9) & 1, tap = idx >> 10;
+            const int co = 16 * j + (lane & 15), cin_l = 16 * q + 4 * (lane >> 4) + el;
+            e.wpf[(((((size_t)tap * 4 + blockIdx.x) * 2 + q) * 2 + j) * 64 + lane) * 4 + el] = t[co * PACK_CO_STRIDE + cin_l * 27 + tap];
+        }
+        return;
+    }
     float* wpb = e.wpb + (size_t)cin0 * 27 * 32;
     for (int idx = threadIdx.x; idx < 32 * 864; idx += 256) {            // wpb[cin][tap][co]
         const int co = idx & 31, ct = idx >> 5;                           // ct = cin_l * 27 + tap
@@ -823,15 +856,18 @@ __global__ __launch_bounds__(256) void pack_conv3_table_kernel(const TabPtrs tab
         e.wpf[((size_t)co * 27 + tap) * 128 + cin0 + cl] = t[co * PACK_CO_STRIDE + cl * 27 + tap];
     }
 }
-extern "C" int mms_pack_conv3_table_group(const void* const* tables_dev, int ng, int nlayers, hipStream_t s) {
-    if (!tables_dev || ng < 1 || ng > MMS_MAX_GROUP || nlayers <= 0) return MMS_ERR_ARG;
+extern "C" int mms_pack_conv3_table_group_ex(const void* const* tables_dev, int ng, int nlayers, uint64_t fragmask, hipStream_t s) {
+    if (!tables_dev || ng < 1 || ng > MMS_MAX_GROUP || nlayers <= 0 || nlayers > 64) return MMS_ERR_ARG;
     TabPtrs tp;
     for (int g = 0; g < ng; ++g) tp.t[g] = tables_dev[g];
     constexpr int smem = 32 * PACK_CO_STRIDE * sizeof(float);
     static std::once_flag attr_once;
     std::call_once(attr_once, [&] { hipFuncSetAttribute((const void*)pack_conv3_table_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem); });
-    MMS_LAUNCH(pack_conv3_table_kernel, dim3(4, nlayers, ng), dim3(256), smem, s, tp);
+    MMS_LAUNCH(pack_conv3_table_kernel, dim3(4, nlayers, ng), dim3(256), smem, s, tp, fragmask);
     return mms_check_launch();
+}
+extern "C" int mms_pack_conv3_table_group(const void* const* tables_dev, int ng, int nlayers, hipStream_t s) {
+    return mms_pack_conv3_table_group_ex(tables_dev, ng, nlayers, 0ull, s);
 }
 extern "C" int mms_pack_conv3_table(const void* table_dev, int nlayers, hipStream_t s) {
     return mms_pack_conv3_table_group(&table_dev, 1, nlayers, s);

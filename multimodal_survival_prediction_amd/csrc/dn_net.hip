@@ -154,7 +154,7 @@ inline BnSrc mk_bn(void* ws, size_t st_off, int Ctot_, const float* const* prm, 
 }  // namespace
 
 extern "C" int mms_init_coords(int*, int, int, int, int, hipStream_t);
-extern "C" int mms_pack_conv3_table_group(const void* const*, int, int, hipStream_t);
+extern "C" int mms_pack_conv3_table_group_ex(const void* const*, int, int, uint64_t, hipStream_t);
 extern "C" int mms_unpack_conv3_grads(const void*, int, hipStream_t);
 extern "C" int mms_unpack_conv3_grads_group(const float* const*, float* const* const*, int, int, hipStream_t);
 extern "C" int mms_bn_running_update_group(const void* const*, int, int, float, hipStream_t);
@@ -285,6 +285,18 @@ static int conv3_nsplit(int M, int ng, long cap_rows, const Dims3& g) {
     return (27 + tpw - 1) / tpw;                                         // every workgroup owns >= 1 tap
 }
 
+// Which dense layers get their conv2 weights packed in MFMA-fragment order (Conv3FwdP.wfrag): those of blocks 1-3 whose launches go to the
+// small-grid kernels of dn_c3s.hip.  Block 4 keeps the classic packs (its persistent kernels, dn_b4.hip, read those; its per-layer fallback
+// path runs the small-grid kernels on them).  A function of the plan and MMS_CONV3_SMALL only, so forward and backward agree.
+static bool conv3_frag_block(const Plan& P, int b, int ng) { return b < NB - 1 && mms_conv3_small_jn(P.M[b], ng, P.g[b]) != 0; }
+static uint64_t conv3_fragmask(const Plan& P, int ng) {
+    uint64_t m = 0;
+    int l = 0;
+    for (int b = 0; b < NB; ++b)
+        for (int i = 0; i < LAYERS[b]; ++i, ++l) if (conv3_frag_block(P, b, ng)) m |= 1ull << l;
+    return m;
+}
+
 // MMS_CONV1_KSPLIT=0: never split the conv1 K loop over workgroups (A/B tests; group-vs-single parity tests)
 static bool conv1_ksplit_on() { const char* e = getenv("MMS_CONV1_KSPLIT"); return !(e && e[0] == '0'); }
 
@@ -317,7 +329,7 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
         TRY(mms_zero_regions_group(regs, ng, P.stats_end - P.stats_begin, s));
     }
     FOR_G tabs[g] = at<void>(cx[g].ws, P.tab_pack);
-    TRY(mms_pack_conv3_table_group(tabs, ng, NLAYER, s));
+    TRY(mms_pack_conv3_table_group_ex(tabs, ng, NLAYER, conv3_fragmask(P, ng), s));
     auto st = [&](void* ws, size_t off, int Ctot_, int coff, bool sq) -> double* {
         return train ? at<double>(ws, off) + (sq ? Ctot_ : 0) + coff : nullptr;
     };
@@ -381,7 +393,7 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
                                   slab + C, CTOT[b], mk_bn(c.ws, P.st_y1[l], 128, c.prm, ip + 3, c.buf, IDX.bn_layer2[l], P.M[b] * bw, train, P.R[b]),
                                   st(c.ws, P.st_slab[b], CTOT[b], C, false), st(c.ws, P.st_slab[b], CTOT[b], C, true),
                                   ns3 > 1 ? at<float>(c.ws, P.partial) : nullptr, ns3};
-                c3[g].srep = P.R[b]; c3[g].sstride = 2 * CTOT[b];
+                c3[g].srep = P.R[b]; c3[g].sstride = 2 * CTOT[b]; c3[g].wfrag = conv3_frag_block(P, b, ng) ? 1 : 0;
             }
             TRY(mms_conv1_fwd_group(c1, ng, s));
             SYNC(at<double>(cx[0].ws, P.st_y1[l]), P.R[b], 2 * 128, 128, 128);
@@ -528,7 +540,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
                                       at<float>(c.ws, P.y1[l]), bn2, dmid,
                                       at<double>(c.ws, P.bb_y1[l]), at<double>(c.ws, P.bb_y1[l]) + 128,
                                       ns3 > 1 ? at<float>(c.ws, P.partial) : nullptr, ns3};
-                bd[g].srep = P.R[b]; bd[g].sstride = 2 * 128;
+                bd[g].srep = P.R[b]; bd[g].sstride = 2 * 128; bd[g].wfrag = conv3_frag_block(P, b, ng) ? 1 : 0;
                 bw[g] = Conv3BwdWP{at<float>(c.ws, P.y1[l]), at<int>(c.ws, P.coords[b]), P.g[b], M, bn2, dslab + C, CTOT[b],
                                    at<float>(c.ws, P.dwp[l]), ms3, 1};
                 Conv1BwdP& q = c1[g];

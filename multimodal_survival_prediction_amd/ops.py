@@ -49,10 +49,12 @@ def conv1_fwd(x, K, w, y, bn, M, osum=None, osumsq=None, pool=False, in_dims=(0,
     call("mms_conv1_fwd", p)
 
 
-def conv3_fwd(y1, coords, dims, wp, out, bn, osum=None, osumsq=None, partial=None, nsplit=27):
+def conv3_fwd(y1, coords, dims, wp, out, bn, osum=None, osumsq=None, partial=None, nsplit=27, wfrag=False):
+    """wfrag: wp is the fragment-ordered pack (pack_conv3_frag) -- small grids only (Conv3FwdP.wfrag in mmsurv.h)."""
     M = y1.shape[0]
     p = _S()["Conv3FwdP"](ptr(y1), ptr(coords), dims3(dims), M, ptr(wp), ptr(out), out.stride(0), bn,
                           ptr(osum), ptr(osumsq), ptr(partial), nsplit)
+    p.wfrag = 1 if wfrag else 0
     call("mms_conv3_fwd", p)
 
 
@@ -80,14 +82,23 @@ def pack_conv3(w):
     return wpf, wpb
 
 
+def pack_conv3_frag(w):
+    """canonical conv2 weight -> the two MFMA-fragment-ordered packs the small-grid kernels read with contiguous 1-KB loads."""
+    wff = torch.empty(32 * 27 * 128, dtype=torch.float32, device=w.device)
+    wfb = torch.empty(128 * 27 * 32, dtype=torch.float32, device=w.device)
+    _lib.check(_lib.load_library().mms_pack_conv3_frag(w.data_ptr(), wff.data_ptr(), wfb.data_ptr(), stream()), "mms_pack_conv3_frag")
+    return wff, wfb
+
+
 # ---- backward ops ---------------------------------------------------------------------------------------
 def bnbwd(s1, s2):
     return _S()["BnBwd"](ptr(s1), ptr(s2))
 
 
-def conv3_bwd_data(dz, coords, dims, wpb, y1, bn, dbn, s1, s2, partial=None, nsplit=27):
+def conv3_bwd_data(dz, coords, dims, wpb, y1, bn, dbn, s1, s2, partial=None, nsplit=27, wfrag=False):
     p = _S()["Conv3BwdDataP"](ptr(dz), dz.stride(0), ptr(coords), dims3(dims), y1.shape[0], ptr(wpb), ptr(y1), bn,
                               ptr(dbn), ptr(s1), ptr(s2), ptr(partial), nsplit)
+    p.wfrag = 1 if wfrag else 0
     call("mms_conv3_bwd_data", p)
 
 

@@ -27,11 +27,15 @@ def _d(t):
                                               (3, (7, 7, 8), 64, 256, 4), (2, (8, 16, 16), 96, 256, 8)])
 # small: MMS_CONV3_SMALL for the unsplit conv2 launches (None = default: the all-tap 16-row kernels of dn_c3s.hip on every grid here whose
 # neighbourhood window fits -- all but 16x16x8, 7x7x8, 8x16x16; "0" = tile-GEMM form; "1" / "2" = one / two 16-column tiles per wave)
-@pytest.mark.parametrize("split,small", [(0, None), (0, "0"), (0, "1"), (0, "2"), (27, None), (3, None)])
+# "f1" / "f2": the same with the weights in MFMA-fragment order (wfrag -- what the network driver feeds those kernels)
+@pytest.mark.parametrize("split,small", [(0, None), (0, "0"), (0, "1"), (0, "2"), (0, "f1"), (0, "f2"), (27, None), (3, None)])
 def test_dense_layer_backward(ops, B, dims, C, Ctot, ms, split, small, monkeypatch):
     """One _DenseLayer: norm1-relu-conv1-norm2-relu-conv2 + cat; gradient w.r.t. every parameter and the input slab."""
+    frag = small is not None and small[0] == "f"
+    if frag and 16 + 2 * (dims[1] * dims[2] + dims[2] + 1) > 120:
+        pytest.skip("fragment-ordered weights: small grids only")
     if small is not None:
-        monkeypatch.setenv("MMS_CONV3_SMALL", small)
+        monkeypatch.setenv("MMS_CONV3_SMALL", small[-1])
     torch.manual_seed(0)
     M = B * dims[0] * dims[1] * dims[2]
     x = (torch.randn(B, C, *dims) * 1.3 + 0.2).requires_grad_(True)
@@ -58,13 +62,15 @@ def test_dense_layer_backward(ops, B, dims, C, Ctot, ms, split, small, monkeypat
     s1y, q1y = stats(DEV, 128)
     ops.conv1_fwd(slab, C, w1, y1d, bn1, M, s1y, q1y)
     bn2 = ops.bnsrc(g2, b2, M, True, s1y, q1y)
-    ops.conv3_fwd(y1d, coords, dims, wpf, slab[:, C:C + 32], bn2)
+    if frag:
+        wpf, wpb = ops.pack_conv3_frag(w2)
+    ops.conv3_fwd(y1d, coords, dims, wpf, slab[:, C:C + 32], bn2, wfrag=frag)
     assert_close(slab[:, C:C + 32], cl(z), 1e-4, "fwd z")
     # backward chain, in the driver's order
     dbn_mid = torch.empty(M, 128, device=DEV)
     a1, a2 = stats(DEV, 128)
     part = torch.empty(27 * M * 128, device=DEV) if split else None
-    ops.conv3_bwd_data(dslab[:, C:C + 32], coords, dims, wpb, y1d, bn2, dbn_mid, a1, a2, part, split or 27)
+    ops.conv3_bwd_data(dslab[:, C:C + 32], coords, dims, wpb, y1d, bn2, dbn_mid, a1, a2, part, split or 27, wfrag=frag)
     dw2 = torch.zeros_like(w2)
     monkeypatch.setenv("MMS_CONV3W_MT", "0")            # one-tap GEMM form
     ops.conv3_bwd_weight(y1d, coords, dims, bn2, dslab[:, C:C + 32], dw2, ms)

@@ -104,11 +104,16 @@ def test_transition_fwd(ops, B, dims, K):
 @pytest.mark.parametrize("train", [True, False])
 # small: MMS_CONV3_SMALL -- None = default (the all-tap 16-row kernels of dn_c3s.hip wherever the rows' neighbourhood window fits: every grid
 # here except 16x16x8, 7x7x8, 8x16x16), "0" = off (tile-GEMM form), "1" / "2" = force one / two 16-column output tiles per wave
-@pytest.mark.parametrize("split,mt,small", [(0, "2", None), (0, "2", "0"), (0, "2", "1"), (0, "2", "2"), (0, "3", None), (27, "2", None), (3, "2", None), (5, "2", None)])
+# "f1" / "f2": the same with the weights in MFMA-fragment order (Conv3FwdP.wfrag -- what the network driver feeds those kernels)
+@pytest.mark.parametrize("split,mt,small", [(0, "2", None), (0, "2", "0"), (0, "2", "1"), (0, "2", "2"), (0, "2", "f1"), (0, "2", "f2"), (0, "3", None),
+                                            (27, "2", None), (3, "2", None), (5, "2", None)])
 def test_conv3_fwd(ops, B, dims, train, split, mt, small, monkeypatch):
     monkeypatch.setenv("MMS_CONV3_MT", mt)      # take a multi-tap kernel whenever the shape allows it (default: by tile count)
+    frag = small is not None and small[0] == "f"
+    if frag and 16 + 2 * (dims[1] * dims[2] + dims[2] + 1) > 120:
+        pytest.skip("fragment-ordered weights: small grids only")
     if small is not None:
-        monkeypatch.setenv("MMS_CONV3_SMALL", small)
+        monkeypatch.setenv("MMS_CONV3_SMALL", small[-1])
     torch.manual_seed(2)
     M = B * dims[0] * dims[1] * dims[2]
     y1 = torch.randn(B, 128, *dims) + 0.1
@@ -126,7 +131,8 @@ def test_conv3_fwd(ops, B, dims, train, split, mt, small, monkeypatch):
     slab = torch.zeros(M, 256, device=DEV)
     os_, oq = stats(DEV, 32)
     part = torch.empty(27 * M * 32, device=DEV) if split else None      # tap-split path: partial tiles + reduce kernel
-    ops.conv3_fwd(y1d, coords, dims, wpf, slab[:, 64:96], bn, os_ if train else None, oq if train else None, part, split or 27)
+    ops.conv3_fwd(y1d, coords, dims, ops.pack_conv3_frag(wd)[0] if frag else wpf, slab[:, 64:96], bn, os_ if train else None, oq if train else None, part,
+                  split or 27, wfrag=frag)
     torch.cuda.synchronize()
     assert_close(slab[:, 64:96], cl(ref), 1e-4, "conv3 out")
     assert float(slab[:, :64].abs().max()) == 0.0 and float(slab[:, 96:].abs().max()) == 0.0

@@ -1,0 +1,40 @@
+"""In-kernel phase times of the small-grid conv2 forward kernel (dn_c3s.hip), GPU box.  Builds the library with -DC3S_TIMING into a scratch copy,
+runs a 3-model PartialModalityNet step a few times (cold weights, as in the epoch) and prints the mean shader-clock gaps between the
+stamps: 0 start | 1 prologue loads landed | 2 window staged + barrier | 3 taps done | 4 tile written | 5 statistics atomics acknowledged.
+usage: python tools/c3s_timing.py [G]"""
+import os, sys, ctypes
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+os.environ["MMS_CXXFLAGS"] = "-DC3S_TIMING"
+from multimodal_survival_prediction_amd import _build
+_build.build(force=True)
+import torch
+from multimodal_survival_prediction_amd import _lib, data, models
+from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
+
+G = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+dev = torch.device("cuda:0")
+lib = ctypes.CDLL(_lib.lib_path())
+buf = torch.zeros(8 * 4096, dtype=torch.int64, device=dev)
+assert lib.mms_c3s_timing_buffer(ctypes.c_void_p(buf.data_ptr())) == 0
+ms = []
+for g in range(G):
+    torch.manual_seed(g)
+    ms.append(models.PartialModalityNet(rna_dim=5005).to(dev).train())
+grp = FoldGroupEngine(ms, lr=1e-4, weight_decay=1e-4, gate_entropy_weight=0.01)
+c = data.cohort_to(data.make_cohort(n=64, dims=(64, 64, 32), rna_dim=5005, seed=1, complete=False), dev)
+idx = [[4 * g + i for i in range(4)] for g in range(G)]
+for it in range(6):
+    grp.train_step_indexed(c, idx)
+torch.cuda.synchronize()
+# the buffer holds the records of the LAST forward launch of each grid shape that ran; the last c3s forward launch of a step is block 3's
+# (block 4 runs persistent) -- grid (8, 2, G): 16 G records
+n = 16 * G
+t = buf[:8 * n].view(n, 8).cpu().numpy().astype("float64")
+d = t[:, 1:6] - t[:, 0:5]
+print("block-3 forward launch of the last step, %d workgroups, shader-clock cycles (mean / max over workgroups):" % n)
+for i, name in enumerate(["prologue loads landed", "window staged + barrier", "27 taps", "tile reduced + written", "statistics atomics acknowledged"]):
+    print("  %-34s %8.0f / %8.0f" % (name, d[:, i].mean(), d[:, i].max()))
+print("  %-34s %8.0f / %8.0f   (spread of start stamps: %.0f)" % ("total", (t[:, 5] - t[:, 0]).mean(), (t[:, 5] - t[:, 0]).max(), t[:, 0].max() - t[:, 0].min()))
+os.environ.pop("MMS_CXXFLAGS")
+_build.build(force=True)
