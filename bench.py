@@ -18,10 +18,13 @@ Default workload `c3` = the configuration BASELINE.json's metric is quoted on, N
 Other workloads: `--workload c2` (BASELINE configs[1]: MultiModalSurvivalNet, 109 complete patients, fold models in flight
 configurable -- round 1's headline), `--workload c5` (BASELINE config 5: RNA-seq-only model, batch 2048).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]            (N>1: launched by torch.distributed.run)
-N > 1 (weak scaling, no data-path collective): rank r runs repetition r of the 5-fold cross-validation (repeated K-fold:
-same cohort, KFold random_state 42 + r, its own 5 models); the same run also times ONE cross-validation's 5 folds dealt over
-the ranks (fold k -> rank k mod N, BASELINE config 3's layout) and reports it as `one_cv_sharded_patients_per_s`.
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+N > 1: under torch.distributed.run (RANK / WORLD_SIZE set) every process is one rank; started plainly, bench.py launches its own N
+ranks as children (torch.distributed.run --standalone-style on 127.0.0.1) BEFORE touching the GPU and relays rank 0's JSON line and the
+exit code -- it never prints an n_gpus = 1 line for a --gpus N request.  `value` at N > 1 is BASELINE config 3's literal layout: ONE
+5-fold cross-validation's folds dealt over the ranks (fold k -> rank k mod N, no data-path collective; "scaling": "strong" -- the job
+is fixed, at N = 4 the ranks hold 2/1/1/1 fold models, at N = 8 three ranks idle).  The repeated-K-fold figure (rank r = its own
+repetition of the 5-fold CV, per-GPU work fixed: weak scaling) is reported beside it as `repeated_kfold_patients_per_s`.
 `--mode ddp` = BASELINE config 4's data-parallel step (one model, global batch N*B, gradient all-reduce over RCCL).
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
@@ -32,6 +35,8 @@ import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -171,6 +176,20 @@ def roofline_block(B, dims, dev, group_sizes):
                             "frac": v[1] / v[0] / 1e12 / PEAK_FP32_MFMA_TFLOPS} for op, v in fam.items()}}
 
 
+def _host_cores():
+    """-> (physical cores available to this process, torch intra-op threads actually used)"""
+    threads = torch.get_num_threads()
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or threads
+        logical = psutil.cpu_count(logical=True) or phys
+        avail = len(os.sched_getaffinity(0))
+        phys = max(1, min(phys, avail * phys // max(logical, 1) if avail < logical else phys))
+    except Exception:
+        phys = threads
+    return phys, threads
+
+
 # ---- CPU baselines (the oracle = torch fp32 restatement; bench.py's cpu_baseline leg is one of the three places allowed to use it)
 def cpu_baseline_partial(cohort, train_idx, steps, B):
     """The CPU oracle's train_epoch_partial loop body (oracle/loops.py, partial_modality_training.py:382-435) on the SAME cohort
@@ -180,7 +199,7 @@ def cpu_baseline_partial(cohort, train_idx, steps, B):
     torch.manual_seed(0)
     model = OM.PartialModalityNet(rna_dim=cohort["rnaseq"].shape[1], use_monai=True)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-4)
-    cores = torch.get_num_threads()
+    cores, threads = _host_cores()
 
     def loader(lo, hi):
         for i in range(lo, hi):
@@ -191,9 +210,9 @@ def cpu_baseline_partial(cohort, train_idx, steps, B):
     t0 = time.perf_counter()
     OLP.train_epoch_partial(model, loader(1, steps + 1), opt, "cpu")
     dt = time.perf_counter() - t0
-    return dict(value=steps * B / dt, unit="patients/s", cores=cores, kind="port",
+    return dict(value=steps * B / dt, unit="patients/s", cores=cores, threads=threads, kind="port", full_epoch=False,
                 sample=f"{steps} batches (batch {B}) of the torch-fp32 CPU oracle's train_epoch_partial on fold 1's training split "
-                       f"of the same cohort, after 1 warm-up batch, {dt:.1f} s")
+                       f"of the same cohort, after 1 warm-up batch, {dt:.1f} s (a bounded sample, not BASELINE.md's full epoch)")
 
 
 def cpu_baseline_final(cohort, train_idx, steps, B):
@@ -204,7 +223,7 @@ def cpu_baseline_final(cohort, train_idx, steps, B):
     model = OM.MultiModalSurvivalNet(rna_dim=cohort["rnaseq"].shape[1], use_monai=True)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-4)
     model.train()
-    cores = torch.get_num_threads()
+    cores, threads = _host_cores()
 
     def one(i):
         j = train_idx[i * B:(i + 1) * B]
@@ -220,7 +239,7 @@ def cpu_baseline_final(cohort, train_idx, steps, B):
     for i in range(1, steps + 1):
         one(i)
     dt = time.perf_counter() - t0
-    return dict(value=steps * B / dt, unit="patients/s", cores=cores, kind="port",
+    return dict(value=steps * B / dt, unit="patients/s", cores=cores, threads=threads, kind="port", full_epoch=False,
                 sample=f"{steps} training steps (batch {B}) of the torch-fp32 CPU oracle after 1 warm-up step, {dt:.1f} s")
 
 
@@ -244,20 +263,26 @@ def run_config3(args, world, rank, dev):
         return ([data.BatchLoader(cohort, t, B, shuffle=True, seed=random_state + k, lazy=True, with_valid=True) for k, t in enumerate(tr)],
                 [data.BatchLoader(cohort, v, B, shuffle=False, lazy=True, with_valid=True) for v in va], tr, folds)
 
-    rep = rank                                                     # N > 1: rank r = repetition r of the K-fold CV
-    train_loaders, val_loaders, train_sets, folds = cv_loaders(42 + rep)
+    # N = 1: the 5-fold CV on this GPU.  N > 1: the SAME cross-validation (KFold random_state 42, fold k's model seeded 42 + k on every
+    # rank), its folds dealt over the ranks: rank r steps the fold models k with k mod N == r (distributed.folds_of_rank) -- BASELINE
+    # config 3's literal layout, no data-path collective.  Every rank builds all K models (the repeated-K-fold side leg uses them).
+    train_loaders, val_loaders, train_sets, folds = cv_loaders(42)
     ms = []
     for k in range(K):
-        torch.manual_seed(42 + rep * K + k)
+        torch.manual_seed(42 + k)
         ms.append(models.PartialModalityNet(rna_dim=5005).to(dev).train())
     group = FoldGroupEngine(ms, lr=1e-4, weight_decay=1e-4, adamw=False, gate_entropy_weight=0.01)
     conc = args.lockstep_streams
     steps_per_epoch = max(len(l) for l in train_loaders)
     patients_per_epoch = sum(len(t) for t in train_sets)
+    mine = tuple(D.folds_of_rank(K, world, rank)) if world > 1 else tuple(range(K))
 
-    def epoch(members=None):
+    def epoch(members=None, loaders=None):
         mem = tuple(range(K)) if members is None else tuple(members)
-        return train_epoch_lockstep(group, [train_loaders[g] for g in mem], "partial", members=mem, concurrent=conc)
+        if not mem:
+            return []
+        ld = train_loaders if loaders is None else loaders
+        return train_epoch_lockstep(group, [ld[g] for g in mem], "partial", members=mem, concurrent=conc)
 
     def timed(fn):
         torch.cuda.synchronize(); D.barrier(); torch.cuda.synchronize()
@@ -268,32 +293,36 @@ def run_config3(args, world, rank, dev):
 
     n_warm = max(1, math.ceil(args.warmup / steps_per_epoch))       # whole epochs: every sub-group / ragged-tail graph gets captured
     for _ in range(n_warm):
-        epoch()
+        epoch(mine)
     n_ep = max(1, math.ceil(args.steps / steps_per_epoch))
     last = []
 
     def run_epochs():
         for _ in range(n_ep):
-            last[:] = epoch()
+            last[:] = epoch(mine)
     dt, _ = timed(run_epochs)
-    value = world * n_ep * patients_per_epoch / dt
+    value = n_ep * patients_per_epoch / dt          # the whole job's training patients (all folds, all ranks) per second
     if args.timed_only:
         if rank == 0:
             print(f"timed-only: {value:.1f} patients/s, {dt / (n_ep * steps_per_epoch) * 1e3:.3f} ms per lock-step step, "
                   f"{dt / n_ep:.3f} s per epoch", flush=True)
         D.barrier()
         return
-    nsub = 1 if conc <= 1 or K < 4 else min(conc, K)
-    sub_groups = tuple(K // nsub + (1 if h < K % nsub else 0) for h in range(nsub))
+    def subs(n):        # training.train_epoch_lockstep: sub-group sizes of n fold models on this GPU
+        ns = 1 if conc <= 1 or n < 4 else min(conc, n)
+        return tuple(n // ns + (1 if h < n % ns else 0) for h in range(ns))
+    sub_groups = subs(len(mine)) if mine else subs(1)
+    import torch.distributed as tdist
+    backend = tdist.get_backend() if tdist.is_initialized() else None
 
-    # ONE cross-validation's folds dealt over the ranks (BASELINE config 3's layout: fold k -> rank k mod N), one epoch
-    sharded = None
+    # side leg at N > 1: repeated K-fold (rank r = repetition r of the 5-fold CV on the same cohort, KFold random_state 42 + r, all K
+    # fold models of this rank in lock-step): per-GPU work fixed as N grows = weak scaling, no collective
+    repeated = None
     if world > 1:
-        mine = D.folds_of_rank(K, world, rank)
-        if mine:
-            epoch(mine)                                              # capture the sub-group graphs of this member set
-        dts, _ = timed(lambda: epoch(mine) if mine else None)
-        sharded = patients_per_epoch / dts
+        rep_loaders = cv_loaders(42 + rank)[0]
+        epoch(None, rep_loaders)                                     # capture the full-group graphs
+        dtr, _ = timed(lambda: epoch(None, rep_loaders))
+        repeated = world * patients_per_epoch / dtr
     # one fold model alone on the GPU (what a rank with a single fold of config 3 runs)
     n1 = max(20, min(steps_per_epoch, args.steps // 3))
     idx1 = train_loaders[0].idx
@@ -323,9 +352,10 @@ def run_config3(args, world, rank, dev):
             "metric": "patients/sec per epoch (training epoch of the K-fold job: fwd + Cox + gate entropy + bwd + clip + Adam)",
             "value": value, "unit": "patients/s", "n_gpus": world, "steps": n_ep * steps_per_epoch,
             "warmup": n_warm * steps_per_epoch, "ms_per_step": dt / (n_ep * steps_per_epoch) * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "BASELINE config 3, N=1 leg (the metric's configuration): %d synthetic patients with modality masks "
+                "workload": ("BASELINE config 3, N=1 leg" if world == 1 else "BASELINE config 3, one 5-fold CV sharded over %d GPUs" % world) +
+                            " (the metric's configuration): %d synthetic patients with modality masks "
                             "(%d CT / %d RNA-seq / %d clinical / %d labelled), PartialModalityNet (DenseNet121-3D CT %dx%dx%d + RNA-seq 5005 + "
                             "clinical, softmax gate + 0.01 x gate entropy), %d-fold CV over the labelled patients with all %d unlabelled "
                             "patients in every training split (%d training patients per epoch over the folds), batch %d, Adam lr 1e-4 wd "
@@ -336,16 +366,19 @@ def run_config3(args, world, rank, dev):
                 "step": "one lock-step step of the K-fold job: every fold model takes one batch (<= %d x %d patients)" % (K, B),
                 "steps_requested": args.steps, "warmup_requested": args.warmup, "epochs_timed": n_ep, "steps_per_epoch": steps_per_epoch,
                 "train_patients_per_epoch": patients_per_epoch, "seconds_per_epoch": dt / n_ep,
-                "global_batch": world * K * B,
-                "parallelism": (f"{world} rank(s), each its own repetition of the {K}-fold CV (repeated K-fold, no data-path collective); "
-                                f"per GPU the {K} fold models in lock-step as sub-groups of {'+'.join(map(str, sub_groups))} on "
-                                f"{len(sub_groups)} HIP stream(s), one step graph per sub-group"),
+                "global_batch": K * B,
+                "parallelism": (f"1 GPU: the {K} fold models in lock-step as sub-groups of {'+'.join(map(str, sub_groups))} on "
+                                f"{len(sub_groups)} HIP stream(s), one step graph per sub-group" if world == 1 else
+                                f"kfold-shard x{world}: ONE {K}-fold CV, fold k on rank k mod {world} (rank 0 holds {len(mine)} fold model(s), "
+                                f"{max(0, world - K)} rank(s) idle), no data-path collective (torch.distributed backend {backend}); value = the "
+                                f"CV's training patients / max-over-ranks epoch time"),
                 "fold_models_in_flight": K, "lockstep_streams": conc,
-                "one_cv_sharded_patients_per_s": sharded,
-                "single_chain_patients_per_s": world * B / dt1, "single_chain_ms_per_step": dt1 * 1e3,
-                "validation_patients_per_s": world * n_val / dtv,
+                "rccl_ranks_seen": (tdist.get_world_size() if backend == "nccl" else 0),
+                "repeated_kfold_patients_per_s": repeated,
+                "single_chain_patients_per_s": B / dt1, "single_chain_ms_per_step": dt1 * 1e3,
+                "validation_patients_per_s": n_val / dtv,
                 "h2d": h2d, "many_folds": many,
-                "hip_graph": True, "bn": "per-model batch statistics", "cox": "per-batch risk sets (Breslow = reference on distinct times)",
+                "hip_graph": True, "bn": "per-model batch statistics", "cox": "per-batch risk sets, Efron ties = torchsurv's rule (identical to Breslow on the cohort's distinct times)",
                 "train_loss_last_epoch": [[float(a), float(b)] for a, b in last],
                 "val_loss_cindex": [[float(a), float(b)] for a, b in val]},
         }
@@ -467,7 +500,7 @@ def run_config5(args, dev):
                 c0 = time.perf_counter()
             opt.zero_grad(); OL.neg_partial_log_likelihood(ref(x).squeeze(), ec, tc).backward(); opt.step()
         cdt = time.perf_counter() - c0
-        out["cpu_baseline"] = dict(value=args.cpu_steps * B / cdt, unit="patients/s", cores=torch.get_num_threads(), kind="port",
+        out["cpu_baseline"] = dict(value=args.cpu_steps * B / cdt, unit="patients/s", cores=_host_cores()[0], threads=torch.get_num_threads(), kind="port", full_epoch=False,
                                    sample=f"{args.cpu_steps} training steps (batch {B}) of the torch-fp32 CPU oracle after 1 warm-up step, {cdt:.1f} s")
     print(json.dumps(out), flush=True)
 
@@ -582,6 +615,29 @@ def run_config2(args, world, rank, dev):
     D.barrier()
 
 
+def _spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children through torch.distributed.run (one process per GPU,
+    rendezvous on 127.0.0.1) and return their exit code.  Refuses when fewer than N GPUs are visible -- a --gpus N request never
+    yields an n_gpus = 1 line."""
+    n = args.gpus
+    if not (args.rendezvous_check or args.dry_launch):
+        ndev = torch.cuda.device_count()
+        if ndev < n:
+            print(f"bench.py: --gpus {n} but only {ndev} GPU(s) are visible; not running on fewer GPUs than asked", file=sys.stderr)
+            return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + [a for a in argv if a != "--dry-launch"]
+    if args.dry_launch:
+        print(json.dumps({"launch": cmd}), flush=True)
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -618,12 +674,32 @@ def main():
     ap.add_argument("--mode", choices=["fold", "ddp"], default="fold",
                     help="c2, N>1: 'fold' = K-fold units sharded over ranks, no collective; 'ddp' = one model, global "
                          "batch N*B, bucketed gradient all-reduce (RCCL) per step")
+    ap.add_argument("--dry-launch", action="store_true", help="--gpus N > 1 started without a launcher: print the rank-launch command as JSON and exit")
+    ap.add_argument("--rendezvous-check", action="store_true",
+                    help="ranks only rendezvous (torch.distributed init + one all-gather) and rank 0 prints {rendezvous: N, ranks: [...]}: "
+                         "checks the self-launch path on a box without N GPUs (CPU: gloo)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: become the launcher.  Nothing above has touched the GPU (torch.cuda.device_count() does not initialise it), so
+        # the ranks are plain children; this process only relays their output (rank 0's JSON line) and exit code.
+        raise SystemExit(_spawn_ranks(args, sys.argv[1:]))
 
     from multimodal_survival_prediction_amd import distributed as D
     world, rank, local = D.init()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as {args.gpus} GPUs")
+    if args.rendezvous_check:
+        import torch.distributed as tdist
+        seen = [None] * world
+        if world > 1:
+            tdist.all_gather_object(seen, rank)
+        else:
+            seen = [0]
+        if rank == 0:
+            print(json.dumps({"rendezvous": world, "ranks": sorted(seen), "backend": tdist.get_backend() if world > 1 else None}), flush=True)
+        D.barrier()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
     torch.cuda.set_device(local)

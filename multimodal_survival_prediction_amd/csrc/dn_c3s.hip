@@ -41,11 +41,11 @@ constexpr int C3S_NI = (MMS_C3S_MAXROWS + 7) / 8;
 // -DC3S_TIMING (tools/c3s_timing.py): shader-clock stamps of the kernel's phases, one record of 8 words per workgroup
 #ifdef C3S_TIMING
 __device__ unsigned long long* c3s_ts_buf = nullptr;
-#define C3S_TS_DECL unsigned long long ts_[6] = {0, 0, 0, 0, 0, 0}
+#define C3S_TS_DECL unsigned long long ts_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define C3S_STAMP(i) do { asm volatile("" ::: "memory"); ts_[i] = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); } while (0)
 #define C3S_STAMPW(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); ts_[i] = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); } while (0)
 #define C3S_TS_FLUSH() do { if (threadIdx.x == 0 && c3s_ts_buf) { unsigned long long* o = c3s_ts_buf + 8 * (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)); \
-    for (int i_ = 0; i_ < 6; ++i_) o[i_] = ts_[i_]; } } while (0)
+    for (int i_ = 0; i_ < 8; ++i_) o[i_] = ts_[i_]; } } while (0)
 #else
 #define C3S_TS_DECL
 #define C3S_STAMP(i)
@@ -107,6 +107,9 @@ __global__ __launch_bounds__(256) void conv3s_fwd_kernel(const Grp<Conv3FwdP> gr
     const int W = g.W, HW = g.H * g.W, halo = HW + W + 1, nrows = C3S_TM + 2 * halo;
     C3S_TS_DECL;
     C3S_STAMP(0);
+#ifdef C3S_TIMING
+    { int probe_ = M + g.W; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 0" : "+s"(probe_) :: "memory"); ts_[6] = __builtin_amdgcn_s_memtime(); }
+#endif
 
     // window rows (raw y1) -> registers: branch-free, from clamped (always valid) addresses; rows outside [0, M) are zeroed when staged
     const int c4 = (tid & 31) * 4;
@@ -142,6 +145,7 @@ __global__ __launch_bounds__(256) void conv3s_fwd_kernel(const Grp<Conv3FwdP> gr
     C3S_PIN();
     // BatchNorm2 constants of this thread's 4 channels; transform -> LDS
     float mean[4], sc[4], beta[4];
+    C3S_STAMP(7);
     bn_consts4(p.bn, c4, mean, sc, beta);
     C3S_STAMPW(1);
     const unsigned m9 = myrow < M ? c3s_mask9(mycoord, g, false) : 0u;

@@ -4,9 +4,11 @@ Two ways the path shards:
   * K-fold level -- independent units, zero data-path exchange: fold k runs on rank k mod world; only the per-fold
     result records are gathered at the end (`gather_fold_results`).  Reproduces single-GPU results exactly.
   * patient/batch level (DDP): each rank steps on its shard of the global batch; the flat gradient buffer is
-    all-reduced (SUM then /world) between backward and the clip+Adam kernels (`allreduce_mean_`), one collective of
-    all-reduced (SUM) in 5 buckets -- heads, then the DenseNet121 backward stages 3..0 -- each launched asynchronously as soon as
-    its stage has been enqueued (`allreduce_ranges_async`), overlapping the rest of the backward; the update waits for them.
+    all-reduced between backward and the clip+Adam kernels: one blocking collective (`allreduce_mean_`), or -- the default of
+    the staged step -- SUM in 5 buckets (`gradient_buckets`: heads, then the DenseNet121 backward stages 3..0), each launched
+    asynchronously as soon as its stage has been enqueued (`allreduce_ranges_async`) so that it overlaps the rest of the backward; the
+    update waits for all of them and divides by the world size.  (The RCCL branch has not run on hardware yet: 1-GPU leases; the gloo
+    CPU tests take the same async code path.)
     Cox risk set: rank-local (default), or GLOBAL over the world*B patients of the step (`train_step(..., ddp_world=N,
     global_cox=True)`).  BatchNorm: rank-local, or `sync_bn=True` = exact global-batch semantics (engine._ddp_step_syncbn).
 """
@@ -106,6 +108,37 @@ def allreduce_ranges_async(flat, ranges, world):
         for w in works:
             w.wait()
     return wait
+
+
+ENC_STAGE_CUTS = (0, 39, 114, 261, 364)     # csrc/dn_net.hip Idx: parameter-table index where dense block b's backward stage begins (b = 0..3)
+
+
+def gradient_buckets(params, encoder_params, staged):
+    """Gradient buckets of the data-parallel step in the order the backward finalises them: the heads, then (staged = DenseNet121
+    encoder) its backward stages 3, 2, 1, 0 -- each a list of contiguous (offset, length) ranges of the flat gradient buffer, in which
+    the parameters lie in `params` order.  -> [[(offset, length), ...], ...]; together the ranges cover the buffer exactly once."""
+    offs, o = {}, 0
+    for q in params:
+        offs[id(q)] = (o, q.numel())
+        o += q.numel()
+
+    def ranges(ids):
+        out = []
+        for a, n in sorted(offs[i] for i in ids):
+            if out and out[-1][0] + out[-1][1] == a:
+                out[-1] = (out[-1][0], out[-1][1] + n)
+            else:
+                out.append((a, n))
+        return out
+    eids = [id(q) for q in encoder_params]
+    eset = set(eids)
+    hids = [id(q) for q in params if id(q) not in eset]
+    if staged:
+        c = ENC_STAGE_CUTS
+        if len(eids) != c[-1]:
+            raise ValueError("staged buckets are defined for the DenseNet121 encoder (%d parameter tensors), got %d" % (c[-1], len(eids)))
+        return [ranges(hids)] + [ranges(eids[c[b]:c[b + 1]]) for b in (3, 2, 1, 0)]
+    return [ranges(hids + eids)]
 
 
 def max_over_ranks(x, device):

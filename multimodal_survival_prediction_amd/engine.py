@@ -613,35 +613,13 @@ class SurvivalEngine:
         P.graphs[key].replay()
 
     # ---- data-parallel step (one process per GPU) --------------------------------------------------------
-    ENC_STAGE_CUTS = (0, 39, 114, 261, 364)     # dn_net.hip Idx: parameter-table index where dense block b's stage begins (b = 0..3)
-
     def _buckets(self, P):
-        """Gradient buckets in the order the backward finalises them: the heads, then the DenseNet121 stages 3, 2, 1, 0 (each a
-        contiguous range of the flat buffer -- parameters are laid out in module order).  -> [[(offset, length), ...], ...]"""
+        """Gradient buckets in the order the backward finalises them (distributed.gradient_buckets) -> (staged, buckets)."""
         if getattr(self, "_bucket_cache", None) is None:
-            offs, o = {}, 0
-            for q in self.params:
-                offs[id(q)] = (o, q.numel())
-                o += q.numel()
-
-            def ranges(ids):
-                out = []
-                for a, n in sorted(offs[i] for i in ids):
-                    if out and out[-1][0] + out[-1][1] == a:
-                        out[-1] = (out[-1][0], out[-1][1] + n)
-                    else:
-                        out.append((a, n))
-                return out
+            from . import distributed as D
             enc = self.prog["encoder"]
-            eids = [id(q) for q in enc.parameters()] if enc is not None else []
-            eset = set(eids)
-            hids = [id(q) for q in self.params if id(q) not in eset]
             staged = enc is not None and not isinstance(enc, nn.Sequential)
-            if staged:
-                c = self.ENC_STAGE_CUTS
-                self._bucket_cache = (True, [ranges(hids)] + [ranges(eids[c[b]:c[b + 1]]) for b in (3, 2, 1, 0)])
-            else:
-                self._bucket_cache = (False, [ranges(hids + eids)])
+            self._bucket_cache = (staged, D.gradient_buckets(self.params, list(enc.parameters()) if enc is not None else [], staged))
         return self._bucket_cache
 
     def _ddp_sequence(self, P, global_cox):

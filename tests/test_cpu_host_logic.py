@@ -58,6 +58,16 @@ assert out.tolist() == [0, 1, 2, 10, 11, 12]
 s = torch.full((8,), float(rank + 1))
 D.allreduce_sum_(s, world)
 assert torch.allclose(s, torch.full((8,), 3.0))
+# the staged data-parallel step's exchange: buckets launched asynchronously (async_op=True), waited for later -- CPU tensors take the
+# same branch RCCL takes on the GPU (no host detour); every bucket's ranges are summed, nothing outside them is touched
+flat = torch.arange(100.0) * (rank + 1)
+w1 = D.allreduce_ranges_async(flat, [(0, 10), (50, 20)], world)
+w2 = D.allreduce_ranges_async(flat, [(90, 10)], world)
+w2(); w1()
+want = torch.arange(100.0) * (rank + 1)
+for a, n in [(0, 10), (50, 20), (90, 10)]:
+    want[a:a + n] = torch.arange(100.0)[a:a + n] * 3
+assert torch.equal(flat, want), (flat, want)
 D.barrier()
 print("ok", rank)
 '''
@@ -72,6 +82,55 @@ def test_two_rank_gloo(tmp_path):
     outs = [p.communicate(timeout=120)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"ok {r}" in o, o
+
+
+def test_gradient_buckets_cover_flat_buffer_once():
+    """engine._buckets / distributed.gradient_buckets: heads first, then the DenseNet121 backward stages 3..0; contiguous ranges that
+    cover the parameter-ordered flat buffer exactly once, each stage = the parameter tensors of its dense block (+ transition / stem / norm5)."""
+    from multimodal_survival_prediction_amd import distributed as D, models
+    m = models.MultiModalSurvivalNet(rna_dim=16)
+    params = list(m.parameters())
+    enc = list(m.ct_encoder.parameters())
+    assert len(enc) == D.ENC_STAGE_CUTS[-1]
+    buckets = D.gradient_buckets(params, enc, True)
+    assert len(buckets) == 5
+    n = sum(p.numel() for p in params)
+    cover = np.zeros(n, dtype=np.int32)
+    for b in buckets:
+        for a, k in b:
+            cover[a:a + k] += 1
+    assert cover.min() == 1 and cover.max() == 1
+    # finalisation order: stage 3 = denseblock4 + norm5 + class_layers (+ transition3), ..., stage 0 = stem + denseblock1
+    names = [k for k, _ in m.ct_encoder.named_parameters()]
+    offs = np.cumsum([0] + [p.numel() for p in params])
+    start = {id(p): offs[i] for i, p in enumerate(params)}
+    c = D.ENC_STAGE_CUTS
+    for k, blk in enumerate((3, 2, 1, 0)):
+        lo = start[id(enc[c[blk]])]
+        assert buckets[1 + k][0][0] == lo
+        assert sum(x for _, x in buckets[1 + k]) == sum(p.numel() for p in enc[c[blk]:c[blk + 1]])
+    assert names[c[3]].startswith("features.denseblock4") or names[c[3]].startswith("features.transition3")
+    assert names[0] == "features.conv0.weight" and names[c[1]].startswith(("features.denseblock2", "features.transition1"))
+    # single bucket for an encoder-less / fallback model
+    one = D.gradient_buckets(params, [], False)
+    assert one == [[(0, n)]]
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` without a launcher starts N ranks itself (before touching a GPU) and never reports fewer GPUs than asked."""
+    bench = os.path.join(ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-launch"], capture_output=True, text=True, timeout=120)
+    cmd = __import__("json").loads(r.stdout.strip().splitlines()[-1])["launch"]
+    assert r.returncode == 0 and "torch.distributed.run" in cmd and "--nproc-per-node=2" in cmd and cmd[-2:] == ["--gpus", "2"]
+    env = dict(os.environ, MMS_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--rendezvous-check"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    assert __import__("json").loads(line) == {"rendezvous": 2, "ranks": [0, 1], "backend": "gloo"}
+    if torch.cuda.device_count() < 8:      # a request that cannot be met is refused, not downgraded to one GPU
+        r = subprocess.run([sys.executable, bench, "--gpus", "8"], capture_output=True, text=True, timeout=120, env=env)
+        assert r.returncode != 0 and "n_gpus" not in r.stdout
 
 
 def test_schedulers_match_torch():

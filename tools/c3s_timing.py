@@ -35,6 +35,8 @@ d = t[:, 1:6] - t[:, 0:5]
 print("block-3 forward launch of the last step, %d workgroups, shader-clock cycles (mean / max over workgroups):" % n)
 for i, name in enumerate(["prologue loads landed", "window staged + barrier", "27 taps", "tile reduced + written", "statistics atomics acknowledged"]):
     print("  %-34s %8.0f / %8.0f" % (name, d[:, i].mean(), d[:, i].max()))
+print("  %-34s %8.0f / %8.0f" % ("  of which: kernel arguments read", (t[:, 6] - t[:, 0]).mean(), (t[:, 6] - t[:, 0]).max()))
+print("  %-34s %8.0f / %8.0f" % ("  of which: prologue loads ISSUED", (t[:, 7] - t[:, 6]).mean(), (t[:, 7] - t[:, 6]).max()))
 print("  %-34s %8.0f / %8.0f   (spread of start stamps: %.0f)" % ("total", (t[:, 5] - t[:, 0]).mean(), (t[:, 5] - t[:, 0]).max(), t[:, 0].max() - t[:, 0].min()))
 os.environ.pop("MMS_CXXFLAGS")
 _build.build(force=True)
