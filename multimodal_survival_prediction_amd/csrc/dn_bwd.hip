@@ -606,23 +606,26 @@ struct Conv1BwdDataOp {
     __device__ void krange(const Params& p, int, int& kb, int& ke) { kb = 0; ke = p.N; }
     struct ARaw { float4 g, y; };
     typedef float4 BRaw;
+    // branch-free loaders (see Conv1FwdOp): clamped addresses, out-of-range pieces zeroed in *_tx
     __device__ ARaw a_ld(const Params& p, int, int m, int n, bool& ok) const {   // A(m, n) = dy[m][n..n+3]
-        ARaw r; r.g = Z4; r.y = Z4;
+        ARaw r; r.y = Z4;
         ok = m < p.M && n < p.N;
-        if (!ok) return r;
-        r.g = *(const float4*)(p.dyraw + (size_t)m * p.lddy + n);
-        if (p.has_bn_out) r.y = *(const float4*)(p.y + (size_t)m * p.ldy + n);
+        const size_t mm = m < p.M ? m : p.M - 1;
+        const int nn = n < p.N ? n : p.N - 4;
+        r.g = *(const float4*)(p.dyraw + mm * p.lddy + nn);
+        if (p.has_bn_out) r.y = *(const float4*)(p.y + mm * p.ldy + nn);
         return r;
     }
     __device__ float4 a_tx(const Params& p, int, const ARaw& r, int, int n, bool ok) const {
-        if (!ok || !p.has_bn_out) return r.g;
+        if (!ok) return Z4;
+        if (!p.has_bn_out) return r.g;
         return make_float4(dc.dy(p, r.g.x, r.y.x, n), dc.dy(p, r.g.y, r.y.y, n + 1), dc.dy(p, r.g.z, r.y.z, n + 2), dc.dy(p, r.g.w, r.y.w, n + 3));
     }
     __device__ float4 b_ld(const Params& p, int, int k, int n, bool& ok) const {   // B(col k..k+3, n) = W[n][k..k+3]
         ok = n < p.N && k < p.K;
-        return ok ? *(const float4*)(p.w + (size_t)n * p.K + k) : Z4;
+        return *(const float4*)(p.w + (size_t)(n < p.N ? n : p.N - 1) * p.K + (k < p.K ? k : p.K - 4));
     }
-    __device__ float4 b_tx(const Params&, int, const float4& v, int, int, bool) const { return v; }
+    __device__ float4 b_tx(const Params&, int, const float4& v, int, int, bool ok) const { return ok ? v : Z4; }
     __device__ void epilogue(const Params& p, int m0_, int n0, int, const float* Cs, int tid, bool active) {
         constexpr int RG = 256 / TN;              // row groups
         const int c = tid % TN, rg = tid / TN, k = n0 + c;
@@ -773,16 +776,18 @@ struct Conv1BwdWOp {
     }
     struct ARaw { float4 g, y; };
     typedef float4 BRaw;
-    __device__ ARaw a_ld(const Params& p, int, int n, int m, bool& ok) const {   // A(row n..n+3, m) = dy[m][n..n+3]
-        ARaw r; r.g = Z4; r.y = Z4;
+    __device__ ARaw a_ld(const Params& p, int, int n, int m, bool& ok) const {   // A(row n..n+3, m) = dy[m][n..n+3]; branch-free (see Conv1FwdOp)
+        ARaw r; r.y = Z4;
         ok = m < me && n < p.N;
-        if (!ok) return r;
-        r.g = *(const float4*)(p.dyraw + (size_t)m * p.lddy + n);
-        if (p.has_bn_out) r.y = *(const float4*)(p.y + (size_t)m * p.ldy + n);
+        const size_t mm = m < me ? m : me - 1;        // (the K loop only runs when mb < me)
+        const int nn = n < p.N ? n : p.N - 4;
+        r.g = *(const float4*)(p.dyraw + mm * p.lddy + nn);
+        if (p.has_bn_out) r.y = *(const float4*)(p.y + mm * p.ldy + nn);
         return r;
     }
     __device__ float4 a_tx(const Params& p, int, const ARaw& r, int n, int, bool ok) const {
-        if (!ok || !p.has_bn_out) return r.g;
+        if (!ok) return Z4;
+        if (!p.has_bn_out) return r.g;
         const int i = n - n0r;
         return make_float4(dc.dy(p, r.g.x, r.y.x, i), dc.dy(p, r.g.y, r.y.y, i + 1), dc.dy(p, r.g.z, r.y.z, i + 2), dc.dy(p, r.g.w, r.y.w, i + 3));
     }
@@ -792,8 +797,8 @@ struct Conv1BwdWOp {
     }
     __device__ float4 b_ld(const Params& p, int, int k, int m, bool& ok) const {   // B(col k..k+3, m) = a[m][k..k+3]
         ok = m < me && k < p.K;
+        if (!POOL) return *(const float4*)(p.x + (size_t)(m < me ? m : me - 1) * p.ldx + (k < p.K ? k : p.K - 4));
         if (!ok) return Z4;
-        if (!POOL) return *(const float4*)(p.x + (size_t)m * p.ldx + k);
         const int i = k - k0c;
         const int D2 = p.in.D >> 1, H2 = p.in.H >> 1, W2 = p.in.W >> 1, vox2 = D2 * H2 * W2;
         const int b = m / vox2, r = m % vox2, d = r / (H2 * W2), h = (r / W2) % H2, w = r % W2;
@@ -807,8 +812,9 @@ struct Conv1BwdWOp {
         }
         return make_float4(s.x * 0.125f, s.y * 0.125f, s.z * 0.125f, s.w * 0.125f);
     }
-    __device__ float4 b_tx(const Params&, int, const float4& v, int k, int, bool ok) const {
-        if (POOL || !ok) return v;
+    __device__ float4 b_tx(const Params& p, int, const float4& v, int k, int, bool ok) const {
+        if (POOL) return v;
+        if (!ok) return Z4;
         return act4(v, k - k0c);
     }
     __device__ void epilogue(const Params& p, int, int, int, const float* Cs, int tid, bool active) {

@@ -76,10 +76,12 @@ struct Conv1FwdOp {
     }
     typedef float4 ARaw;
     typedef float4 BRaw;
+    // Loaders are BRANCH-FREE: a predicated load compiles to an exec-masked block that re-reads its kernel arguments (s_load + wait) --
+    // one serial scalar round trip per piece and K-step.  Out-of-range pieces load from a clamped (valid) address and are zeroed in *_tx.
     __device__ float4 a_ld(const Params& p, int, int m, int k, bool& ok) const {
         ok = m < p.M && k < p.K;
+        if (!POOL) return *(const float4*)(p.x + (size_t)(m < p.M ? m : p.M - 1) * p.ldx + (k < p.K ? k : p.K - 4));
         if (!ok) return make_float4(0, 0, 0, 0);
-        if (!POOL) return *(const float4*)(p.x + (size_t)m * p.ldx + k);
         // transition: 8 source voxels per pooled row -- activation applied while loading (6 launches per step)
         const int base = srcbase[m - m0], HW = p.in.H * p.in.W, W = p.in.W;
         float4 s = make_float4(0, 0, 0, 0);
@@ -91,15 +93,17 @@ struct Conv1FwdOp {
         }
         return make_float4(s.x * 0.125f, s.y * 0.125f, s.z * 0.125f, s.w * 0.125f);
     }
-    __device__ float4 a_tx(const Params&, int, const float4& v, int, int k, bool ok) const {
-        if (POOL || !ok) return v;
-        return act4(v, k);
+    __device__ float4 a_tx(const Params& p, int, const float4& v, int, int k, bool ok) const {
+        if (POOL) return v;
+        const float4 r = act4(v, k < p.K ? k : p.K - 4);
+        const float z = ok ? 1.f : 0.f;
+        return make_float4(z * r.x, z * r.y, z * r.z, z * r.w);
     }
     __device__ float4 b_ld(const Params& p, int, int n, int k, bool& ok) const {
         ok = n < p.N && k < p.K;
-        return ok ? *(const float4*)(p.w + (size_t)n * p.K + k) : make_float4(0, 0, 0, 0);
+        return *(const float4*)(p.w + (size_t)(n < p.N ? n : p.N - 1) * p.K + (k < p.K ? k : p.K - 4));
     }
-    __device__ float4 b_tx(const Params&, int, const float4& v, int, int, bool) const { return v; }
+    __device__ float4 b_tx(const Params&, int, const float4& v, int, int, bool ok) const { return ok ? v : make_float4(0, 0, 0, 0); }
     __device__ void epilogue(const Params& p, int m0_, int n0, int z, const float* Cs, int tid, bool active) {
         if (!active) return;
         if (KSPLIT) {        // publish the partial tile; the last-arriving workgroup of the tile sums them (fixed order)
