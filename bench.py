@@ -60,7 +60,7 @@ def _stat_reps(M):                 # dn_net.hip make_plan: statistic-accumulator
 def _conv3_nsplit(M, ng, gd):      # dn_net.hip conv3_nsplit (scratch assumed large enough)
     if os.environ.get("MMS_CONV3_SMALL", "") != "0" and 16 + 2 * (gd[1] * gd[2] + gd[2] + 1) <= 120:
         return 1                   # dn_ops.h mms_conv3_small_jn: the all-tap 16-row kernels of dn_c3s.hip, no tap split
-    target = int(os.environ.get("MMS_SPLIT_WGS", "0")) or (256 if ng > 1 else 864)
+    target = int(os.environ.get("MMS_SPLIT_WGS", "0")) or 256
     tiles = ((M + 31) // 32) * ng
     if tiles >= 256 and tiles >= target:
         return 1

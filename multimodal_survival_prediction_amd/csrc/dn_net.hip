@@ -268,10 +268,11 @@ extern "C" int mms_dn121_init_sync(void* ws, int B, int D, int H, int W, const v
 // Tap split of the 3x3x3 convolutions (forward and backward-data): a launch should put about `target` workgroups on the
 // 256 CUs.  One model's block with M <= 1024 rows has <= 32 row tiles, so its 27 taps are spread over workgroups and
 // summed by a reduce kernel; a fold group multiplies the tiles by ng and needs less (or no) splitting.
-static int split_target(int ng) {     // measured: 864 for one model (27-way split of a 32-tile block), 256 for fold groups
+static int split_target(int) {        // 256 workgroups.  (Round 1 used 864 for a single model: its blocks 2-4 took the 27-way split; they now run on the
+                                      // small-grid kernels, and block 1 of ONE model is faster unsplit on the multi-tap kernel: 890 -> 934 patients/s)
     const char* e = getenv("MMS_SPLIT_WGS");      // tuning / test override, read at launch (i.e. graph-capture) time
     const int v = e ? atoi(e) : 0;
-    return v > 0 ? v : (ng > 1 ? 256 : 864);
+    return v > 0 ? v : 256;
 }
 static int conv3_nsplit(int M, int ng, long cap_rows, const Dims3& g) {
     if (mms_conv3_small_jn(M, ng, g)) return 1;       // small grids: the all-tap kernels of dn_c3s.hip (no tap split, no reduce launch)

@@ -794,11 +794,11 @@ class SurvivalEngine:
     def reset_epoch_stats(self):
         self.acc.zero_()
 
-    def epoch_stats(self):
-        """-> dict(sum_loss, n_usable, sum_entropy, n_batches) (one device->host sync).  Also the place where the sticky time-out
-        word of the block-4 persistent kernel (csrc/dn_b4.hip) is checked: a cluster whose workgroups never became co-resident
-        (more than ~256 persistent workgroups in flight at once) leaves garbage and must not pass silently."""
-        a = self.acc.tolist()
+    def check_b4(self):
+        """The sticky time-out word of the block-4 persistent kernels (csrc/dn_b4.hip): a cluster whose workgroups never became
+        co-resident (more persistent workgroups in flight than the chip holds) leaves garbage behind and must not pass silently --
+        neither in training (epoch_stats) nor in validation / inference (validate_*, validate_lockstep, evaluate_model.py).  One
+        device->host read per plan; the word is cleared before raising so that the workspace stays usable."""
         for P in self.plans.values():
             if getattr(P, "has_enc", False) and not P.fallback:
                 if getattr(P, "b4_err", None) is None:
@@ -807,8 +807,14 @@ class SurvivalEngine:
                     _lib.check(self.lib.mms_dn121_region(P.B, D, H, W, b"b4_err", 0, ctypes.byref(off), ctypes.byref(nb)), "mms_dn121_region")
                     P.b4_err = P.ws[off.value:off.value + 4].view(torch.int32)
                 if int(P.b4_err.item()) != 0:
+                    P.b4_err.zero_()
                     raise RuntimeError("mmsurv: a hand-off of the block-4 persistent kernel timed out (too many persistent launches in "
-                                       "flight at once?); results of this epoch are invalid -- rerun with MMS_PERSIST_B4=0")
+                                       "flight at once?); the results since the last check are invalid -- rerun with MMS_PERSIST_B4=0")
+
+    def epoch_stats(self):
+        """-> dict(sum_loss, n_usable, sum_entropy, n_batches) (one device->host sync); checks the block-4 time-out word (check_b4)."""
+        a = self.acc.tolist()
+        self.check_b4()
         return dict(sum_loss=a[0], n_usable=a[1], sum_entropy=a[2], n_batches=a[3])
 
 

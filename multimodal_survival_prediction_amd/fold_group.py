@@ -175,8 +175,19 @@ class FoldGroupEngine:
                 for b, b0 in zip(e.model.buffers(), s[6]):
                     b.copy_(b0)
 
+    def _guard_persistent_b4(self, GP):
+        """The block-4 persistent kernels (csrc/dn_b4.hip) hand data between 8 co-resident workgroups per model; a launch of them per
+        worker stream may be in flight at once.  If those workgroups could outnumber the CUs, take the per-layer path instead (read at
+        capture time by the drivers) rather than rely on the kernels' bounded spin + time-out word."""
+        import os
+        if GP.has_enc and "MMS_PERSIST_B4" not in os.environ:
+            cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+            if 8 * GP.ng * ops.max_worker_streams() > cus:
+                os.environ["MMS_PERSIST_B4"] = "0"
+
     def _graph(self, GP, key, body):
         if key not in GP.graphs:
+            self._guard_persistent_b4(GP)
             snap = self._snapshot(GP.eng)
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())

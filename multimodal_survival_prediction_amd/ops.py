@@ -232,3 +232,8 @@ def worker_streams(device, n):
     while len(lst) < n:
         lst.append(torch.cuda.Stream(device=device))
     return lst[:n]
+
+
+def max_worker_streams():
+    """How many worker streams this process has created (over all devices: an upper bound on concurrently stepping sub-groups)."""
+    return max([len(v) for v in _WORKER_STREAMS.values()] or [1])

@@ -114,6 +114,7 @@ def validate_final(model, loader, device):
         nb += 1
         hs.append(hz); ts.append(label[:, 0]); es.append(label[:, 1])
     c = losses.calculate_cindex(torch.cat(hs), torch.cat(es), torch.cat(ts)) if hs else 0.5
+    eng.check_b4()
     return (total / nb if nb > 0 else 0), c
 
 
@@ -150,6 +151,7 @@ def validate_partial(model, loader, device):
                 nb += 1
                 hs.append(h); ts.append(t); es.append(e)
     c = losses.calculate_cindex(torch.cat(hs), torch.cat(es), torch.cat(ts)) if hs else 0.5
+    eng.check_b4()
     return (total / nb if nb > 0 else 0), c
 
 
@@ -190,6 +192,7 @@ def validate_simple(model, loader, device):
     if not hs:
         return 0.0, 0.5
     c = losses.ConcordanceIndex()(torch.cat(hs), torch.cat(es), torch.cat(ts)).item()
+    eng.check_b4()
     return (total / nb if nb > 0 else 0.0), c
 
 
@@ -231,6 +234,7 @@ def validate_flexible(model, loader, device):
     if not hs:
         return 0.0, 0.5
     c = losses.ConcordanceIndex()(torch.cat(hs), torch.cat(es), torch.cat(ts)).item()
+    eng.check_b4()
     return (total / nb if nb > 0 else 0.0), c
 
 
@@ -427,6 +431,8 @@ def _validate_lockstep_named(group, loaders, style, members, concurrent=1):
 
     _run_subgroups(group, loaders, members, concurrent, advance)
     torch.cuda.synchronize()
+    for g in members:
+        group.engines[g].check_b4()          # the pass's single sync point: a timed-out block-4 hand-off must not yield a C-index
     out = []
     for g, ld in zip(members, loaders):
         a = group.engines[g].acc_eval.tolist()
@@ -508,6 +514,8 @@ def validate_lockstep(group, loaders, style, device, members=None, concurrent=1)
                     a["total"] += losses.neg_partial_log_likelihood(h, e, t).item(); a["nb"] += 1
                 a["hs"].append(h); a["ts"].append(t); a["es"].append(e)
     out = []
+    for g in members:
+        group.engines[g].check_b4()
     for g in members:
         a = acc[g]
         if not a["hs"]:

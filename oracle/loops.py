@@ -4,8 +4,8 @@ import torch
 from .losses import concordance_index_np, cox_loss, gate_entropy_loss, neg_partial_log_likelihood
 
 
-def train_epoch_final(model, loader, optimizer, device):
-    """final_multimodal.py:238-265: Cox on the whole batch, no label mask."""
+def train_epoch_final(model, loader, optimizer, device, on_batch=None):
+    """final_multimodal.py:238-265: Cox on the whole batch, no label mask.  (on_batch: test hook, called with each batch's loss.)"""
     model.train()
     total, nb = 0.0, 0
     for batch in loader:
@@ -20,6 +20,8 @@ def train_epoch_final(model, loader, optimizer, device):
         optimizer.step()
         total += loss.item()
         nb += 1
+        if on_batch is not None:
+            on_batch(loss.item())
     return total / nb if nb > 0 else 0
 
 
@@ -40,8 +42,8 @@ def validate_final(model, loader, device, tie_credit=0.5):
     return (total / nb if nb > 0 else 0), concordance_index_np(hs, es, ts, tie_credit=tie_credit)
 
 
-def train_epoch_partial(model, loader, optimizer, device, gate_entropy_weight=0.01):
-    """partial_modality_training.py:382-435."""
+def train_epoch_partial(model, loader, optimizer, device, gate_entropy_weight=0.01, on_batch=None):
+    """partial_modality_training.py:382-435.  (on_batch: test hook, called with each batch's (Cox, entropy) losses.)"""
     model.train()
     tot_cox, tot_ent, n_surv, nb = 0.0, 0.0, 0, 0
     for batch in loader:
@@ -64,11 +66,13 @@ def train_epoch_partial(model, loader, optimizer, device, gate_entropy_weight=0.
         torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
         optimizer.step()
         nb += 1
+        if on_batch is not None:
+            on_batch(float(c_loss.item()), e_loss.item())
     return (tot_cox / n_surv if n_surv > 0 else 0), (tot_ent / nb if nb > 0 else 0)
 
 
-def train_epoch_simple(model, loader, optimizer, device):
-    """simple_fusion.py:242-279 (both `continue`s kept, the second one after the forward)."""
+def train_epoch_simple(model, loader, optimizer, device, on_batch=None):
+    """simple_fusion.py:242-279 (both `continue`s kept, the second one after the forward).  (on_batch: test hook, each stepped batch's loss.)"""
     model.train()
     total, nb = 0.0, 0
     for batch in loader:
@@ -88,6 +92,8 @@ def train_epoch_simple(model, loader, optimizer, device):
         optimizer.step()
         total += loss.item()
         nb += 1
+        if on_batch is not None:
+            on_batch(loss.item())
     return total / nb if nb > 0 else 0.0
 
 

@@ -80,6 +80,7 @@ def predict(checkpoint, kind, fold, n_folds, batch_size, out_csv):
         else:
             hz, _ = eng.forward_eval(None, rna)
         risks.append(hz.clone().cpu())
+    eng.check_b4()                                     # a timed-out block-4 hand-off must not end up in the predictions file
     lab = cohort["label"].cpu().numpy()[idx]
     ids = cohort.get("patient_id")
     df = pd.DataFrame({"patient_id": [ids[i] for i in idx] if ids is not None else [f"SYN-{i:04d}" for i in idx],

@@ -19,6 +19,12 @@ def env_float(name, default):
     return float(os.environ.get(name, default))
 
 
+def env_dims(default=(64, 64, 32)):
+    """MMS_VOLUME="D,H,W": CT volume size of the synthetic cohort (default: the reference's target_size 64,64,32)."""
+    v = os.environ.get("MMS_VOLUME")
+    return tuple(int(x) for x in v.split(",")) if v else tuple(default)
+
+
 def setup_device():
     from multimodal_survival_prediction_amd import distributed as D
     world, rank, local = D.init()
@@ -76,7 +82,7 @@ def cv_lockstep(style, models, loaders, group_kw, num_epochs, patience, make_sch
     opts = [FusedOptimizer(m, lr=group_kw.get("lr", 1e-4), weight_decay=group_kw.get("weight_decay", 1e-4)) for m in models]
     scheds = [make_scheduler(o) for o in opts]
     takes_metric = [len(inspect.signature(s.step).parameters) > 0 for s in scheds]
-    st = [dict(best=0.0, best_epoch=0, bad=0, done=False, t=0.0, n=0) for _ in models]
+    st = [dict(best=0.0, best_epoch=0, bad=0, done=False, t=0.0, n=0, epochs=0) for _ in models]
     for epoch in range(1, num_epochs + 1):
         active = [g for g in range(len(models)) if not st[g]["done"]]
         if not active:
@@ -91,6 +97,7 @@ def cv_lockstep(style, models, loaders, group_kw, num_epochs, patience, make_sch
         for g, trg, (val_loss, c) in zip(active, tr, va):
             s = st[g]
             s["t"] += dt; s["n"] += n_ep                       # the group's aggregate rate while this fold was active
+            s["epochs"] = epoch
             scheds[g].step(c) if takes_metric[g] else scheds[g].step()
             if c > s["best"]:
                 s["best"], s["best_epoch"], s["bad"] = c, epoch, 0
@@ -102,4 +109,5 @@ def cv_lockstep(style, models, loaders, group_kw, num_epochs, patience, make_sch
             if epoch % log_every == 0 or epoch == 1:
                 print(f"[rank {rank}] fold {fold_names[g]} epoch {epoch:3d}: train={trg} val_loss={val_loss:.4f} "
                       f"C-index={c:.4f} best={s['best']:.4f}", flush=True)
-    return [dict(best_c_index=s["best"], best_epoch=s["best_epoch"], patients_per_sec=s["n"] / max(s["t"], 1e-9)) for s in st]
+    return [dict(best_c_index=s["best"], best_epoch=s["best_epoch"], epochs_run=s["epochs"], patients_per_sec=s["n"] / max(s["t"], 1e-9))
+            for s in st]

@@ -15,7 +15,7 @@ import time
 import numpy as np
 import torch
 
-from _common import cv_lockstep, env_float, env_int, load_or_make_cohort, lockstep_enabled, save_json, setup_device
+from _common import cv_lockstep, env_dims, env_float, env_int, load_or_make_cohort, lockstep_enabled, save_json, setup_device
 
 from multimodal_survival_prediction_amd import data, distributed as D
 from multimodal_survival_prediction_amd.losses import calculate_cindex, cox_loss, gate_entropy_loss  # noqa: F401
@@ -38,7 +38,7 @@ def main():
     torch.manual_seed(SEED)
     np.random.seed(SEED)
     world, rank, device = setup_device()
-    cohort = load_or_make_cohort(device, n=N_PATIENTS, seed=608, complete=False)      # data/processed/* in the cwd, else synthetic
+    cohort = load_or_make_cohort(device, n=N_PATIENTS, dims=env_dims(), seed=608, complete=False)      # data/processed/* in the cwd, else synthetic
     has_surv = cohort["has_survival"].cpu().numpy()
     survival = np.nonzero(has_surv)[0]
     non_survival = np.nonzero(~has_surv)[0]
@@ -56,7 +56,8 @@ def main():
                           NUM_EPOCHS, PATIENCE, lambda o: ReduceLROnPlateau(o, mode="max", factor=0.5, patience=5),
                           lambda name: f"models/partial_modality/fold_{name}_best.pth", device, rank, [f + 1 for f in my_folds])
         local = [{"fold": f + 1, "best_c_index": r["best_c_index"], "train_size": int(len(tr_all)),
-                  "train_survival_size": int(len(folds[f][0])), "val_size": int(len(va_s)), "patients_per_sec": r["patients_per_sec"]}
+                  "train_survival_size": int(len(folds[f][0])), "val_size": int(len(va_s)), "patients_per_sec": r["patients_per_sec"],
+                  "epochs_run": r["epochs_run"]}
                  for f, r, (tr_all, va_s) in zip(my_folds, res, splits)]
         my_folds = []
     for fold in my_folds:
@@ -69,8 +70,9 @@ def main():
         optimizer = FusedOptimizer(model, lr=LEARNING_RATE, weight_decay=1e-4, adamw=False,
                                    gate_entropy_weight=GATE_ENTROPY_WEIGHT)
         scheduler = ReduceLROnPlateau(optimizer, mode="max", factor=0.5, patience=5)
-        best_c_index, patience_counter, t_train, n_train = 0, 0, 0.0, 0
+        best_c_index, patience_counter, t_train, n_train, epochs_run = 0, 0, 0.0, 0, 0
         for epoch in range(NUM_EPOCHS):
+            epochs_run = epoch + 1
             torch.cuda.synchronize(); t0 = time.perf_counter()
             train_cox, train_entropy = train_epoch(model, train_loader, optimizer, device)
             torch.cuda.synchronize(); t_train += time.perf_counter() - t0; n_train += len(train_all)
@@ -88,7 +90,7 @@ def main():
                     break
         local.append({"fold": fold + 1, "best_c_index": best_c_index, "train_size": int(len(train_all)),
                       "train_survival_size": int(len(tr)), "val_size": int(len(val_survival)),
-                      "patients_per_sec": n_train / t_train})
+                      "patients_per_sec": n_train / t_train, "epochs_run": epochs_run})
     cv_results = D.gather_fold_results(local, world)
     if rank == 0:
         c = [r["best_c_index"] for r in cv_results]

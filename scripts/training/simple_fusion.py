@@ -14,7 +14,7 @@ import time
 import numpy as np
 import torch
 
-from _common import cv_lockstep, env_float, env_int, lockstep_enabled, save_json, setup_device
+from _common import cv_lockstep, env_dims, env_float, env_int, lockstep_enabled, save_json, setup_device
 
 from multimodal_survival_prediction_amd import data, distributed as D
 from multimodal_survival_prediction_amd.losses import ConcordanceIndex, neg_partial_log_likelihood  # noqa: F401
@@ -35,7 +35,7 @@ N_PATIENTS = env_int("MMS_PATIENTS", 88)
 def main():
     world, rank, device = setup_device()
     os.makedirs(RESULTS_DIR, exist_ok=True)
-    cohort = data.cohort_to(data.make_cohort(n=N_PATIENTS, seed=88, complete=True), device)
+    cohort = data.cohort_to(data.make_cohort(n=N_PATIENTS, dims=env_dims(), seed=88, complete=True), device)
     folds = data.kfold_indices(cohort["n"], N_FOLDS, seed=42)
     local = []
     my_folds = list(D.folds_of_rank(N_FOLDS, world, rank))
