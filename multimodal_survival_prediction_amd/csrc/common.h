@@ -59,11 +59,21 @@ __device__ __forceinline__ bool tile_last_arriver(unsigned* counter, unsigned ns
     return s_last != 0u;
 }
 
+// Two accumulators of one channel with their replicas: BOTH base loads are issued before the replica loop, so the pair costs one
+// memory round trip (two rep_sum calls in a row cost two: the first call's loop block separates the loads and its result is consumed
+// before the second load is issued).
+__device__ __forceinline__ void rep_sum2(const double* a, const double* b, int c, int nrep, int stride, double& sa, double& sb) {
+    sa = a[c]; sb = b[c];
+    for (int r = 1; r < nrep; ++r) { sa += a[c + (size_t)r * stride]; sb += b[c + (size_t)r * stride]; }
+}
+
 // mean / rstd of channel c.  The batch variance is the biased one (what torch normalises with).
 __device__ __forceinline__ void bn_mean_rstd(const BnSrc& b, int c, float& mean, float& rstd) {
     if (b.train) {
-        double m = rep_sum(b.sum, c, b.nrep, b.rep_stride) * (double)b.inv_count;
-        double v = rep_sum(b.sumsq, c, b.nrep, b.rep_stride) * (double)b.inv_count - m * m;
+        double s, q;
+        rep_sum2(b.sum, b.sumsq, c, b.nrep, b.rep_stride, s, q);
+        const double m = s * (double)b.inv_count;
+        double v = q * (double)b.inv_count - m * m;
         v = v > 0.0 ? v : 0.0;
         mean = (float)m;
         rstd = 1.0f / sqrtf((float)v + b.eps);      // the fp64 part is the cancellation-prone E[x^2]-E[x]^2 only
@@ -71,6 +81,27 @@ __device__ __forceinline__ void bn_mean_rstd(const BnSrc& b, int c, float& mean,
         mean = b.rmean[c];
         rstd = 1.0f / sqrtf(b.rvar[c] + b.eps);
     }
+}
+
+// (mean, rstd, gamma, beta) of channel c with gamma / beta requested BEFORE the statistics' replica loop: one round trip.
+__device__ __forceinline__ void bn_consts1(const BnSrc& b, int c, float& mean, float& rstd, float& gamma, float& beta) {
+    gamma = b.gamma[c]; beta = b.beta[c];
+    bn_mean_rstd(b, c, mean, rstd);
+}
+
+// Everything a BatchNorm-backward consumer needs for channel c of a training-mode BatchNorm -- (mean, rstd, gamma) and the two backward
+// sums (s1 = sum dy, s2 = sum dy * xhat) -- with all five base loads issued together (one round trip instead of five).
+__device__ __forceinline__ void bn_bwd_consts(const BnSrc& b, const BnBwd& bb, int c, float& mean, float& rstd, float& gamma, double& t1, double& t2) {
+    double s = b.sum[c], q = b.sumsq[c];
+    t1 = bb.s1[c]; t2 = bb.s2[c];
+    gamma = b.gamma[c];
+    for (int r = 1; r < b.nrep; ++r) { s += b.sum[c + (size_t)r * b.rep_stride]; q += b.sumsq[c + (size_t)r * b.rep_stride]; }
+    for (int r = 1; r < bb.nrep; ++r) { t1 += bb.s1[c + (size_t)r * bb.rep_stride]; t2 += bb.s2[c + (size_t)r * bb.rep_stride]; }
+    const double m = s * (double)b.inv_count;
+    double v = q * (double)b.inv_count - m * m;
+    v = v > 0.0 ? v : 0.0;
+    mean = (float)m;
+    rstd = 1.0f / sqrtf((float)v + b.eps);
 }
 
 // BatchNorm constants of the 4 consecutive channels c .. c+3 (c % 4 == 0) as (mean, gamma*rstd, beta).  A thread's four bn_mean_rstd
@@ -120,12 +151,19 @@ __device__ __forceinline__ void bn_consts_to_lds(const BnSrc& b, int C, int tid,
     double s[NJ], q[NJ];
     float g[NJ], be[NJ], rm[NJ], rv[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
+    for (int j = 0; j < NJ; ++j) {             // every base load first (no loop between them: one round trip) ...
         const int c = tid + 256 * j, cc = c < C ? c : C - 1;
-        if (b.train) { s[j] = rep_sum(b.sum, cc, b.nrep, b.rep_stride); q[j] = rep_sum(b.sumsq, cc, b.nrep, b.rep_stride); rm[j] = 0.f; rv[j] = 0.f; }
+        if (b.train) { s[j] = b.sum[cc]; q[j] = b.sumsq[cc]; rm[j] = 0.f; rv[j] = 0.f; }
         else { rm[j] = b.rmean[cc]; rv[j] = b.rvar[cc]; s[j] = 0; q[j] = 0; }
         g[j] = b.gamma[cc]; be[j] = b.beta[cc];
     }
+    if (b.train)                               // ... then the replicas, if any
+        for (int r = 1; r < b.nrep; ++r)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int c = tid + 256 * j, cc = c < C ? c : C - 1;
+                s[j] += b.sum[cc + (size_t)r * b.rep_stride]; q[j] += b.sumsq[cc + (size_t)r * b.rep_stride];
+            }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int c = tid + 256 * j;

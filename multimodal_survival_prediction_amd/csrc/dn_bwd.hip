@@ -47,9 +47,9 @@ struct Conv3BwdDataOp {
         ex = extra;
         p_nsplit = p.nsplit > 0 ? p.nsplit : 27;
         if (tid < 128) {
-            float mu, rstd;
-            bn_mean_rstd(p.bn, tid, mu, rstd);
-            extra[tid] = mu; extra[128 + tid] = rstd; extra[256 + tid] = p.bn.gamma[tid]; extra[384 + tid] = p.bn.beta[tid];
+            float mu, rstd, ga_, be_;
+            bn_consts1(p.bn, tid, mu, rstd, ga_, be_);
+            extra[tid] = mu; extra[128 + tid] = rstd; extra[256 + tid] = ga_; extra[384 + tid] = be_;
         }
         rz = make_rsrc(p.dz, (unsigned)(p.M - 1) * (unsigned)p.lddz * 4u + 128u);
         rw = make_rsrc(p.wpb, 128u * 27u * 32u * 4u);
@@ -552,11 +552,12 @@ struct DyConsts {   // per output channel n (LDS): dy = A*(dbn - B - yhat*C), yh
         for (int i = tid; i < cnt; i += 256) {
             const int n = n0 + i;
             if (n < p.N) {
-                float mu, rs;
-                bn_mean_rstd(p.bn_out, n, mu, rs);
-                A[i] = p.bn_out.gamma[n] * rs;
-                Bc[i] = (float)(rep_sum(p.bb_out.s1, n, p.bb_out.nrep, p.bb_out.rep_stride) * (double)p.bn_out.inv_count);
-                Cc[i] = (float)(rep_sum(p.bb_out.s2, n, p.bb_out.nrep, p.bb_out.rep_stride) * (double)p.bn_out.inv_count);
+                float mu, rs, ga;
+                double t1, t2;
+                bn_bwd_consts(p.bn_out, p.bb_out, n, mu, rs, ga, t1, t2);      // five loads, one round trip
+                A[i] = ga * rs;
+                Bc[i] = (float)(t1 * (double)p.bn_out.inv_count);
+                Cc[i] = (float)(t2 * (double)p.bn_out.inv_count);
                 mean[i] = mu; rstd[i] = rs;
             } else {
                 A[i] = Bc[i] = Cc[i] = mean[i] = rstd[i] = 0.f;
@@ -590,7 +591,7 @@ struct Conv1BwdDataOp {
         if (tid < TN) {
             const int k = n0 + tid;
             float mu = 0, rs = 0, ga = 0, be = 0;
-            if (k < p.K) { bn_mean_rstd(p.bn_in, k, mu, rs); ga = p.bn_in.gamma[k]; be = p.bn_in.beta[k]; }
+            if (k < p.K) bn_consts1(p.bn_in, k, mu, rs, ga, be);
             ein[tid] = mu; ein[TN + tid] = rs; ein[2 * TN + tid] = ga; ein[3 * TN + tid] = be;
         }
         if (POOL && tid < TM) {
@@ -757,7 +758,7 @@ struct Conv1BwdWOp {
         if (tid < 64) {
             const int k = k0c + tid;
             float mu = 0, rs = 0, ga = 0, be = 0;
-            if (k < p.K) { bn_mean_rstd(p.bn_in, k, mu, rs); ga = p.bn_in.gamma[k]; be = p.bn_in.beta[k]; }
+            if (k < p.K) bn_consts1(p.bn_in, k, mu, rs, ga, be);
             extra[320 + tid] = mu; extra[384 + tid] = ga * rs; extra[448 + tid] = be;
         }
         int mc = (p.M + p.msplit - 1) / p.msplit;
@@ -851,10 +852,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const Grp<BnBwdApplyP
     const int nc = p.C - c0 < 256 ? p.C - c0 : 256;          // channels of this chunk (multiple of 4)
     if (tid < nc) {
         const int c = c0 + tid;
-        float mu, rs;
-        bn_mean_rstd(p.bn, c, mu, rs);
-        const double t1 = rep_sum(p.bb.s1, c, p.bb.nrep, p.bb.rep_stride), t2 = rep_sum(p.bb.s2, c, p.bb.nrep, p.bb.rep_stride);
-        cm[0][tid] = mu; cm[1][tid] = p.bn.gamma[c] * rs;
+        float mu, rs, ga;
+        double t1, t2;
+        bn_bwd_consts(p.bn, p.bb, c, mu, rs, ga, t1, t2);                       // five loads, one round trip
+        cm[0][tid] = mu; cm[1][tid] = ga * rs;
         cm[2][tid] = (float)(t1 * (double)p.bn.inv_count);
         cm[3][tid] = rs * (float)(t2 * (double)p.bn.inv_count);
         if (blockIdx.x == 0 && p.dgamma) {
@@ -923,7 +924,7 @@ __global__ __launch_bounds__(256) void head_bwd_feat_kernel(const Grp<HeadBwdP> 
     const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
     const bool ok = c < p.C;
     float mu = 0.f, rs = 0.f, ga = 0.f, be = 0.f;
-    if (ok) { bn_mean_rstd(p.bn, c, mu, rs); ga = p.bn.gamma[c]; be = p.bn.beta[c]; }
+    if (ok) bn_consts1(p.bn, c, mu, rs, ga, be);
     const int M = p.B * p.V;
     const float invV = 1.f / (float)p.V;
     double s1 = 0, s2 = 0;
@@ -992,9 +993,9 @@ MMS_SINGLE(mms_head_bwd, HeadBwdP)
 __global__ __launch_bounds__(256) void head_bwd_sums_kernel(const HeadBwdP p) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= p.C) return;
-    float mu, rs;
-    bn_mean_rstd(p.bn, c, mu, rs);
-    const float ga = p.bn.gamma[c], be = p.bn.beta[c], invV = 1.f / (float)p.V;
+    float mu, rs, ga, be;
+    bn_consts1(p.bn, c, mu, rs, ga, be);
+    const float invV = 1.f / (float)p.V;
     double s1 = 0, s2 = 0;
     for (int b = 0; b < p.B; ++b) {
         float dp = 0;
@@ -1053,9 +1054,8 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const Grp<PoolBwdP> grp) 
     // addresses and selected afterwards (the duplicate candidate of an even coordinate is masked out).
     __shared__ double red[2][4][64];
     const int c = threadIdx.x & 63, vr = threadIdx.x >> 6;
-    float mu, rs;
-    bn_mean_rstd(p.bn, c, mu, rs);
-    const float ga = p.bn.gamma[c], be = p.bn.beta[c];
+    float mu, rs, ga, be;
+    bn_consts1(p.bn, c, mu, rs, ga, be);
     const int vox_in = p.in.D * p.in.H * p.in.W, Min = p.B * vox_in, vox_out = p.out.D * p.out.H * p.out.W;
     double s1 = 0, s2 = 0;
     for (int it = 0; it < 16; ++it) {
@@ -1129,9 +1129,8 @@ __global__ __launch_bounds__(256) void pool_bwd_brick_kernel(const Grp<PoolBwdP>
         cg[cand][c] = ok ? p.dslab[mo * p.ld + c] : 0.f;
         ca[cand][c] = ok ? p.argmax[mo * 64 + c] : (uint8_t)255;
     }
-    float mu, rs;
-    bn_mean_rstd(p.bn, c, mu, rs);
-    const float ga = p.bn.gamma[c], be = p.bn.beta[c];
+    float mu, rs, ga, be;
+    bn_consts1(p.bn, c, mu, rs, ga, be);
     __syncthreads();
     double s1 = 0, s2 = 0;
     for (int v = vr; v < 8 * WT; v += 4) {
@@ -1203,10 +1202,10 @@ struct Conv0BwdWOp {
         k0r = m0_;
         A = extra; Bc = extra + 64; Cc = extra + 128; mean = extra + 192; rstd = extra + 256;
         if (tid < 64) {
-            float mu, rs;
-            bn_mean_rstd(p.bn, tid, mu, rs);
-            A[tid] = p.bn.gamma[tid] * rs;
-            const double t1 = rep_sum(p.bb.s1, tid, p.bb.nrep, p.bb.rep_stride), t2 = rep_sum(p.bb.s2, tid, p.bb.nrep, p.bb.rep_stride);
+            float mu, rs, ga_;
+            double t1, t2;
+            bn_bwd_consts(p.bn, p.bb, tid, mu, rs, ga_, t1, t2);
+            A[tid] = ga_ * rs;
             Bc[tid] = (float)(t1 * (double)p.bn.inv_count);
             Cc[tid] = (float)(t2 * (double)p.bn.inv_count);
             mean[tid] = mu; rstd[tid] = rs;
@@ -1310,10 +1309,10 @@ __global__ __launch_bounds__(256) void conv0_bwd_weight_kernel(const Grp<Conv0Bw
     const Conv0BwdWP& p = grp.p[model];
     __syncthreads();                          // the previous segment is done with cst / xs / dys
     if (tid < 64) {
-        float mu, rs;
-        bn_mean_rstd(p.bn, tid, mu, rs);
-        cA[tid] = p.bn.gamma[tid] * rs;
-        const double t1 = rep_sum(p.bb.s1, tid, p.bb.nrep, p.bb.rep_stride), t2 = rep_sum(p.bb.s2, tid, p.bb.nrep, p.bb.rep_stride);
+        float mu, rs, ga_;
+        double t1, t2;
+        bn_bwd_consts(p.bn, p.bb, tid, mu, rs, ga_, t1, t2);
+        cA[tid] = ga_ * rs;
         cB[tid] = (float)(t1 * (double)p.bn.inv_count);
         cC[tid] = (float)(t2 * (double)p.bn.inv_count);
         cM[tid] = mu; cR[tid] = rs;

@@ -671,9 +671,9 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const Grp<PoolFwdP> grp) 
     // issued together from clamped (always valid) addresses and selected afterwards: branch-free, 27 loads in flight.
     __shared__ double red[2][4][64];
     const int c = threadIdx.x & 63, vr = threadIdx.x >> 6;
-    float mu, rstd;
-    bn_mean_rstd(p.bn, c, mu, rstd);
-    const float sc = p.bn.gamma[c] * rstd, be = p.bn.beta[c];
+    float mu, rstd, ga_, be;
+    bn_consts1(p.bn, c, mu, rstd, ga_, be);
+    const float sc = ga_ * rstd;
     const int vox_out = p.out.D * p.out.H * p.out.W, Mout = p.B * vox_out;
     double s = 0, q = 0;
     for (int it = 0; it < 4; ++it) {
@@ -737,9 +737,9 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const Grp<HeadFwdP> grp) 
     const int tid = threadIdx.x;
     for (int idx = tid; idx < p.B * p.C; idx += 256) {
         int b = idx / p.C, c = idx % p.C;
-        float mu, rstd;
-        bn_mean_rstd(p.bn, c, mu, rstd);
-        const float sc = p.bn.gamma[c] * rstd, be = p.bn.beta[c];
+        float mu, rstd, ga_, be;
+        bn_consts1(p.bn, c, mu, rstd, ga_, be);
+        const float sc = ga_ * rstd;
         float a = 0;
         for (int v = 0; v < p.V; ++v) a += fmaxf(bn_apply(p.slab[(size_t)(b * p.V + v) * p.ld + c], mu, sc, be), 0.f);
         a /= (float)p.V;

@@ -1,12 +1,13 @@
 """The three entry points the reference's users run (SURVEY.md section 8b "Entry points to keep"): scripts/training/final_multimodal.py,
-partial_modality_training.py and simple_fusion.py executed as `python <script>` from a scratch cwd on a small synthetic cohort
+partial_modality_training.py and simple_fusion.py executed as `python <script>` from a scratch cwd on a small synthetic cohort (42 patients: no
+training split ends in a batch of ONE patient, which BatchNorm1d rejects in the reference and here alike)
 (R/scripts/training/final_multimodal.py:316-417, partial_modality_training.py:496-607, simple_fusion.py:369-451):
   * results/<name>/cv_results.json carries the reference's keys (final_multimodal.py:403-417, simple_fusion.py:444-451);
   * the lock-step K-fold driver (scripts/training/_common.py::cv_lockstep: scheduler per fold, best-checkpoint save, early stopping,
     the group shrinking as folds stop) -- with patience 1 at least one fold stops before the last epoch;
   * the saved best checkpoints load into the ORACLE class (same state_dict keys as the reference's modules) and give the hazards
     the HIP model gives, eval mode, 1e-4;
-  * MMS_LOCKSTEP=0 (fold after fold, as the reference trains) reaches the same best C-index per fold."""
+  * MMS_LOCKSTEP=0 (fold after fold, as the reference trains) gives the same per-fold best C-index and stopping epoch (compared at lr = 0)."""
 import json
 import os
 import subprocess
@@ -18,7 +19,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ENV = dict(MMS_PATIENTS="40", MMS_EPOCHS="4", MMS_FOLDS="3", MMS_PATIENCE="1", MMS_BATCH_SIZE="4", MMS_VOLUME="32,32,32")
+ENV = dict(MMS_PATIENTS="42", MMS_EPOCHS="4", MMS_FOLDS="3", MMS_PATIENCE="1", MMS_BATCH_SIZE="4", MMS_VOLUME="32,32,32")
 
 
 def _run(script, cwd, **extra):
@@ -63,15 +64,21 @@ def test_partial_modality_training_entry_point(tmp_path):
     for k in (1, 2, 3):
         assert os.path.exists(tmp_path / "models" / "partial_modality" / f"fold_{k}_best.pth")
     _hazards_match(tmp_path / "models" / "partial_modality" / "fold_1_best.pth", "PartialModalityNet",
-                   dict(n=40, dims=(32, 32, 32), seed=608, complete=False),
+                   dict(n=42, dims=(32, 32, 32), seed=608, complete=False),
                    lambda m, c, d: m(c["image"].to(d), c["rnaseq"].to(d), c["clinical"].to(d), c["mask"].to(d))[0])
-    # fold after fold (the reference's order): the same folds, the same trajectories -> the same best C-index per fold
-    seq_dir = tmp_path / "seq"
-    seq_dir.mkdir()
-    _run("partial_modality_training.py", seq_dir, MMS_LOCKSTEP="0")
-    seq = json.load(open(seq_dir / "results" / "partial_modality" / "cv_results.json"))["fold_results"]
-    for a, b in zip(folds, seq):
-        assert a["best_c_index"] == pytest.approx(b["best_c_index"], abs=1e-6) and a["epochs_run"] == b["epochs_run"], (folds, seq)
+    # Fold after fold (the reference's order, MMS_LOCKSTEP=0) against the lock-step group.  Compared at lr = 0: with the scripts' lr the
+    # two runs' weights part ways at the 1e-3 level within a few Adam steps (lr * sign(g) on gradient entries that are rounding noise,
+    # tests/test_gpu_epoch_parity.py) and a C-index over 8 validation patients then differs by whole pairs; with frozen weights the
+    # driver logic under test -- per-fold loaders and shuffles, BatchNorm running statistics moving with every training forward, the
+    # scheduler, best-checkpoint rule, early stopping and the group shrinking -- must give the same per-fold numbers in both orders.
+    runs = []
+    for mode in ("1", "0"):
+        d = tmp_path / ("lr0_lockstep" + mode)
+        d.mkdir()
+        _run("partial_modality_training.py", d, MMS_LOCKSTEP=mode, MMS_LR="0")
+        runs.append(json.load(open(d / "results" / "partial_modality" / "cv_results.json"))["fold_results"])
+    for a, b in zip(*runs):
+        assert a["best_c_index"] == pytest.approx(b["best_c_index"], abs=1e-6) and a["epochs_run"] == b["epochs_run"], runs
 
 
 def test_final_multimodal_entry_point(tmp_path):
@@ -81,7 +88,7 @@ def test_final_multimodal_entry_point(tmp_path):
     assert set(res["hyperparameters"]) >= {"batch_size", "learning_rate", "epochs", "n_folds"}
     assert [r["fold"] for r in res["fold_results"]] == [1, 2, 3]
     assert all(0.0 <= r["best_c_index"] <= 1.0 for r in res["fold_results"])
-    _hazards_match(tmp_path / "models" / "final" / "fold_2_best.pth", "MultiModalSurvivalNet", dict(n=40, dims=(32, 32, 32), seed=608, complete=True),
+    _hazards_match(tmp_path / "models" / "final" / "fold_2_best.pth", "MultiModalSurvivalNet", dict(n=42, dims=(32, 32, 32), seed=608, complete=True),
                    lambda m, c, d: m(c["image"].to(d), c["rnaseq"].to(d), c["clinical"].to(d)))
 
 
@@ -92,5 +99,5 @@ def test_simple_fusion_entry_point(tmp_path):
     assert res["n_folds"] == 3 and res["num_epochs"] == 4
     for r in res["fold_results"]:
         assert {"fold", "best_c_index", "best_epoch", "train_size", "val_size"} <= set(r) and 1 <= r["best_epoch"] <= 4
-    _hazards_match(tmp_path / "results" / "simple_fusion" / "best_model_fold1.pth", "SimpleFusionModel", dict(n=40, dims=(32, 32, 32), seed=88, complete=True),
+    _hazards_match(tmp_path / "results" / "simple_fusion" / "best_model_fold1.pth", "SimpleFusionModel", dict(n=42, dims=(32, 32, 32), seed=88, complete=True),
                    lambda m, c, d: m(c["image"].to(d), c["rnaseq"].to(d)))
