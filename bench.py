@@ -163,7 +163,7 @@ def roofline_block(B, dims, dev, group_sizes):
     t, f, n, _ = fam[dom]
     traffic = None      # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_conv2_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_conv2_traffic.json")) as fh:
             j = json.load(fh)
         if tuple(j.get("sub_groups", ())) == tuple(group_sizes):          # the committed passes ran on this launch configuration
             traffic = j[dom]["avg_hbm_bytes_per_launch"]
@@ -593,6 +593,7 @@ def run_config2(args, world, rank, dev):
         D.barrier()
         return
     stats = engines[0].epoch_stats()
+    sync_per_step = getattr(engines[0], "sync_collectives", 0) / max(1, args.steps + max(args.warmup, 3 * F * G)) if ddp and args.sync_bn else None
     if rank == 0:
         out = {
             "metric": "patients/sec per epoch (training: fwd + Cox + bwd + clip + Adam)",
@@ -603,7 +604,8 @@ def run_config2(args, world, rank, dev):
                                    "109 synthetic complete patients, 5-fold split, batch %d, Adam lr 1e-4 wd 1e-4, clip 1.0" % (dims + (B,)),
                        "global_batch": world * B,
                        "parallelism": (f"ddp x{world} (gradient all-reduce per step in {args.ddp_buckets} bucket(s) overlapped with backward, "
-                                       f"{'Sync' if args.sync_bn else 'local'} BN + {'global' if args.global_cox else 'local'} Cox risk set)" if ddp else
+                                       f"{'Sync' if args.sync_bn else 'local'} BN + {'global' if args.global_cox else 'local'} Cox risk set"
+                                       + (f"; {sync_per_step:.0f} statistic all-reduces per step = 2 per BatchNorm layer and pass, the data-dependence floor" if sync_per_step else "") + ")" if ddp else
                                        f"kfold-shard x{world} ranks x {F} concurrent groups x {G} lock-step fold models per GPU (one stream + step graph per group, no collective)"),
                        "concurrent_folds": F, "fold_group": G, "fold_models_in_flight": F * G,
                        "hip_graph": not args.no_graph, "mean_train_loss": stats["sum_loss"] / max(stats["n_batches"], 1)},

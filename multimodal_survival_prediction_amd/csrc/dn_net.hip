@@ -175,6 +175,16 @@ extern "C" int mms_head_bwd_apply(const HeadBwdP*, hipStream_t);
 extern "C" int mms_pool_bwd_group(const PoolBwdP*, int, hipStream_t);
 extern "C" int mms_conv0_bwd_weight_group(const Conv0BwdWP*, int, hipStream_t);
 
+// Width of class_layers.out (MONAI DenseNet121 `out_channels`): 128 in the three hot-path models (final_multimodal.py:66-71), a free
+// constructor argument (img_feature_dim) in simple_fusion.py:163 / flexible_multimodal.py.  A per-thread launch attribute rather than a
+// parameter of the seven driver entry points: set it (mms_dn121_out_features) before the driver calls it applies to; default 128.
+static thread_local int tl_out_features = 128;
+extern "C" int mms_dn121_out_features(int n) {
+    if (n < 1 || n > 4096) return MMS_ERR_ARG;
+    tl_out_features = n;
+    return MMS_OK;
+}
+
 #define TRY(x) do { int rc_ = (x); if (rc_ != MMS_OK) { fprintf(stderr, "mmsurv: %s -> %d (dn_net.hip:%d)\n", #x, rc_, __LINE__); return rc_; } } while (0)
 
 extern "C" int mms_dn121_workspace_bytes(int B, int D, int H, int W, size_t* bytes) {
@@ -421,7 +431,7 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
         const Ctx& c = cx[g];
         hd[g] = HeadFwdP{at<float>(c.ws, P.slab[3]), CTOT[3], 1024, B, P.M[3] / B,
                          mk_bn(c.ws, P.st_slab[3], CTOT[3], c.prm, IDX.n5w, c.buf, IDX.bn5, P.M[3] * bw, train, P.R[3]),
-                         c.prm[IDX.outw], c.prm[IDX.outb], 128, at<float>(c.ws, P.pooled), c.out, ldo};
+                         c.prm[IDX.outw], c.prm[IDX.outb], tl_out_features, at<float>(c.ws, P.pooled), c.out, ldo};
     }
     TRY(mms_head_fwd_group(hd, ng, s));
     if (train) {
@@ -451,7 +461,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
         FOR_G {
             const Ctx& c = cx[g];
             hb[g] = HeadBwdP{c.dout, lddout, at<float>(c.ws, P.pooled), at<float>(c.ws, P.slab[3]), CTOT[3], 1024, B, P.M[3] / B,
-                             mk_bn(c.ws, P.st_slab[3], CTOT[3], c.prm, IDX.n5w, nullptr, 0, P.M[3] * bnw, 1, P.R[3]), c.prm[IDX.outw], 128,
+                             mk_bn(c.ws, P.st_slab[3], CTOT[3], c.prm, IDX.n5w, nullptr, 0, P.M[3] * bnw, 1, P.R[3]), c.prm[IDX.outw], tl_out_features,
                              c.grd[IDX.outw], c.grd[IDX.outb], c.grd[IDX.n5w], c.grd[IDX.n5b], at<float>(c.ws, P.dslab[3]), CTOT[3]};
         }
         if (sync) {     // norm5's backward sums must span all ranks: sums kernel | all-reduce | apply kernel

@@ -79,8 +79,8 @@ class DenseNet121(nn.Module):
         self.features, c = _build_features()
         self.class_layers = _holder(relu=nn.ReLU(inplace=True), pool=nn.AdaptiveAvgPool3d(1), flatten=nn.Flatten(1),
                                     out=nn.Linear(c, out_channels))
-        if out_channels != 128:
-            raise ValueError("out_channels must be 128 (kernel head width)")
+        if not 1 <= out_channels <= 4096 or out_channels % 4:
+            raise ValueError("out_channels must be a multiple of 4 in [4, 4096] (16-byte aligned feature columns)")
         for m in self.modules():   # MONAI's init
             if isinstance(m, nn.Conv3d):
                 nn.init.kaiming_normal_(m.weight)

@@ -64,24 +64,25 @@ def head_program(model):
             _Lin(f[4], ("f1", 0), ("f2", 0), True, pro_bn=f[1], pro_drop=f[3]),
             _Lin(f[7], ("f2", 0), ("hz", 0), False, pro_drop=f[6]),
         ]
-        rd = r[8].out_features                      # rna_feature_dim (simple_fusion.py:163); the encoder's 128 columns follow
-        bufs = dict(rna=r[0].in_features, r1=1024, r2=512, feats=rd + 128, f1=256, f2=128, hz=1)
-        return dict(kind=kind, width=rd + 128, ct_cols=rd, lins=lins, gate=None, bufs=bufs, encoder=model.image_encoder,
-                    n_pre=3)
+        rd = r[8].out_features                      # rna_feature_dim (simple_fusion.py:163); the encoder's img_feature_dim columns follow
+        idim = f[0].in_features - rd
+        bufs = dict(rna=r[0].in_features, r1=1024, r2=512, feats=rd + idim, f1=256, f2=128, hz=1)
+        return dict(kind=kind, width=rd + idim, ct_cols=rd, lins=lins, gate=None, bufs=bufs, encoder=model.image_encoder,
+                    n_pre=3, enc_width=idim)
     if kind == "FlexibleMultimodalModel":      # flexible_multimodal.py:157-256: simple-fusion heads, [image | rna] order, missing bias
         r, f = model.rna_encoder, model.fusion
         lins = [
             _Lin(r[0], ("rna", 0), ("r1", 0), False, need_dx=False),
             _Lin(r[4], ("r1", 0), ("r2", 0), False, pro_bn=r[1], pro_drop=r[3]),
-            _Lin(r[8], ("r2", 0), ("feats", 128), True, pro_bn=r[5], pro_drop=r[7]),
+            _Lin(r[8], ("r2", 0), ("feats", model.missing_image_bias.numel()), True, pro_bn=r[5], pro_drop=r[7]),
             _Lin(f[0], ("feats", 0), ("f1", 0), False),
             _Lin(f[4], ("f1", 0), ("f2", 0), True, pro_bn=f[1], pro_drop=f[3]),
             _Lin(f[7], ("f2", 0), ("hz", 0), False, pro_drop=f[6]),
         ]
-        rd = r[8].out_features
-        bufs = dict(rna=r[0].in_features, r1=1024, r2=512, feats=128 + rd, f1=256, f2=128, hz=1)
-        return dict(kind=kind, width=128 + rd, ct_cols=0, lins=lins, gate=None, bufs=bufs, encoder=model.image_encoder, n_pre=3,
-                    mix=dict(biases=[model.missing_image_bias, model.missing_rna_bias], segs=[(0, 128), (128, rd)]))
+        rd, idim = r[8].out_features, model.missing_image_bias.numel()
+        bufs = dict(rna=r[0].in_features, r1=1024, r2=512, feats=idim + rd, f1=256, f2=128, hz=1)
+        return dict(kind=kind, width=idim + rd, ct_cols=0, lins=lins, gate=None, bufs=bufs, encoder=model.image_encoder, n_pre=3,
+                    mix=dict(biases=[model.missing_image_bias, model.missing_rna_bias], segs=[(0, idim), (idim, rd)]), enc_width=idim)
     if kind == "RNASeqSurvivalModel":          # train_rnaseq_only.py:126-151: [Linear, BN1d, ReLU, Dropout] x n + Linear(., 1)
         mods = list(model.mlp)
         lin_idx = [i for i, m in enumerate(mods) if isinstance(m, nn.Linear)]
@@ -367,6 +368,7 @@ class SurvivalEngine:
             feats = P.buf["feats"]
             out = feats[:, prog["ct_cols"]:]
             fwd = lib.mms_fb_forward if P.fallback else lib.mms_dn121_forward
+            lib.mms_dn121_out_features(prog.get("enc_width", 128))      # per-thread driver attribute: class_layers.out's width
             _lib.check(fwd(P.ws.data_ptr(), B, D, H, W, P.ct.data_ptr(), P.ptab, P.btab, out.data_ptr(),
                            feats.stride(0), 1 if train else 0, st), "encoder forward")
         if P.big:
@@ -426,6 +428,7 @@ class SurvivalEngine:
         B, (D, H, W) = P.B, P.dims
         dfe = P.dbuf["feats"]
         dct = dfe[:, prog["ct_cols"]:]
+        lib.mms_dn121_out_features(prog.get("enc_width", 128))
         if stage is not None or hook is not None or P.bn_world > 1:
             hi, lo = stage if stage is not None else (3, 0)
             _lib.check(lib.mms_dn121_backward_stage(P.ws.data_ptr(), B, D, H, W, P.ct.data_ptr(), P.ptab, dct.data_ptr(), dfe.stride(0),
@@ -698,6 +701,7 @@ class SurvivalEngine:
 
             def hook(user, base, nrep, rstride, ncols, pstride, stream):
                 try:
+                    self.sync_collectives = getattr(self, "sync_collectives", 0) + 1      # (reported by bench.py --mode ddp --sync-bn)
                     t = ws64.as_strided((nrep, 2, ncols), (rstride, pstride, 1), (base - base0) // 8)
                     buf = t.contiguous()
                     D.allreduce_sum_(buf, world)
@@ -711,7 +715,14 @@ class SurvivalEngine:
         return P.sync_hook
 
     def _ddp_step_syncbn(self, P, world):
-        """Exact single-process semantics for a global batch of world*B patients (SURVEY.md section 8e ii-iii), eager launches:
+        """Exact single-process semantics for a global batch of world*B patients (SURVEY.md section 8e ii-iii), eager launches.
+        Collectives per step: ONE all-reduce per statistic-producing kernel (all replicas and both moments of its channels in one
+        message): 121 in the forward (conv0, pool0, conv1 + conv2 of the 58 dense layers, 3 transitions), 121 in the backward, + the
+        feature / label all-gathers and the gradient all-reduce -- 2 per BatchNorm layer and pass, the same count torch's SyncBatchNorm
+        issues.  It cannot be lower without changing the arithmetic: layer l's conv2 normalises with the statistics of ITS conv1's
+        output and layer l+1's conv1 with those of layer l's conv2 output, so the chain y1-stats(l) -> z-stats(l) -> y1-stats(l+1) is
+        strictly sequential (the slab's OLDER channels are reduced once, when they are produced, and reused by every later layer).
+        `self.sync_collectives` counts them; bench.py --mode ddp --sync-bn reports the count per step.
           * encoder: every BatchNorm3d statistic (forward sums, backward sums) is all-reduced between the kernel that produces it
             and the kernels that consume it (the drivers' hook);
           * heads (BatchNorm1d over the batch, gate, Cox risk set): replicated -- the encoder features and the small per-patient
@@ -732,6 +743,7 @@ class SurvivalEngine:
         cc = prog["ct_cols"]
         self.gflat.zero_(); self.sumsq.zero_()
         feats = P.buf["feats"]
+        lib.mms_dn121_out_features(prog.get("enc_width", 128))
         _lib.check(lib.mms_dn121_forward_sync(P.ws.data_ptr(), B, Dd, H, W, P.ct.data_ptr(), P.ptab, P.btab, feats[:, cc:].data_ptr(),
                                               feats.stride(0), world, hook, None, st), "mms_dn121_forward_sync")
 
@@ -739,7 +751,8 @@ class SurvivalEngine:
             tmp = torch.empty(world * src.shape[0], *src.shape[1:], device=self.device)
             D.all_gather_into(tmp.view(-1), src.contiguous().view(-1), world)
             dst.copy_(tmp.view(dst.shape))
-        gather(Pg.buf["feats"][:, cc:cc + 128], feats[:, cc:cc + 128])
+        ew = prog.get("enc_width", 128)
+        gather(Pg.buf["feats"][:, cc:cc + ew], feats[:, cc:cc + ew])
         for name in ("rna", "clin"):
             if name in P.buf:
                 gather(Pg.buf[name], P.buf[name])
@@ -751,7 +764,7 @@ class SurvivalEngine:
         self._forward(Pg, True)                                   # heads only (Pg.has_enc is False)
         _lib.check(lib.mms_cox_fwd_bwd(ctypes.byref(Pg.cox), st), "mms_cox_fwd_bwd")
         self._backward_heads(Pg)
-        P.dbuf["feats"][:, cc:cc + 128].copy_(Pg.dbuf["feats"][rank * B:(rank + 1) * B, cc:cc + 128])
+        P.dbuf["feats"][:, cc:cc + ew].copy_(Pg.dbuf["feats"][rank * B:(rank + 1) * B, cc:cc + ew])
         self._backward_encoder(P, hook=hook)
         if getattr(self, "_share", None) is None or self._share[0] != world:
             sh = torch.full_like(self.gflat, 1.0 / world)        # heads + BatchNorm3d parameters: global value on every rank

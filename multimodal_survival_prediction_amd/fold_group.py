@@ -117,6 +117,7 @@ class FoldGroupEngine:
         prog = GP.eng[0].prog
         if GP.has_enc:
             B, (D, H, W) = GP.B, GP.dims
+            lib.mms_dn121_out_features(prog.get("enc_width", 128))      # per-thread driver attribute: class_layers.out's width
             _lib.check(lib.mms_dn121_forward_group(ng, GP.ws, B, D, H, W, GP.x, GP.params, GP.buffers, GP.out, GP.ld,
                                                    1 if train else 0, st), "mms_dn121_forward_group")
         lf = GP.lin_fwd[train]
@@ -156,6 +157,7 @@ class FoldGroupEngine:
             _lib.check(lib.mms_linear_bwd_group(GP.lin_bwd[i], ng, st), "mms_linear_bwd_group")
         if GP.has_enc:
             B, (D, H, W) = GP.B, GP.dims
+            lib.mms_dn121_out_features(prog.get("enc_width", 128))
             _lib.check(lib.mms_dn121_backward_group(ng, GP.ws, B, D, H, W, GP.x, GP.params, GP.dout, GP.ld, GP.grads, st),
                        "mms_dn121_backward_group")
         ad = GP.adam[bool(skip_if_unusable)]

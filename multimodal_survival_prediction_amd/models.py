@@ -123,10 +123,9 @@ class PartialModalityNet(nn.Module):
 class SimpleFusionModel(nn.Module):
     def __init__(self, rna_dim=5005, img_feature_dim=128, rna_feature_dim=256):
         super().__init__()
-        if img_feature_dim != 128:       # rna_feature_dim is free (simple_fusion.py:163); the DenseNet121 driver's class_layers.out is 1024 -> 128
-            raise ValueError("img_feature_dim must be 128 (the reference default): the DenseNet121-3D driver writes a 128-wide feature")
-        if rna_feature_dim % 4 != 0 or rna_feature_dim <= 0:      # the heads read feature rows with 16-byte loads: the encoder's columns start at rna_feature_dim
-            raise ValueError("rna_feature_dim must be a positive multiple of 4 (16-byte aligned feature columns)")
+        # both widths are free constructor arguments (simple_fusion.py:163); the heads read feature rows with 16-byte loads
+        if rna_feature_dim % 4 != 0 or rna_feature_dim <= 0 or img_feature_dim % 4 != 0 or img_feature_dim <= 0:
+            raise ValueError("rna_feature_dim and img_feature_dim must be positive multiples of 4 (16-byte aligned feature columns)")
         self.rna_encoder = nn.Sequential(
             nn.Linear(rna_dim, 1024), nn.BatchNorm1d(1024), nn.ReLU(), nn.Dropout(0.3),
             nn.Linear(1024, 512), nn.BatchNorm1d(512), nn.ReLU(), nn.Dropout(0.3),
@@ -150,10 +149,9 @@ class FlexibleMultimodalModel(nn.Module):
 
     def __init__(self, rna_dim=5005, img_feature_dim=128, rna_feature_dim=256):
         super().__init__()
-        if img_feature_dim != 128:       # rna_feature_dim is free (simple_fusion.py:163); the DenseNet121 driver's class_layers.out is 1024 -> 128
-            raise ValueError("img_feature_dim must be 128 (the reference default): the DenseNet121-3D driver writes a 128-wide feature")
-        if rna_feature_dim % 4 != 0 or rna_feature_dim <= 0:      # the heads read feature rows with 16-byte loads: the encoder's columns start at rna_feature_dim
-            raise ValueError("rna_feature_dim must be a positive multiple of 4 (16-byte aligned feature columns)")
+        # both widths are free constructor arguments (simple_fusion.py:163); the heads read feature rows with 16-byte loads
+        if rna_feature_dim % 4 != 0 or rna_feature_dim <= 0 or img_feature_dim % 4 != 0 or img_feature_dim <= 0:
+            raise ValueError("rna_feature_dim and img_feature_dim must be positive multiples of 4 (16-byte aligned feature columns)")
         self.image_encoder = _ct_encoder(img_feature_dim)
         self.use_monai = USE_MONAI
         if USE_MONAI:

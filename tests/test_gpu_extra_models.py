@@ -130,14 +130,16 @@ def test_flexible_model_parity():
         assert_close(dict(net.named_parameters())[k].grad, dict(ref.named_parameters())[k].grad, 1e-4, k)
 
 
+@pytest.mark.parametrize("idim", [128, 64])
 @pytest.mark.parametrize("cls", ["SimpleFusionModel", "FlexibleMultimodalModel"])
-def test_rna_feature_dim_other_than_256(cls):
-    """simple_fusion.py:163 / flexible_multimodal.py: rna_feature_dim is a constructor argument; the heads' feature buffer is then
-    rna_feature_dim + 128 wide with the encoder's columns starting at rna_feature_dim (multiples of 4: 16-byte aligned columns)."""
+def test_rna_feature_dim_other_than_256(cls, idim):
+    """simple_fusion.py:163 / flexible_multimodal.py: rna_feature_dim AND img_feature_dim are constructor arguments; the heads' feature
+    buffer is rna_feature_dim + img_feature_dim wide (multiples of 4: 16-byte aligned columns), the DenseNet121 class_layers.out is
+    1024 -> img_feature_dim (driver attribute mms_dn121_out_features)."""
     from oracle import losses as OL
     from multimodal_survival_prediction_amd import losses as HL, models as HM
     B, dims, rna_dim = 4, (64, 64, 32), 96          # (the headline volume: on 32^3 block 4 has ONE voxel per sample and BatchNorm over 4 values is ill-conditioned)
-    ref, net = _pair(cls, 8, rna_dim=rna_dim, rna_feature_dim=64)
+    ref, net = _pair(cls, 8, rna_dim=rna_dim, rna_feature_dim=64, img_feature_dim=idim)
     ct = structured_volumes(B, dims, 5)
     rna = torch.tensor(np.random.default_rng(2).normal(0, 1, (B, rna_dim)).astype(np.float32))
     mask = torch.tensor([[1, 1], [0, 1], [1, 0], [1, 1]], dtype=torch.float32)

@@ -1,6 +1,6 @@
 """rocprofv3 counter/trace CSVs of `bench.py --roofline-only` -> per-op figures of the conv2 family (GPU box).
 usage: pmc_conv2.py trace  <kernel_trace.csv>                    -> live-vs-trace agreement JSON (durations)
-       pmc_conv2.py pmc    <FETCH counter csv> <WRITE counter csv> -> profiles/r02_pmc_conv2_traffic.json content
+       pmc_conv2.py pmc    <FETCH counter csv> <WRITE counter csv> -> profiles/r03_pmc_conv2_traffic.json content
 The leg launches, for every sub-group size G of the timed region, block 0..3, op in (fwd, bwd_data, bwd_weight): 3 warm-up + 20
 timed calls; a call is one main kernel (+ its tap-split reduce kernel where the driver splits)."""
 import csv, json, sys
@@ -13,8 +13,8 @@ B, DIMS = 4, (64, 64, 32)
 def kind(name):
     if "conv3_fwd_reduce" in name: return ("fwd", True)
     if "conv3_bwd_data_reduce" in name: return ("bwd_data", True)
-    if "conv3_fwd_mt" in name or "Conv3FwdOp" in name: return ("fwd", False)
-    if "Conv3BwdDataOp" in name: return ("bwd_data", False)
+    if "conv3_fwd_mt" in name or "Conv3FwdOp" in name or "conv3s_fwd_kernel" in name: return ("fwd", False)
+    if "Conv3BwdDataOp" in name or "conv3s_bwd_data_kernel" in name: return ("bwd_data", False)
     if "conv3_bwdw_mt" in name or "Conv3BwdWOp" in name: return ("bwd_weight", False)
     return None
 
