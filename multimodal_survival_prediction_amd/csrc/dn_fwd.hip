@@ -140,6 +140,10 @@ extern "C" int mms_conv1_fwd_group(const Conv1FwdP* pp, int ng, hipStream_t s) {
         if (q.M != p.M || q.N != p.N || q.K != p.K || q.ldx % 4 != 0 || q.pool != p.pool || q.in.D != p.in.D || q.in.H != p.in.H ||
             q.in.W != p.in.W) return MMS_ERR_ARG;
     }
+    if (mms_conv1_small_ok(p, ng)) {      // few rows: 16 x 16 tiles over the whole K range from LDS-resident panels (dn_c1s.hip)
+        for (int g = 0; g < ng; ++g) if (((uintptr_t)pp[g].x | (uintptr_t)pp[g].w) & 15) return MMS_ERR_ARG;
+        return mms_c1s_fwd(pp, ng, s);
+    }
     // big M: 64x64 tiles, no in-workgroup K split; small M: 32x32 tiles with the 4 waves splitting K
     const int big_ng = getenv("MMS_BIG_NG") ? atoi(getenv("MMS_BIG_NG")) : 1;      // 1: count the whole group's tiles (0: tests that need ng-independent arithmetic)
     const bool big = (long)p.M * p.N * (big_ng ? ng : 1) >= 256L * 64 * 64;

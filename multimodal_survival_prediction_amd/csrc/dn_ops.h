@@ -25,6 +25,19 @@ static inline int mms_conv3_small_jn(int M, int ng, const Dims3& g) {
     const long tiles = (long)((M + 15) / 16) * ng;
     return tiles > 128 ? 2 : 1;
 }
+// Small-launch 1x1x1 convolution forward (dn_c1s.hip): 16 x 16 output tiles, the whole K range per workgroup, both operand panels in LDS -- no
+// K split over workgroups, no ticket.  Taken for un-pooled launches with at most MMS_C1S_MAX_WGS tiles (default 640: dense block 3 of every
+// fold group, block 2 of a single model -- measured per launch at 3 models: block 3 (192 tiles) 13.5 -> 8.8 us, block 2 (1536 tiles: three
+// rounds of two workgroups per CU) 14.9 -> 20.7 us; one model: block 2 (512 tiles) 12.3 -> 8.9 us); MMS_CONV1_SMALL=0 disables it (A/B, the
+// K-split tests), =1 forces it whenever the shape allows.
+static inline bool mms_conv1_small_ok(const Conv1FwdP& p, int ng) {
+    const char* e = getenv("MMS_CONV1_SMALL");
+    if ((e && e[0] == '0') || p.pool || p.K % 32 != 0 || p.K > 1024 || p.K < 32 || p.ldx % 4 != 0) return false;
+    if (e && e[0] == '1') return true;
+    static const long maxwg = getenv("MMS_C1S_MAX_WGS") ? atol(getenv("MMS_C1S_MAX_WGS")) : 640;
+    return (long)((p.M + 15) / 16) * ((p.N + 15) / 16) * ng <= maxwg;
+}
+int mms_c1s_fwd(const Conv1FwdP* pp, int ng, hipStream_t s);
 int mms_c3s_fwd(const Conv3FwdP* pp, int ng, hipStream_t s);
 int mms_c3s_bwd_data(const Conv3BwdDataP* pp, int ng, hipStream_t s);
 

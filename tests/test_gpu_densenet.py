@@ -104,8 +104,8 @@ def test_densenet_grad_accumulates_and_requires_gpu():
         net(x)                      # CPU tensor: no fallback
 
 
-@pytest.mark.parametrize("B,dims", [(4, (64, 64, 32)), (4, (32, 64, 64))])
-def test_densenet_backward_flip_free(B, dims):
+@pytest.mark.parametrize("B,dims,signs", [(4, (64, 64, 32), "positive"), (4, (32, 64, 64), "positive"), (4, (64, 64, 32), "mixed")])
+def test_densenet_backward_flip_free(B, dims, signs):
     """STRICT network-level gradient parity.  Every BatchNorm bias is set to +4 with gains in [0.3, 0.6]: a BatchNorm output is then
     4 + gamma * xhat > 0 for |xhat| < 6.6, i.e. (training-mode statistics bound |xhat| by sqrt(rows)) no ReLU input comes near zero
     and no ReLU mask can flip between two fp32 implementations (the max-pool argmax is decided on well-separated stem activations).
@@ -114,9 +114,14 @@ def test_densenet_backward_flip_free(B, dims):
     test_densenet_train_forward_backward exist only because of the flips)."""
     ref, net = _make(3)
     with torch.no_grad():
-        for m in ref.modules():
+        for k, m in ref.named_modules():
             if isinstance(m, torch.nn.BatchNorm3d):
                 m.weight.uniform_(0.3, 0.6); m.bias.fill_(4.0)
+                if signs == "mixed" and not k.endswith("norm0"):
+                    # "mixed" (round 3): every second channel of every BatchNorm inside the dense blocks / transitions / norm5 sits at
+                    # -4 + gamma * xhat < 0 instead -- its ReLU is firmly OFF.  The network-level backward is then exercised on BOTH
+                    # sides of every ReLU mask (masked channels must contribute exactly nothing), still without a single flip.
+                    m.bias[1::2] = -4.0
     net.load_state_dict(ref.state_dict())
     x = structured_volumes(B, dims, 11)
     dout = torch.randn(B, 128)

@@ -23,7 +23,9 @@ def _bn_ref(x, g, b, train, rm=None, rv=None):
                                            (4, (8, 8, 4), 480, 128, 512), (4, (2, 2, 1), 992, 128, 1024),
                                            (1, (4, 4, 2), 256, 128, 1024)])
 @pytest.mark.parametrize("train", [True, False])
-def test_conv1_fwd(ops, B, dims, K, N, ld, train):
+@pytest.mark.parametrize("small", ["0", "1"])      # MMS_CONV1_SMALL: tile-GEMM forms / the 16 x 16 whole-K kernel of dn_c1s.hip (round 3)
+def test_conv1_fwd(ops, B, dims, K, N, ld, train, small, monkeypatch):
+    monkeypatch.setenv("MMS_CONV1_SMALL", small)
     torch.manual_seed(0)
     M = B * dims[0] * dims[1] * dims[2]
     x = torch.randn(B, K, *dims) * 1.5 + 0.3
@@ -49,9 +51,11 @@ def test_conv1_fwd(ops, B, dims, K, N, ld, train):
 
 
 @pytest.mark.parametrize("M,K,ksplit", [(128, 640, 5), (16, 992, 8), (100, 288, 3), (128, 256, 2)])
-def test_conv1_fwd_ksplit(ops, M, K, ksplit):
+def test_conv1_fwd_ksplit(ops, M, K, ksplit, monkeypatch):
     """K loop split over workgroups + last-arriver fixup (no second launch): same y and statistics as the unsplit kernel;
-    repeated launches reuse the self-re-arming ticket counters."""
+    repeated launches reuse the self-re-arming ticket counters.  (MMS_CONV1_SMALL=0: the tile-GEMM forms under test; the same
+    shapes -- ragged rows, K not a multiple of 64 -- go through the small-launch kernel at the end.)"""
+    monkeypatch.setenv("MMS_CONV1_SMALL", "0")
     torch.manual_seed(3)
     N, ld = 128, 1024
     slab = torch.randn(M, ld, device=DEV) * 1.5 + 0.3
@@ -72,6 +76,12 @@ def test_conv1_fwd_ksplit(ops, M, K, ksplit):
         assert_close(s1, s0, 1e-6, "ksplit sum"); assert_close(q1, q0, 1e-6, "ksplit sumsq")
     a = torch.relu((slab[:, :K].double() - (s / M)) / torch.sqrt(q / M - (s / M) ** 2 + 1e-5) * g.double() + b.double())
     assert_close(y1, a @ w.double().t(), 1e-4, "ksplit y vs fp64 reference")
+    monkeypatch.setenv("MMS_CONV1_SMALL", "1")
+    y2 = torch.zeros(M, N, device=DEV); s2, q2 = stats(DEV, N)
+    ops.conv1_fwd(slab, K, w, y2, bn, M, s2, q2)
+    torch.cuda.synchronize()
+    assert_close(y2, a @ w.double().t(), 1e-4, "small-launch kernel y vs fp64 reference")
+    assert_close(s2, s0, 1e-5, "small-launch sum"); assert_close(q2, q0, 1e-5, "small-launch sumsq")
 
 
 @pytest.mark.parametrize("B,dims,K", [(4, (16, 16, 8), 256), (2, (8, 8, 4), 512), (4, (4, 4, 2), 1024)])

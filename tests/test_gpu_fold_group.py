@@ -41,7 +41,7 @@ def test_group_step_equals_single_steps(cls, G, monkeypatch):
     # same tap split (27-way) for the single models and the group: identical per-model arithmetic, so the comparison is
     # tight; with the default, group-size dependent split the fp32 summation order differs and parity becomes statistical
     # (ReLU-mask flips, see test_gpu_densenet.py) -- covered by test_group_default_split_statistical below
-    monkeypatch.setenv("MMS_SPLIT_WGS", "1000000"); monkeypatch.setenv("MMS_CONV1_KSPLIT", "0"); monkeypatch.setenv("MMS_CONV3_MT", "0"); monkeypatch.setenv("MMS_BIG_NG", "0"); monkeypatch.setenv("MMS_MS3_ROWS", "512"); monkeypatch.setenv("MMS_CONV3W_MT", "0"); monkeypatch.setenv("MMS_MS1_DIV", "1")
+    monkeypatch.setenv("MMS_SPLIT_WGS", "1000000"); monkeypatch.setenv("MMS_CONV1_KSPLIT", "0"); monkeypatch.setenv("MMS_CONV1_SMALL", "0"); monkeypatch.setenv("MMS_CONV3_MT", "0"); monkeypatch.setenv("MMS_BIG_NG", "0"); monkeypatch.setenv("MMS_MS3_ROWS", "512"); monkeypatch.setenv("MMS_CONV3W_MT", "0"); monkeypatch.setenv("MMS_MS1_DIV", "1")
     from multimodal_survival_prediction_amd.engine import SurvivalEngine
     from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
     B, dims, rna_dim = 4, (64, 64, 32), 1024
@@ -160,7 +160,7 @@ def test_group_rejects_mismatched_shapes():
 
 def test_indexed_step_equals_batch_step(monkeypatch):
     """train_step_indexed (one gather launch from the device-resident cohort) == train_step on the same batches."""
-    monkeypatch.setenv("MMS_SPLIT_WGS", "1000000"); monkeypatch.setenv("MMS_CONV1_KSPLIT", "0"); monkeypatch.setenv("MMS_CONV3_MT", "0"); monkeypatch.setenv("MMS_BIG_NG", "0"); monkeypatch.setenv("MMS_MS3_ROWS", "512"); monkeypatch.setenv("MMS_CONV3W_MT", "0"); monkeypatch.setenv("MMS_MS1_DIV", "1")
+    monkeypatch.setenv("MMS_SPLIT_WGS", "1000000"); monkeypatch.setenv("MMS_CONV1_KSPLIT", "0"); monkeypatch.setenv("MMS_CONV1_SMALL", "0"); monkeypatch.setenv("MMS_CONV3_MT", "0"); monkeypatch.setenv("MMS_BIG_NG", "0"); monkeypatch.setenv("MMS_MS3_ROWS", "512"); monkeypatch.setenv("MMS_CONV3W_MT", "0"); monkeypatch.setenv("MMS_MS1_DIV", "1")
     from multimodal_survival_prediction_amd import data
     from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
     cls, G, B, dims, rna_dim = "PartialModalityNet", 2, 4, (32, 32, 32), 64
@@ -194,7 +194,7 @@ def test_indexed_step_equals_batch_step(monkeypatch):
 def test_lockstep_epoch_matches_sequential(style, monkeypatch):
     """train_epoch_lockstep / validate_lockstep == train_epoch_<style> / validate_<style> fold by fold (ragged fold sizes:
     the last batch positions run as sub-groups)."""
-    monkeypatch.setenv("MMS_SPLIT_WGS", "1000000"); monkeypatch.setenv("MMS_CONV1_KSPLIT", "0"); monkeypatch.setenv("MMS_CONV3_MT", "0"); monkeypatch.setenv("MMS_BIG_NG", "0"); monkeypatch.setenv("MMS_MS3_ROWS", "512"); monkeypatch.setenv("MMS_CONV3W_MT", "0"); monkeypatch.setenv("MMS_MS1_DIV", "1")
+    monkeypatch.setenv("MMS_SPLIT_WGS", "1000000"); monkeypatch.setenv("MMS_CONV1_KSPLIT", "0"); monkeypatch.setenv("MMS_CONV1_SMALL", "0"); monkeypatch.setenv("MMS_CONV3_MT", "0"); monkeypatch.setenv("MMS_BIG_NG", "0"); monkeypatch.setenv("MMS_MS3_ROWS", "512"); monkeypatch.setenv("MMS_CONV3W_MT", "0"); monkeypatch.setenv("MMS_MS1_DIV", "1")
     from multimodal_survival_prediction_amd import data, models as HM, training as T
     from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
     dims, rna_dim, K, B = (32, 32, 32), 48, 3, 4
@@ -234,7 +234,7 @@ def test_lockstep_epoch_matches_sequential(style, monkeypatch):
 
 def test_lockstep_two_streams_matches_one(monkeypatch):
     """concurrent=2 (two sub-groups on two streams) trains the same folds as concurrent=1."""
-    monkeypatch.setenv("MMS_SPLIT_WGS", "1000000"); monkeypatch.setenv("MMS_CONV1_KSPLIT", "0"); monkeypatch.setenv("MMS_CONV3_MT", "0"); monkeypatch.setenv("MMS_BIG_NG", "0"); monkeypatch.setenv("MMS_MS3_ROWS", "512"); monkeypatch.setenv("MMS_CONV3W_MT", "0"); monkeypatch.setenv("MMS_MS1_DIV", "1")
+    monkeypatch.setenv("MMS_SPLIT_WGS", "1000000"); monkeypatch.setenv("MMS_CONV1_KSPLIT", "0"); monkeypatch.setenv("MMS_CONV1_SMALL", "0"); monkeypatch.setenv("MMS_CONV3_MT", "0"); monkeypatch.setenv("MMS_BIG_NG", "0"); monkeypatch.setenv("MMS_MS3_ROWS", "512"); monkeypatch.setenv("MMS_CONV3W_MT", "0"); monkeypatch.setenv("MMS_MS1_DIV", "1")
     from multimodal_survival_prediction_amd import data, models as HM, training as T
     from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
     dims, rna_dim, K, B = (32, 32, 32), 48, 5, 4
