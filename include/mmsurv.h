@@ -460,8 +460,9 @@ int mms_clip_adam(const AdamP* p, hipStream_t s);              /* clip by global
 int mms_dn121_workspace_bytes(int B, int D, int H, int W, size_t* bytes);
 int mms_dn121_region(int B, int D, int H, int W, const char* name, int index, size_t* off, size_t* bytes);
 int mms_dn121_init(void* ws, int B, int D, int H, int W, const void* const* params, const void* const* buffers, hipStream_t s);
-/* Width N of class_layers.out ([N][1024] weight, [N] bias; out / dout carry N columns): a per-thread attribute of the calling thread's
- * subsequent mms_dn121_* driver calls, default 128 (R/scripts/training/simple_fusion.py:163 img_feature_dim).  1 <= n <= 4096. */
+/* Width N of class_layers.out ([N][1024] weight, [N] bias; out / dout carry N columns) for the NEXT mms_dn121_* forward / backward driver
+ * call of the calling thread (one-shot: the call after that sees 128 again unless set anew), default 128
+ * (R/scripts/training/simple_fusion.py:163 img_feature_dim).  1 <= n <= 4096. */
 int mms_dn121_out_features(int n);
 int mms_dn121_forward(void* ws, int B, int D, int H, int W, const float* x, const void* const* params,
                       const void* const* buffers, float* out, int ldo, int train, hipStream_t s);

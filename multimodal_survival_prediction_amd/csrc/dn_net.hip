@@ -177,13 +177,15 @@ extern "C" int mms_conv0_bwd_weight_group(const Conv0BwdWP*, int, hipStream_t);
 
 // Width of class_layers.out (MONAI DenseNet121 `out_channels`): 128 in the three hot-path models (final_multimodal.py:66-71), a free
 // constructor argument (img_feature_dim) in simple_fusion.py:163 / flexible_multimodal.py.  A per-thread launch attribute rather than a
-// parameter of the seven driver entry points: set it (mms_dn121_out_features) before the driver calls it applies to; default 128.
+// parameter of the seven driver entry points.  ONE-SHOT: it applies to the NEXT mms_dn121_* forward / backward driver call on the calling
+// thread only and falls back to 128 afterwards, so a caller that never sets it can never inherit another model's width.
 static thread_local int tl_out_features = 128;
 extern "C" int mms_dn121_out_features(int n) {
     if (n < 1 || n > 4096) return MMS_ERR_ARG;
     tl_out_features = n;
     return MMS_OK;
 }
+static inline int take_out_features() { const int n = tl_out_features; tl_out_features = 128; return n; }
 
 #define TRY(x) do { int rc_ = (x); if (rc_ != MMS_OK) { fprintf(stderr, "mmsurv: %s -> %d (dn_net.hip:%d)\n", #x, rc_, __LINE__); return rc_; } } while (0)
 
@@ -328,6 +330,7 @@ struct Dp {
 
 // Forward of ng models of identical shape in lock-step: every launch below carries all ng parameter blocks.
 static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W, int ldo, int train, hipStream_t s, const Dp& dp = Dp()) {
+    const int nout = take_out_features();
     Plan P;
     if (!make_plan(P, B, D, H, W) || ng < 1 || ng > MMS_MAX_GROUP) return MMS_ERR_ARG;
     if ((dp.hook || dp.bn_world > 1) && (ng != 1 || !train)) return MMS_ERR_ARG;
@@ -431,7 +434,7 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
         const Ctx& c = cx[g];
         hd[g] = HeadFwdP{at<float>(c.ws, P.slab[3]), CTOT[3], 1024, B, P.M[3] / B,
                          mk_bn(c.ws, P.st_slab[3], CTOT[3], c.prm, IDX.n5w, c.buf, IDX.bn5, P.M[3] * bw, train, P.R[3]),
-                         c.prm[IDX.outw], c.prm[IDX.outb], tl_out_features, at<float>(c.ws, P.pooled), c.out, ldo};
+                         c.prm[IDX.outw], c.prm[IDX.outb], nout, at<float>(c.ws, P.pooled), c.out, ldo};
     }
     TRY(mms_head_fwd_group(hd, ng, s));
     if (train) {
@@ -446,6 +449,7 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
 // (caller zeroes them, e.g. one hipMemsetAsync over a flat gradient buffer).  dout: [B][128] per model.
 static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W, int lddout, hipStream_t s, hipStream_t side,
                                hipEvent_t ev_fork, hipEvent_t ev_join, const Dp& dp = Dp()) {
+    const int nout = take_out_features();
     hipStream_t sw = side ? side : s;       // stream of the weight-gradient kernels
     bool side_pending = false;
     Plan P;
@@ -461,7 +465,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
         FOR_G {
             const Ctx& c = cx[g];
             hb[g] = HeadBwdP{c.dout, lddout, at<float>(c.ws, P.pooled), at<float>(c.ws, P.slab[3]), CTOT[3], 1024, B, P.M[3] / B,
-                             mk_bn(c.ws, P.st_slab[3], CTOT[3], c.prm, IDX.n5w, nullptr, 0, P.M[3] * bnw, 1, P.R[3]), c.prm[IDX.outw], tl_out_features,
+                             mk_bn(c.ws, P.st_slab[3], CTOT[3], c.prm, IDX.n5w, nullptr, 0, P.M[3] * bnw, 1, P.R[3]), c.prm[IDX.outw], nout,
                              c.grd[IDX.outw], c.grd[IDX.outb], c.grd[IDX.n5w], c.grd[IDX.n5b], at<float>(c.ws, P.dslab[3]), CTOT[3]};
         }
         if (sync) {     // norm5's backward sums must span all ranks: sums kernel | all-reduce | apply kernel

@@ -125,8 +125,10 @@ class DenseNet121(nn.Module):
     def _run_forward(self, x):
         e = self._tables(x)
         B, D, H, W = e["dims"]
-        out = torch.empty(B, 128, device=x.device, dtype=torch.float32)
+        nout = self.class_layers.out.out_features
+        out = torch.empty(B, nout, device=x.device, dtype=torch.float32)
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        e["lib"].mms_dn121_out_features(nout)          # one-shot driver attribute: class_layers.out's width
         _lib.check(e["lib"].mms_dn121_forward(e["ws"].data_ptr(), B, D, H, W, x.data_ptr(), e["ptab"], e["btab"],
                                               out.data_ptr(), out.stride(0), 1 if self.training else 0, st), "mms_dn121_forward")
         return out
@@ -161,6 +163,7 @@ class DenseNet121(nn.Module):
         gtab = self._grad_table()
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         dout = dout.contiguous().float()
+        e["lib"].mms_dn121_out_features(self.class_layers.out.out_features)
         _lib.check(e["lib"].mms_dn121_backward(e["ws"].data_ptr(), B, D, H, W, x.data_ptr(), e["ptab"],
                                                dout.data_ptr(), dout.stride(0), gtab, st), "mms_dn121_backward")
 

@@ -368,7 +368,8 @@ class SurvivalEngine:
             feats = P.buf["feats"]
             out = feats[:, prog["ct_cols"]:]
             fwd = lib.mms_fb_forward if P.fallback else lib.mms_dn121_forward
-            lib.mms_dn121_out_features(prog.get("enc_width", 128))      # per-thread driver attribute: class_layers.out's width
+            if not P.fallback:
+                lib.mms_dn121_out_features(prog.get("enc_width", 128))      # one-shot driver attribute: class_layers.out's width
             _lib.check(fwd(P.ws.data_ptr(), B, D, H, W, P.ct.data_ptr(), P.ptab, P.btab, out.data_ptr(),
                            feats.stride(0), 1 if train else 0, st), "encoder forward")
         if P.big:
@@ -428,7 +429,8 @@ class SurvivalEngine:
         B, (D, H, W) = P.B, P.dims
         dfe = P.dbuf["feats"]
         dct = dfe[:, prog["ct_cols"]:]
-        lib.mms_dn121_out_features(prog.get("enc_width", 128))
+        if not P.fallback:
+            lib.mms_dn121_out_features(prog.get("enc_width", 128))
         if stage is not None or hook is not None or P.bn_world > 1:
             hi, lo = stage if stage is not None else (3, 0)
             _lib.check(lib.mms_dn121_backward_stage(P.ws.data_ptr(), B, D, H, W, P.ct.data_ptr(), P.ptab, dct.data_ptr(), dfe.stride(0),
