@@ -7,7 +7,8 @@ Default workload `c3` = the configuration BASELINE.json's metric is quoted on, N
   348 labelled patients with all 260 unlabelled patients added to every training split
   (R/scripts/training/partial_modality_training.py:496-532), batch 4, Adam(lr 1e-4, wd 1e-4), clip_grad_norm_(1.0).
   The K = 5 fold models are advanced in lock-step by `training.train_epoch_lockstep` (what scripts/training/
-  partial_modality_training.py runs): ONE launch sequence per lock-step step carries all fold models of a sub-group.
+  partial_modality_training.py runs): ONE launch sequence per lock-step step carries all fold models of a sub-group
+  (default: sub-groups of 2 + 2 + 1 on three HIP streams).
   A "step" is one lock-step step: every fold model that still has a batch takes one optimisation step on it (zero-grad,
   forward, Cox partial likelihood on the labelled patients + gate entropy, backward, clip, Adam -- one replayed HIP graph per
   sub-group).  The timed region is WHOLE EPOCHS of the 5-fold job (135 steps each: 134 full batches + the ragged tail of every
@@ -335,8 +336,8 @@ def run_config3(args, world, rank, dev):
     dt1, _ = timed(lambda: chain(n1))
     dt1 /= n1
     # validation (reported separately): validate_lockstep over the K validation splits
-    validate_lockstep(group, val_loaders, "partial", dev, concurrent=conc)
-    dtv, val = timed(lambda: validate_lockstep(group, val_loaders, "partial", dev, concurrent=conc))
+    validate_lockstep(group, val_loaders, "partial", dev, concurrent=args.validation_streams)
+    dtv, val = timed(lambda: validate_lockstep(group, val_loaders, "partial", dev, concurrent=args.validation_streams))
     n_val = sum(len(l.idx) for l in val_loaders)
     for e_ in group.engines:
         e_.model.train()
@@ -654,7 +655,9 @@ def main():
                          "headline; also hosts --mode ddp); c5: BASELINE config 5 (RNA-seq-only model, batch 2048, single GPU)")
     ap.add_argument("--patients", type=int, default=608)
     ap.add_argument("--folds", type=int, default=5)
-    ap.add_argument("--lockstep-streams", type=int, default=2, help="c3: 2 = the folds step as two lock-step sub-groups on two HIP streams")
+    ap.add_argument("--lockstep-streams", type=int, default=3,
+                    help="c3: the folds step as this many lock-step sub-groups on as many HIP streams (default 3: 5 folds = 2 + 2 + 1; round 2 ran 3 + 2)")
+    ap.add_argument("--validation-streams", type=int, default=2, help="c3: sub-groups / streams of the validation pass")
     ap.add_argument("--h2d", action="store_true", default=True, help="c3: also time the epoch with the cohort in pinned host memory")
     ap.add_argument("--no-h2d", dest="h2d", action="store_false")
     ap.add_argument("--many-folds", action="store_true", default=True, help="c3: also time 2 x 10 fold models in flight")

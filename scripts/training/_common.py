@@ -89,11 +89,11 @@ def cv_lockstep(style, models, loaders, group_kw, num_epochs, patience, make_sch
             break
         torch.cuda.synchronize(); t0 = time.perf_counter()
         tr = train_epoch_lockstep(group, [loaders[g][0] for g in active], style, members=active,
-                                  concurrent=env_int("MMS_LOCKSTEP_STREAMS", 2))
+                                  concurrent=env_int("MMS_LOCKSTEP_STREAMS", 3))
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         n_ep = sum(len(loaders[g][0].idx) for g in active)
         va = validate_lockstep(group, [loaders[g][1] for g in active], style, device, members=active,
-                               concurrent=env_int("MMS_LOCKSTEP_STREAMS", 2))
+                               concurrent=env_int("MMS_VALIDATE_STREAMS", 2))
         for g, trg, (val_loss, c) in zip(active, tr, va):
             s = st[g]
             s["t"] += dt; s["n"] += n_ep                       # the group's aggregate rate while this fold was active
