@@ -571,9 +571,11 @@ struct DyConsts {   // per output channel n (LDS): dy = A*(dbn - B - yhat*C), yh
 };
 
 // ---- data: dbn_in[m][k] = [a>0] * sum_n dy[m][n] * W[n][k]  (+ un-pool) ; rows m, cols k, reduce over n
-template <int WM_, int WN_, int WK_, bool POOL>
+template <int WM_, int WN_, int WK_, bool POOL, bool ONE_ = false>
 struct Conv1BwdDataOp {
     typedef Conv1BwdP Params;
+    static constexpr bool ONE_TILE = ONE_;       // N <= 32 WK: the whole reduction is one tile (dense layers: N = 128 = TK of <1, 1, 4>)
+    static constexpr bool SINGLE_BUF = WK_ == 4;   // 128-deep tiles: one LDS buffer (tile_gemm.h)
     static constexpr int WM = WM_, WN = WN_, WK = WK_, AMODE = LD_K4, BMODE = LD_R4;
     __device__ void step(const Params&, int) {}
     static constexpr int TM = 32 * WM, TN = 32 * WN;
@@ -723,6 +725,9 @@ extern "C" int mms_conv1_bwd_data_group(const Conv1BwdP* pp, int ng, hipStream_t
     for (int g = 0; g < ng; ++g) if ((pp[g].fuse_dx != nullptr) != (p.fuse_dx != nullptr)) return MMS_ERR_ARG;
     if (p.fuse_dx) {      // norm1 backward fused into the epilogue: one workgroup must own every row of its 32 channels
         if (p.pool || p.M > 128 || p.fuse_lddx % 4 != 0) return MMS_ERR_ARG;
+        bool small = true;
+        for (int g = 0; g < ng; ++g) small = small && mms_conv1_small_bwd_ok(pp[g]);
+        if (small) return mms_c1s_bwd(pp, ng, s);
         dim3 g(1, (p.K + 31) / 32, 1);
         return p.M <= 32 ? launch_tile_gemm<Conv1BwdDataOp<1, 1, 4, false>>(pp, ng, g, s)
                          : launch_tile_gemm<Conv1BwdDataOp<4, 1, 1, false>>(pp, ng, g, s);
@@ -735,6 +740,7 @@ extern "C" int mms_conv1_bwd_data_group(const Conv1BwdP* pp, int ng, hipStream_t
                       : launch_tile_gemm<Conv1BwdDataOp<2, 2, 1, false>>(pp, ng, g, s);
     }
     dim3 g((p.M + 31) / 32, (p.K + 31) / 32, 1);
+    if (!p.pool && p.N <= 128) return launch_tile_gemm<Conv1BwdDataOp<1, 1, 4, false, true>>(pp, ng, g, s);     // one K tile: single LDS buffer
     return p.pool ? launch_tile_gemm<Conv1BwdDataOp<1, 1, 4, true>>(pp, ng, g, s)
                   : launch_tile_gemm<Conv1BwdDataOp<1, 1, 4, false>>(pp, ng, g, s);
 }

@@ -41,6 +41,7 @@ template <int WM_, int WN_, int WK_, bool POOL, bool KSPLIT = false>
 struct Conv1FwdOp {
     typedef Conv1FwdP Params;
     static constexpr int WM = WM_, WN = WN_, WK = WK_, AMODE = LD_K4, BMODE = LD_K4;
+    static constexpr bool SINGLE_BUF = WK_ == 4;       // 128-deep tiles: one LDS buffer (tile_gemm.h)
     __device__ void step(const Params&, int) {}
     static constexpr int TM = 32 * WM, TN = 32 * WN;
     static constexpr int EXTRA = 3 * 1024 + TM;

@@ -187,6 +187,16 @@ extern "C" int mms_dn121_out_features(int n) {
 }
 static inline int take_out_features() { const int n = tl_out_features; tl_out_features = 128; return n; }
 
+// MMS_DEBUG_SKIP (64-bit mask, strtoull base 0): TIMING ABLATION ONLY -- the named launches are left out of the step (results are then
+// wrong); what the step gains without a kernel class bounds what optimising that class can gain (tools/ablate_step.sh).
+// bits 0-3 conv1 fwd of dense block 1-4 | 4-7 conv2 fwd | 8-11 conv2 bwd-data | 12-15 conv2 bwd-weight | 16-19 conv1 bwd-weight |
+// 20-23 conv1 bwd-data | 24-27 bn_bwd_apply | 28 stem fwd | 29 stem bwd | 30 transitions fwd | 31 transitions bwd | 32 / 33 block-4
+// persistent fwd / bwd | 34 weight pack | 35 gradient unpack
+static inline bool dbg_skip(int bit) {
+    const char* e = getenv("MMS_DEBUG_SKIP");
+    return e && ((strtoull(e, nullptr, 0) >> bit) & 1ull);
+}
+#define TRYS(bit, x) do { if (!dbg_skip(bit)) TRY(x); } while (0)
 #define TRY(x) do { int rc_ = (x); if (rc_ != MMS_OK) { fprintf(stderr, "mmsurv: %s -> %d (dn_net.hip:%d)\n", #x, rc_, __LINE__); return rc_; } } while (0)
 
 extern "C" int mms_dn121_workspace_bytes(int B, int D, int H, int W, size_t* bytes) {
@@ -343,7 +353,7 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
         TRY(mms_zero_regions_group(regs, ng, P.stats_end - P.stats_begin, s));
     }
     FOR_G tabs[g] = at<void>(cx[g].ws, P.tab_pack);
-    TRY(mms_pack_conv3_table_group_ex(tabs, ng, NLAYER, conv3_fragmask(P, ng), s));
+    TRYS(34, mms_pack_conv3_table_group_ex(tabs, ng, NLAYER, conv3_fragmask(P, ng), s));
     auto st = [&](void* ws, size_t off, int Ctot_, int coff, bool sq) -> double* {
         return train ? at<double>(ws, off) + (sq ? Ctot_ : 0) + coff : nullptr;
     };
@@ -360,9 +370,9 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
                              st(c.ws, P.st_slab[0], CTOT[0], 0, false), st(c.ws, P.st_slab[0], CTOT[0], 0, true)};
             pf[g].srep = P.R[0]; pf[g].sstride = 2 * CTOT[0];
         }
-        TRY(mms_conv0_fwd_group(c0, ng, s));
+        TRYS(28, mms_conv0_fwd_group(c0, ng, s));
         SYNC(at<double>(cx[0].ws, P.st_y0), P.R0, 2 * 64, 64, 64);
-        TRY(mms_pool_fwd_group(pf, ng, s));
+        TRYS(28, mms_pool_fwd_group(pf, ng, s));
         SYNC(at<double>(cx[0].ws, P.st_slab[0]), P.R[0], 2 * CTOT[0], 64, CTOT[0]);
     }
     // block 4 as ONE launch (dn_b4.hip) when its rows fit a single 16-row MFMA tile (batch 4 on 64x64x32 volumes); MMS_PERSIST_B4=0: off
@@ -382,7 +392,7 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
                 regs[g] = at<void>(c.ws, P.b4_cnt);
             }
             if (!train) TRY(mms_zero_regions_group(regs, ng, 256, s));      // (training: the statistics zero-fill above covers the counters)
-            TRY(mms_b4_fwd_group(q, ng, s));
+            TRYS(32, mms_b4_fwd_group(q, ng, s));
             l += LAYERS[3];
             continue;
         }
@@ -409,9 +419,9 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
                                   ns3 > 1 ? at<float>(c.ws, P.partial) : nullptr, ns3};
                 c3[g].srep = P.R[b]; c3[g].sstride = 2 * CTOT[b]; c3[g].wfrag = conv3_frag_block(P, b, ng) ? 1 : 0;
             }
-            TRY(mms_conv1_fwd_group(c1, ng, s));
+            TRYS(b, mms_conv1_fwd_group(c1, ng, s));
             SYNC(at<double>(cx[0].ws, P.st_y1[l]), P.R[b], 2 * 128, 128, 128);
-            TRY(mms_conv3_fwd_group(c3, ng, s));
+            TRYS(4 + b, mms_conv3_fwd_group(c3, ng, s));
             SYNC(at<double>(cx[0].ws, P.st_slab[b]) + C, P.R[b], 2 * CTOT[b], 32, CTOT[b]);
         }
         if (b < 3) {
@@ -425,7 +435,7 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
                                  st(c.ws, P.st_slab[b + 1], CTOT[b + 1], 0, false), st(c.ws, P.st_slab[b + 1], CTOT[b + 1], 0, true), 1, P.g[b]};
                 t[g].srep = P.R[b + 1]; t[g].sstride = 2 * CTOT[b + 1];
             }
-            TRY(mms_conv1_fwd_group(t, ng, s));
+            TRYS(30, mms_conv1_fwd_group(t, ng, s));
             SYNC(at<double>(cx[0].ws, P.st_slab[b + 1]), P.R[b + 1], 2 * CTOT[b + 1], CTOT[b] / 2, CTOT[b + 1]);
         }
     }
@@ -488,10 +498,10 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
     Conv3BwdWP bwq[MMS_MAX_GROUP];
     Conv1BwdP c1q[MMS_MAX_GROUP];
     int nq = 0;
-    auto flush_w = [&]() -> int {
+    auto flush_w = [&](int b) -> int {
         if (nq == 0) return MMS_OK;
-        TRY(mms_conv3_bwd_weight_group(bwq, nq, s));
-        TRY(mms_conv1_bwd_weight_group(c1q, nq, s));
+        TRYS(12 + b, mms_conv3_bwd_weight_group(bwq, nq, s));
+        TRYS(16 + b, mms_conv1_bwd_weight_group(c1q, nq, s));
         nq = 0;
         return MMS_OK;
     };
@@ -504,8 +514,11 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
         // block 4 (<= 32 rows, one MFMA row tile): norm1's backward rides in conv1_bwd_data's epilogue (Conv1BwdP.fuse_dx), no
         // mms_bn_bwd_apply launch.  (Measured at 128 rows -- block 3, 128 x 32 tiles -- the fused form is slower than the two
         // launches it replaces: 25 us against 8.8 + 6.7 us, rocprofv3 kernel stats; MMS_FUSE_APPLY=128 selects it anyway.)
+        // Round 3: up to 128 rows the whole-M kernel of dn_c1s.hip (one workgroup per 16 channels, every row) takes the fused form --
+        // one launch instead of conv1_bwd_data + bn_bwd_apply, no statistic atomics; MMS_CONV1_SMALL_BWD=0 restores the rule above.
         const char* efa = getenv("MMS_FUSE_APPLY");
-        const int fuse_rows = efa ? atoi(efa) : 32;
+        const char* esb = getenv("MMS_CONV1_SMALL_BWD");
+        const int fuse_rows = efa ? atoi(efa) : ((esb && esb[0] == '0') ? 32 : 128);
         const bool fuse_apply = M <= fuse_rows && M <= 128 && !sync;      // SyncBN: the sums leave the workgroup (all-reduce) before they are applied
         // block 4 with <= 16 rows: the whole data path of the block's backward as ONE launch (dn_b4.hip); the loop below then only queues
         // the layers' weight-gradient members.  MMS_PERSIST_B4: 0 = off (both passes), 1 = forward only; default both.
@@ -523,7 +536,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
                     q[g].dg1[i] = (float*)c.grd[ip]; q[g].db1[i] = (float*)c.grd[ip + 1];
                 }
             }
-            TRY(mms_b4_bwd_group(q, ng, s));
+            TRYS(33, mms_b4_bwd_group(q, ng, s));
         }
         for (int i = LAYERS[b] - 1; i >= 0; --i) {
             --l; C -= 32;
@@ -580,29 +593,29 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
                 side_pending = false;
             }
             if (!b4_bwd) {
-                TRY(mms_conv3_bwd_data_group(bd, ng, s));
+                TRYS(8 + b, mms_conv3_bwd_data_group(bd, ng, s));
                 SYNC(at<double>(cx[0].ws, P.bb_y1[l]), P.R[b], 2 * 128, 128, 128);
             }
             if (defer) {
-                if (nq + ng > MMS_MAX_GROUP) TRY(flush_w());
+                if (nq + ng > MMS_MAX_GROUP) TRY(flush_w(b));
                 FOR_G { bwq[nq] = bw[g]; c1q[nq] = c1[g]; ++nq; }
             } else {
                 if (side) {
                     if (hipEventRecord(ev_fork, s) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess) return MMS_ERR_LAUNCH;
                 }
-                TRY(mms_conv3_bwd_weight_group(bw, ng, sw));
-                TRY(mms_conv1_bwd_weight_group(c1, ng, sw));
+                TRYS(12 + b, mms_conv3_bwd_weight_group(bw, ng, sw));
+                TRYS(16 + b, mms_conv1_bwd_weight_group(c1, ng, sw));
                 if (side) {
                     if (hipEventRecord(ev_join, side) != hipSuccess) return MMS_ERR_LAUNCH;
                     side_pending = true;
                 }
             }
             if (b4_bwd) continue;
-            TRY(mms_conv1_bwd_data_group(c1, ng, s));
+            TRYS(20 + b, mms_conv1_bwd_data_group(c1, ng, s));
             SYNC(at<double>(cx[0].ws, P.bb_in[l]), P.R[b], 2 * 1024, C, 1024);
-            if (!fuse_apply) TRY(mms_bn_bwd_apply_group(ap, ng, s));
+            if (!fuse_apply) TRYS(24 + b, mms_bn_bwd_apply_group(ap, ng, s));
         }
-        TRY(flush_w());
+        TRY(flush_w(b));
         if (side && side_pending) {
             if (hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) return MMS_ERR_LAUNCH;
             side_pending = false;
@@ -630,10 +643,10 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
                 ap[g] = BnBwdApplyP{at<float>(c.ws, P.dbn_in), CTOT[t], at<float>(c.ws, P.slab[t]), CTOT[t], at<float>(c.ws, P.dslab[t]), CTOT[t],
                                     Mp, Kp, bnt, bbsrc(c.ws, P.bb_tr[t], 1024, P.R[t]), 0, c.grd[ip], c.grd[ip + 1]};
             }
-            TRY(mms_conv1_bwd_weight_group(c1, ng, s));
-            TRY(mms_conv1_bwd_data_group(c1, ng, s));
+            TRYS(31, mms_conv1_bwd_weight_group(c1, ng, s));
+            TRYS(31, mms_conv1_bwd_data_group(c1, ng, s));
             SYNC(at<double>(cx[0].ws, P.bb_tr[t]), P.R[t], 2 * 1024, Kp, 1024);
-            TRY(mms_bn_bwd_apply_group(ap, ng, s));
+            TRYS(31, mms_bn_bwd_apply_group(ap, ng, s));
         } else {       // stem
             int ms0 = P.M0 / 1024; if (ms0 < 1) ms0 = 1; if (ms0 > 64) ms0 = 64;
             PoolBwdP pb[MMS_MAX_GROUP];
@@ -647,9 +660,9 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
                 cw[g] = Conv0BwdWP{at<float>(c.ws, P.dbn0), at<float>(c.ws, P.y0), bn0, bbsrc(c.ws, P.bb_y0, 64, P.R0), c.x, P.in, P.g0,
                                    at<int>(c.ws, P.coords0), P.M0, c.grd[IDX.conv0], ms0, c.grd[IDX.n0w], c.grd[IDX.n0b]};
             }
-            TRY(mms_pool_bwd_group(pb, ng, s));
+            TRYS(29, mms_pool_bwd_group(pb, ng, s));
             SYNC(at<double>(cx[0].ws, P.bb_y0), P.R0, 2 * 64, 64, 64);
-            TRY(mms_conv0_bwd_weight_group(cw, ng, s));
+            TRYS(29, mms_conv0_bwd_weight_group(cw, ng, s));
         }
     }
     if (side && side_pending) {
@@ -669,7 +682,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
             for (int i = 0; i < nl; ++i) dwt[g][i] = cx[g].grd[IDX.layer[l0 + i] + 5];
             dwp_[g] = dwt[g];
         }
-        TRY(mms_unpack_conv3_grads_group(scr, dwp_, ng, nl, s));
+        TRYS(35, mms_unpack_conv3_grads_group(scr, dwp_, ng, nl, s));
     }
     return MMS_OK;
 }

@@ -38,6 +38,9 @@ static inline bool mms_conv1_small_ok(const Conv1FwdP& p, int ng) {
     return (long)((p.M + 15) / 16) * ((p.N + 15) / 16) * ng <= maxwg;
 }
 int mms_c1s_fwd(const Conv1FwdP* pp, int ng, hipStream_t s);
+// whole-M backward-data + fused norm1 backward (dn_c1s.hip): MMS_CONV1_SMALL_BWD=0 keeps the tile-GEMM forms
+bool mms_conv1_small_bwd_ok(const Conv1BwdP& p);
+int mms_c1s_bwd(const Conv1BwdP* pp, int ng, hipStream_t s);
 int mms_c3s_fwd(const Conv3FwdP* pp, int ng, hipStream_t s);
 int mms_c3s_bwd_data(const Conv3BwdDataP* pp, int ng, hipStream_t s);
 

@@ -39,6 +39,18 @@ enum { LD_K4 = 0, LD_R4 = 1, LD_K1 = 2 };
 // LDS image of one operand tile: K4/K1 loaders -> [row][TK+4] (read with ds_read_b128);
 // R4 loaders (source contiguous along the row index) -> k-major [TK][rows+4]: written with conflict-free
 // ds_write_b128 along the rows, read with one ds_read_b32 per MFMA operand (32 consecutive dwords per half-wave).
+// Optional Op trait: static constexpr bool ONE_TILE = true -- the launcher guarantees a K range of at most one tile (ke - kb <= TK):
+// no second LDS buffer (a third workgroup fits a CU, and the kernel leaves room for the other streams' workgroups), no prefetch set.
+template <class Op, class = void> struct op_one_tile { static constexpr bool value = false; };
+template <class Op> struct op_one_tile<Op, decltype((void)Op::ONE_TILE)> { static constexpr bool value = Op::ONE_TILE; };
+
+// Optional Op trait: static constexpr bool SINGLE_BUF = true -- one LDS tile buffer for a multi-tile K range: the next tile waits in
+// registers (the prefetch sets are unchanged) and is stored after a barrier behind the current tile's MFMAs.  One more barrier per K
+// step for half the LDS: for the 128-deep tiles of the <1, 1, 4> shapes (80 KB double-buffered = 2 workgroups per CU and no room for
+// another stream's workgroups beside them) the footprint, not the barrier, is what costs the step (profiles/r03_step_ablation.txt).
+template <class Op, class = void> struct op_single_buf { static constexpr bool value = false; };
+template <class Op> struct op_single_buf<Op, decltype((void)Op::SINGLE_BUF)> { static constexpr bool value = Op::SINGLE_BUF; };
+
 template <class Op>
 struct TileGemmCfg {
     static constexpr int TM = 32 * Op::WM, TN = 32 * Op::WN, TK = 32 * Op::WK;
@@ -46,7 +58,7 @@ struct TileGemmCfg {
     static constexpr int ATILE = Op::AMODE == 1 ? TK * APITCH : TM * APITCH;
     static constexpr int BTILE = Op::BMODE == 1 ? TK * BPITCH : TN * BPITCH;
     static constexpr size_t main_floats() {
-        size_t tiles = (size_t)2 * (ATILE + BTILE);
+        size_t tiles = (size_t)((op_one_tile<Op>::value || op_single_buf<Op>::value) ? 1 : 2) * (ATILE + BTILE);
         size_t cs = (size_t)TM * (TN + 1);
         return tiles > cs ? tiles : cs;
     }
@@ -72,7 +84,8 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(const Grp<typename Op::P
     constexpr int APITCH = Cfg::APITCH, BPITCH = Cfg::BPITCH, ATILE = Cfg::ATILE, BTILE = Cfg::BTILE;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
-    float* Bs = smem + 2 * ATILE;
+    constexpr bool ONE = op_one_tile<Op>::value, SINGLE = op_single_buf<Op>::value && !ONE;
+    float* Bs = smem + ((ONE || SINGLE) ? 1 : 2) * ATILE;
     float* extra = smem + Cfg::main_floats();
 
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
@@ -206,7 +219,33 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(const Grp<typename Op::P
     };
 
     if (kb < ke) {
-        {
+        if constexpr (ONE) {
+            gload(R0, kb);
+            sstore(R0, 0);
+            __syncthreads();
+            mma(0);
+            __syncthreads();
+        } else if constexpr (SINGLE) {
+            gload(R0, kb);
+            if (kb + TK < ke) gload(R1, kb + TK);
+            sstore(R0, 0);
+            __syncthreads();
+            for (int k0 = kb;; k0 += 2 * TK) {           // same tiles, same prefetch distance and accumulation order as the two-buffer loop
+                if (k0 + 2 * TK < ke) gload(R0, k0 + 2 * TK);
+                mma(0);
+                if (k0 + TK >= ke) break;
+                __syncthreads();
+                sstore(R1, 0);
+                __syncthreads();
+                if (k0 + 3 * TK < ke) gload(R1, k0 + 3 * TK);
+                mma(0);
+                if (k0 + 2 * TK >= ke) break;
+                __syncthreads();
+                sstore(R0, 0);
+                __syncthreads();
+            }
+            __syncthreads();
+        } else {
             // two register sets: the global loads of tile t+2 are issued before the MFMAs of tile t and consumed (transform
             // + LDS store) one step later, so L2/MALL latency has a full step to hide (vmcnt retires in order)
             gload(R0, kb);

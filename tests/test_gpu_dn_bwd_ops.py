@@ -89,15 +89,21 @@ def test_dense_layer_backward(ops, B, dims, C, Ctot, ms, split, small, monkeypat
     ops.conv1_bwd("data", dbn_mid, M, 128, slab, C, bn1, w1, dw1, dbn_in, e1, e2, **kw)
     dslab_f = dslab.clone()
     ops.bn_bwd_apply(dbn_in, slab, dslab, M, C, bn1, ops.bnbwd(e1, e2), True, dg1, db1)
-    if M <= 128:      # small-M blocks: norm1 backward fused into conv1_bwd_data's epilogue (no dbn scratch, no apply launch)
+    # small-M blocks: norm1 backward fused into conv1 backward-data (no dbn scratch, no apply launch) -- the whole-M kernel of
+    # dn_c1s.hip (default) and the tile-GEMM epilogue form (MMS_CONV1_SMALL_BWD=0)
+    for form in (("1", "0") if M <= 128 else ()):
+        monkeypatch.setenv("MMS_CONV1_SMALL_BWD", form)
+        dslab_g = dslab_f.clone()
         dg1f, db1f = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
         f1, f2 = stats(DEV, 1024)
         ops.conv1_bwd("data", dbn_mid, M, 128, slab, C, bn1, w1, dw1, torch.empty(M, Ctot, device=DEV), f1, f2,
-                      fuse_dx=dslab_f, fuse_dgamma=dg1f, fuse_dbeta=db1f, **kw)
+                      fuse_dx=dslab_g, fuse_dgamma=dg1f, fuse_dbeta=db1f, **kw)
         torch.cuda.synchronize()
-        assert_close(dslab_f[:, :C], cl(x.grad), 1e-4, "dx (fused norm1 backward)")
+        assert_close(dslab_g[:, :C], cl(x.grad), 1e-4, f"dx (fused norm1 backward, form {form})")
         assert_close(dg1f, n1.weight.grad, 1e-4, "dgamma1 (fused)"); assert_close(db1f, n1.bias.grad, 1e-4, "dbeta1 (fused)")
-        assert torch.equal(dslab_f[:, C:], dslab[:, C:])
+        assert torch.equal(dslab_g[:, C:], dslab[:, C:])
+        assert float(f1.abs().sum()) == 0.0        # neither form touches the statistic accumulators
+    monkeypatch.delenv("MMS_CONV1_SMALL_BWD", raising=False)
     torch.cuda.synchronize()
     assert_close(dw2, c2.weight.grad, 1e-4, "dW conv2")
     assert_close(dw2m, c2.weight.grad, 1e-4, "dW conv2 (multi-tap kernel)")
