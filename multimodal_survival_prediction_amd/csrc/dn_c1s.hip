@@ -14,8 +14,9 @@
 namespace {
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
-constexpr int C1S_NP = 16;          // operand pieces (float4) per thread and panel at K = 1024
-
+// C1S_NP: operand pieces (float4) per thread and panel -- 16 at K <= 1024 (228 VGPRs), 8 at K <= 512 (156 VGPRs: such a wave still fits
+// on a SIMD that holds two waves of another stream's block-1 kernels, see mms_c3s_fwd)
+template <int C1S_NP>
 __global__ __launch_bounds__(256) void conv1s_fwd_kernel(const Grp<Conv1FwdP> grp) {
     const Conv1FwdP& p = grp.p[blockIdx.z];
     const float* __restrict__ x = p.x;                 // kernel arguments read once (dn_c3s.hip: left in the kernarg segment they are
@@ -275,10 +276,17 @@ int mms_c1s_fwd(const Conv1FwdP* pp, int ng, hipStream_t s) {
     int smem = (16 * (p.K + 4) + 3 * p.K) * (int)sizeof(float);
     if (smem < 4 * 16 * 17 * 4 + 2 * 256 * 8) smem = 4 * 16 * 17 * 4 + 2 * 256 * 8;
     static std::once_flag attr_once;
-    std::call_once(attr_once, [] { hipFuncSetAttribute((const void*)conv1s_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    std::call_once(attr_once, [] { hipFuncSetAttribute((const void*)(void (*)(const Grp<Conv1FwdP>))conv1s_fwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                        (16 * 1028 + 3 * 1024) * (int)sizeof(float)); });
     Grp<Conv1FwdP> a;
     if (!grp_fill(a, pp, ng, 1)) return MMS_ERR_ARG;
-    MMS_LAUNCH(conv1s_fwd_kernel, dim3((p.M + 15) / 16, (p.N + 15) / 16, ng), dim3(256), smem, s, a);
+    const dim3 grid((p.M + 15) / 16, (p.N + 15) / 16, ng);
+    if (p.K <= 512) {
+        const auto kern = conv1s_fwd_kernel<8>;        // 16 x 516 + 3 x 512 floats = 39 KB: below the default dynamic-LDS limit
+        MMS_LAUNCH(kern, grid, dim3(256), smem, s, a);
+    } else {
+        const auto kern = conv1s_fwd_kernel<16>;
+        MMS_LAUNCH(kern, grid, dim3(256), smem, s, a);
+    }
     return mms_check_launch();
 }

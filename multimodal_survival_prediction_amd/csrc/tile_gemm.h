@@ -71,8 +71,11 @@ struct TileGemmCfg {
 template <class Op, class = void> struct has_zremap { static constexpr bool value = false; };
 template <class Op> struct has_zremap<Op, decltype((void)&Op::zremap)> { static constexpr bool value = true; };
 
+#ifndef MMS_TGK_ATTR
+#define MMS_TGK_ATTR            // register-budget experiments: -DMMS_TGK_ATTR='__attribute__((amdgpu_waves_per_eu(4, 4)))'
+#endif
 template <class Op>
-__global__ __launch_bounds__(256) void tile_gemm_kernel(const Grp<typename Op::Params> grp) {
+__global__ __launch_bounds__(256) MMS_TGK_ATTR void tile_gemm_kernel(const Grp<typename Op::Params> grp) {
     int gi, z;                                             // model of the fold group, the op's own z index
     if constexpr (has_zremap<Op>::value) Op::zremap((int)blockIdx.z, grp.zdim, (int)gridDim.z, gi, z);
     else { gi = blockIdx.z / grp.zdim; z = blockIdx.z - gi * grp.zdim; }
