@@ -543,6 +543,21 @@ int mms_dn121_forward_group(int ng, void* const* ws, int B, int D, int H, int W,
 int mms_dn121_backward_group(int ng, void* const* ws, int B, int D, int H, int W, const float* const* x,
                              const void* const* const* params, const float* const* dout, int lddout,
                              void* const* const* grads, hipStream_t s);
+/* Stage variants (round 3): the group step split at dense-block boundaries so that its chip-filling part (stem, early blocks) and its
+   latency-bound part (late blocks, head) can be issued on different HIP streams, e.g. streams with disjoint CU masks
+   (hipExtStreamCreateWithCUMask; fold_group.py, MMS_CU_PARTITION).  The caller orders the stages with events.
+   forward_stage: dense blocks [block_lo, block_hi] (0-based) with their trailing transitions; the statistics zero-fill, the weight
+   packs and the stem belong to block 0, the head (which writes out) and the running-statistics update to block 3.
+   backward_stage: blocks block_hi .. block_lo as mms_dn121_backward_stage; flags bit 0: stop BEFORE the transition / stem below
+   block_lo; bit 1: of block_hi only the transition below it (its dense layers ran in the previous stage); bits 2-3: conv2-gradient
+   unpack -- 0 = the layers processed by this call, 1 = none, 2 = all 58 layers (use on the last stage).
+   Stages of one step in order reproduce mms_dn121_forward_group / _backward_group exactly (same launches, same order). */
+int mms_dn121_forward_stage_group(int ng, void* const* ws, int B, int D, int H, int W, const float* const* x,
+                                  const void* const* const* params, const void* const* const* buffers, float* const* out,
+                                  int ldo, int train, int block_lo, int block_hi, hipStream_t s);
+int mms_dn121_backward_stage_group(int ng, void* const* ws, int B, int D, int H, int W, const float* const* x,
+                                   const void* const* const* params, const float* const* dout, int lddout,
+                                   void* const* const* grads, int block_hi, int block_lo, int flags, hipStream_t s);
 
 #ifdef __cplusplus
 }

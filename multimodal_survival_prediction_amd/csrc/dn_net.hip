@@ -333,6 +333,14 @@ struct Ctx {
 struct Dp {
     int bn_world = 1; mms_sync_fn hook = nullptr; void* user = nullptr;
     int b_hi = NB - 1, b_lo = 0;
+    // Stage splits of the fold-group step (mms_dn121_*_stage_group: a step's chip-filling part and its latency-bound part on
+    // different, CU-partitioned streams).  Forward: dense blocks [f_lo, f_hi] with their trailing transitions; the statistics
+    // zero-fill, the weight packs and the stem go with block 0, the head and the running-statistics update with block NB-1.
+    // Backward: hi_trans_only = of block b_hi only the transition BELOW it (its dense layers belong to the previous stage);
+    // lo_skip_trans = stop before the transition / stem below block b_lo; unpack: 0 = the conv2 gradients of the blocks whose dense
+    // layers this call processed, 1 = none, 2 = all layers (the caller ran every earlier stage).
+    int f_lo = 0, f_hi = NB - 1;
+    int hi_trans_only = 0, lo_skip_trans = 0, unpack = 0;
 };
 #define SYNC(ptr, nrep, rstride, ncols, pstride) do { if (dp.hook) { int rc_ = dp.hook(dp.user, (ptr), (nrep), (long)(rstride), (ncols), (long)(pstride), s); \
     if (rc_ != MMS_OK) { fprintf(stderr, "mmsurv: statistics all-reduce hook failed (dn_net.hip:%d)\n", __LINE__); return MMS_ERR_LAUNCH; } } } while (0)
@@ -346,18 +354,19 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
     if ((dp.hook || dp.bn_world > 1) && (ng != 1 || !train)) return MMS_ERR_ARG;
     const int bw = dp.bn_world;        // BatchNorm statistics are taken over bw * M rows (SyncBN: the hook has summed them over the ranks)
     FOR_G if (!cx[g].ws || !cx[g].x || !cx[g].prm || !cx[g].out) return MMS_ERR_ARG;
+    if (dp.f_lo < 0 || dp.f_hi >= NB || dp.f_lo > dp.f_hi) return MMS_ERR_ARG;
     const void* tabs[MMS_MAX_GROUP];
-    if (train) {
+    if (train && dp.f_lo == 0) {
         void* regs[MMS_MAX_GROUP];
         FOR_G regs[g] = at<void>(cx[g].ws, P.stats_begin);
         TRY(mms_zero_regions_group(regs, ng, P.stats_end - P.stats_begin, s));
     }
     FOR_G tabs[g] = at<void>(cx[g].ws, P.tab_pack);
-    TRYS(34, mms_pack_conv3_table_group_ex(tabs, ng, NLAYER, conv3_fragmask(P, ng), s));
+    if (dp.f_lo == 0) TRYS(34, mms_pack_conv3_table_group_ex(tabs, ng, NLAYER, conv3_fragmask(P, ng), s));
     auto st = [&](void* ws, size_t off, int Ctot_, int coff, bool sq) -> double* {
         return train ? at<double>(ws, off) + (sq ? Ctot_ : 0) + coff : nullptr;
     };
-    {   // stem
+    if (dp.f_lo == 0) {   // stem
         Conv0FwdP c0[MMS_MAX_GROUP];
         PoolFwdP pf[MMS_MAX_GROUP];
         FOR_G {
@@ -381,6 +390,7 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
     int l = 0;
     for (int b = 0; b < NB; ++b) {
         int C = C0[b];
+        if (b < dp.f_lo || b > dp.f_hi) { l += LAYERS[b]; continue; }      // another stage's block
         if (b == 3 && b4_one) {
             B4FwdP q[MMS_MAX_GROUP];
             void* regs[MMS_MAX_GROUP];
@@ -439,6 +449,7 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
             SYNC(at<double>(cx[0].ws, P.st_slab[b + 1]), P.R[b + 1], 2 * CTOT[b + 1], CTOT[b] / 2, CTOT[b + 1]);
         }
     }
+    if (dp.f_hi < NB - 1) return MMS_OK;            // the head belongs to the stage that runs the last block
     HeadFwdP hd[MMS_MAX_GROUP];
     FOR_G {
         const Ctx& c = cx[g];
@@ -470,7 +481,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
     const int bnw = dp.bn_world;
     const bool sync = dp.hook != nullptr || bnw > 1;
     auto bbsrc = [&](void* ws, size_t off, int stride, int nrep) { return BnBwd{at<double>(ws, off), at<double>(ws, off) + stride, nrep, 2 * stride}; };
-    if (dp.b_hi == NB - 1) {
+    if (dp.b_hi == NB - 1 && !dp.hi_trans_only) {
         HeadBwdP hb[MMS_MAX_GROUP];
         FOR_G {
             const Ctx& c = cx[g];
@@ -523,7 +534,9 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
         // block 4 with <= 16 rows: the whole data path of the block's backward as ONE launch (dn_b4.hip); the loop below then only queues
         // the layers' weight-gradient members.  MMS_PERSIST_B4: 0 = off (both passes), 1 = forward only; default both.
         const char* epb = getenv("MMS_PERSIST_B4");
-        const bool b4_bwd = b == 3 && M <= 16 && P.R[3] == 1 && !sync && dp.bn_world == 1 && defer && fuse_apply && !(epb && (epb[0] == '0' || epb[0] == '1'));
+        const bool dense = !(dp.hi_trans_only && b == dp.b_hi);       // false: this block's dense layers ran in the previous stage
+        if (!dense) l -= LAYERS[b];
+        const bool b4_bwd = dense && b == 3 && M <= 16 && P.R[3] == 1 && !sync && dp.bn_world == 1 && defer && fuse_apply && !(epb && (epb[0] == '0' || epb[0] == '1'));
         if (b4_bwd) {
             B4BwdP q[MMS_MAX_GROUP];
             FOR_G {
@@ -538,7 +551,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
             }
             TRYS(33, mms_b4_bwd_group(q, ng, s));
         }
-        for (int i = LAYERS[b] - 1; i >= 0; --i) {
+        for (int i = dense ? LAYERS[b] - 1 : -1; i >= 0; --i) {
             --l; C -= 32;
             const int ip = IDX.layer[l];
             Conv3BwdDataP bd[MMS_MAX_GROUP];
@@ -620,6 +633,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
             if (hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) return MMS_ERR_LAUNCH;
             side_pending = false;
         }
+        if (dp.lo_skip_trans && b == dp.b_lo) continue;        // the transition / stem below this block opens the next stage
         if (b > 0) {   // transition b-1 -> b
             const int t = b - 1, ip = IDX.trans[t], Kp = CTOT[t], Mp = P.M[t];
             int ms1 = M / 256; if (ms1 < 1) ms1 = 1; if (ms1 > 32) ms1 = 32;
@@ -672,7 +686,9 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
         // (the dwp regions are consecutive takes)
         static_assert(NLAYER == 58, "UnpackGroup is sized for DenseNet121");
         int l0 = 0, nl = 0;
-        for (int b = 0; b < NB; ++b) { if (b < dp.b_lo) l0 += LAYERS[b]; else if (b <= dp.b_hi) nl += LAYERS[b]; }
+        for (int b = 0; b < NB; ++b) { if (b < dp.b_lo) l0 += LAYERS[b]; else if (b <= dp.b_hi && !(dp.hi_trans_only && b == dp.b_hi)) nl += LAYERS[b]; }
+        if (dp.unpack == 2) { l0 = 0; nl = NLAYER; }
+        if (dp.unpack == 1 || nl == 0) return MMS_OK;
         const float* scr[MMS_MAX_GROUP];
         float* dwt[MMS_MAX_GROUP][NLAYER];
         float* const* dwp_[MMS_MAX_GROUP];
@@ -731,6 +747,30 @@ extern "C" int mms_dn121_forward_group(int ng, void* const* ws, int B, int D, in
     Ctx c[MMS_MAX_GROUP];
     FOR_G c[g] = Ctx{ws[g], x[g], (const float* const*)params[g], buffers ? buffers[g] : nullptr, out[g], nullptr, nullptr};
     return dn121_forward_impl(c, ng, B, D, H, W, ldo, train, s);
+}
+// Stage variants of the two group drivers (Dp above): the fold-group step split at a dense-block boundary so that its chip-filling
+// part (stem, early blocks, optimiser) and its latency-bound part (late blocks, heads) can run on different HIP streams -- e.g.
+// streams with disjoint CU masks (fold_group.py, MMS_CU_PARTITION).  flags: bit 0 = lo_skip_trans, bit 1 = hi_trans_only,
+// bits 2-3 = unpack mode.
+extern "C" int mms_dn121_forward_stage_group(int ng, void* const* ws, int B, int D, int H, int W, const float* const* x,
+                                             const void* const* const* params, const void* const* const* buffers, float* const* out,
+                                             int ldo, int train, int block_lo, int block_hi, hipStream_t s) {
+    if (ng < 1 || ng > MMS_MAX_GROUP || !ws || !x || !params || !out) return MMS_ERR_ARG;
+    Ctx c[MMS_MAX_GROUP];
+    FOR_G c[g] = Ctx{ws[g], x[g], (const float* const*)params[g], buffers ? buffers[g] : nullptr, out[g], nullptr, nullptr};
+    Dp dp; dp.f_lo = block_lo; dp.f_hi = block_hi;
+    return dn121_forward_impl(c, ng, B, D, H, W, ldo, train, s, dp);
+}
+extern "C" int mms_dn121_backward_stage_group(int ng, void* const* ws, int B, int D, int H, int W, const float* const* x,
+                                              const void* const* const* params, const float* const* dout, int lddout,
+                                              void* const* const* grads, int block_hi, int block_lo, int flags, hipStream_t s) {
+    if (ng < 1 || ng > MMS_MAX_GROUP || !ws || !x || !params || !dout || !grads) return MMS_ERR_ARG;
+    Ctx c[MMS_MAX_GROUP];
+    FOR_G c[g] = Ctx{ws[g], x[g], (const float* const*)params[g], nullptr, nullptr, dout[g], (float* const*)grads[g]};
+    Dp dp; dp.b_hi = block_hi; dp.b_lo = block_lo;
+    dp.lo_skip_trans = flags & 1; dp.hi_trans_only = (flags >> 1) & 1; dp.unpack = (flags >> 2) & 3;
+    if (dp.unpack > 2) return MMS_ERR_ARG;
+    return dn121_backward_impl(c, ng, B, D, H, W, lddout, s, nullptr, nullptr, nullptr, dp);
 }
 extern "C" int mms_dn121_backward_group(int ng, void* const* ws, int B, int D, int H, int W, const float* const* x,
                                         const void* const* const* params, const float* const* dout, int lddout,

@@ -220,6 +220,55 @@ def adam_params(p_, g, m, v, hyper, sumsq, step, skip_flag=None, adamw=False, ac
 _WORKER_STREAMS = {}
 
 
+def cu_partition():
+    """MMS_CU_PARTITION="k[,S]": split the step of a fold sub-group over two CU-masked HIP streams -- the chip-filling part (stem, dense
+    blocks before S, optimiser) on a stream that owns all but k CUs of every XCD, the latency-bound part (dense blocks S.. and the
+    heads) on a stream that owns the other k (fold_group.FoldGroupEngine).  -> (k, S) or None (unset / 0 = off).  S defaults to 2
+    (0-based: dense blocks 3-4 and the heads are the light part)."""
+    import os
+    v = os.environ.get("MMS_CU_PARTITION", "")
+    if not v or v.split(",")[0] in ("0", ""):
+        return None
+    f = v.split(",")
+    k, S = int(f[0]), (int(f[1]) if len(f) > 1 else 2)
+    if not (1 <= k <= 16 and 1 <= S <= 3):
+        raise ValueError("MMS_CU_PARTITION=k[,S]: 1 <= k <= 16 CUs per XCD for the light part, first light block 1 <= S <= 3")
+    return k, S
+
+
+_HIP = None
+_LIGHT = {}
+
+
+def _masked_stream(device, bits, ncu):
+    """HIP stream restricted to the CUs named by `bits` (hipExtStreamCreateWithCUMask; bit i = CU i // 8 of XCD i % 8 on MI355X,
+    tools/micro/cu_mask_probe.hip; an XCD without any bit set would run UNMASKED, so every mask here names CUs of all XCDs)."""
+    global _HIP
+    if _HIP is None:
+        _HIP = ctypes.CDLL("libamdhip64.so")
+    nwords = (ncu + 31) // 32
+    arr = (ctypes.c_uint32 * nwords)()
+    for b in bits:
+        arr[b // 32] |= 1 << (b % 32)
+    st = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = _HIP.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(nwords), arr)
+    if rc != 0 or not st.value:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+    return torch.cuda.ExternalStream(st.value, device=device)
+
+
+def light_partner(stream):
+    """The light-partition stream paired with a heavy-partition worker stream (None when the partition is off or the stream is not one
+    of worker_streams())."""
+    return _LIGHT.get(int(stream.cuda_stream))
+
+
+def light_cus(device):
+    part = cu_partition()
+    return None if part is None else 8 * part[0]
+
+
 def worker_streams(device, n):
     """The process-wide HIP streams that concurrent fold (sub-)groups step on: created once, in a fixed order, and shared by every
     consumer (training epoch, validation pass, the benchmark's legs).  HIP multiplexes streams onto a few hardware queues in the order
@@ -229,8 +278,24 @@ def worker_streams(device, n):
     device = torch.device(device)
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
     lst = _WORKER_STREAMS.setdefault(key, [])
+    part = cu_partition()
     while len(lst) < n:
-        lst.append(torch.cuda.Stream(device=device))
+        if part is None:
+            lst.append(torch.cuda.Stream(device=device))
+        else:       # CU-partitioned pair: the worker stream owns all but k CUs of every XCD, its partner the other k
+            import os
+            ncu = torch.cuda.get_device_properties(device).multi_processor_count
+            nl = 8 * part[0]
+            dbg = os.environ.get("MMS_CU_PARTITION_DEBUG", "")        # diagnosis: "nomask" = the split on two ordinary streams; "nosplit" = masked worker streams, unsplit step
+            if dbg == "nomask":
+                heavy, light = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
+            else:
+                drop = {8 * len(lst)} if "distinct" in dbg else set()      # diagnosis: a different mask per worker stream (one CU of XCD 0 fewer)
+                heavy = _masked_stream(device, [b for b in range(0, ncu - nl) if b not in drop], ncu)
+                light = _masked_stream(device, range(ncu - nl, ncu), ncu)
+            if "nosplit" not in dbg:
+                _LIGHT[int(heavy.cuda_stream)] = light
+            lst.append(heavy)
     return lst[:n]
 
 

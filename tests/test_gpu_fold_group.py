@@ -253,3 +253,42 @@ def test_lockstep_two_streams_matches_one(monkeypatch):
         assert res[0][1][f]["n_batches"] == res[1][1][f]["n_batches"] == res[2][1][f]["n_batches"] == 9
         for other in (1, 2):
             assert abs(res[0][0][f] - res[other][0][f]) <= 8e-2 * max(1.0, abs(res[0][0][f])), (f, other, res[0][0][f], res[other][0][f])
+
+
+@pytest.mark.parametrize("part", ["8,2", "4,1", "8,3"])
+def test_cu_partitioned_step_matches_unsplit(part, monkeypatch):
+    """MMS_CU_PARTITION: the step as three graphs (h1 | l | h2) on two CU-masked streams issues the launches of the unsplit step in the
+    same order -- same gradients after one step (atomic ordering aside), same bookkeeping after three."""
+    monkeypatch.setenv("MMS_SPLIT_WGS", "1000000"); monkeypatch.setenv("MMS_CONV1_KSPLIT", "0"); monkeypatch.setenv("MMS_CONV3_MT", "0"); monkeypatch.setenv("MMS_BIG_NG", "0"); monkeypatch.setenv("MMS_MS3_ROWS", "512"); monkeypatch.setenv("MMS_CONV3W_MT", "0"); monkeypatch.setenv("MMS_MS1_DIV", "1")
+    from multimodal_survival_prediction_amd import data, ops
+    from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
+    cls, G, B, dims, rna_dim = "PartialModalityNet", 2, 4, (64, 64, 32), 64
+    cohort = data.cohort_to(data.make_cohort(n=24, dims=dims, rna_dim=rna_dim, seed=3, complete=False), DEV)
+    cohort["valid"] = cohort["has_survival"].float()
+    base = _models(cls, G, rna_dim)
+    A = FoldGroupEngine([copy.deepcopy(m).to(DEV).train() for m in base])
+    Bg = FoldGroupEngine([copy.deepcopy(m).to(DEV).train() for m in base])
+    monkeypatch.setattr(ops, "_WORKER_STREAMS", {})          # the process-wide worker streams may exist already, unmasked
+    monkeypatch.setattr(ops, "_LIGHT", {})
+    rng = np.random.default_rng(0)
+    for it in range(3):
+        idx = np.stack([rng.permutation(24)[:B] for _ in range(G)])
+        monkeypatch.delenv("MMS_CU_PARTITION", raising=False)
+        A.train_step_indexed(cohort, idx, skip_if_unusable=False)
+        torch.cuda.synchronize()
+        monkeypatch.setenv("MMS_CU_PARTITION", part)
+        heavy = ops.worker_streams(DEV, 1)[0]
+        assert ops.light_partner(heavy) is not None
+        heavy.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(heavy):
+            Bg.train_step_indexed(cohort, idx, skip_if_unusable=False)
+        torch.cuda.synchronize()
+        assert any(k[0] == "train3" for GP in Bg.plans.values() for k in GP.graphs if isinstance(k, tuple)), "the partitioned path did not run"
+        if it == 0:
+            for g in range(G):
+                assert rel_err(Bg.engines[g].gflat, A.engines[g].gflat) <= 2e-5
+    for e in Bg.engines:
+        e.check_b4()
+    for a, b in zip(A.epoch_stats(), Bg.epoch_stats()):
+        assert a["n_batches"] == b["n_batches"] == 3 and a["n_usable"] == b["n_usable"]
+        assert abs(a["sum_loss"] - b["sum_loss"]) <= 5e-2 * max(1.0, abs(a["sum_loss"]))
