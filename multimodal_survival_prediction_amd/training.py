@@ -404,7 +404,9 @@ def _validate_lockstep_named(group, loaders, style, members, concurrent=1):
     hazards stay on the device and the host is synchronised ONCE, at the end (the reference and the eager path sync per batch).
     Bookkeeping as the reference's loops: final -- every batch counts, loss 0 when it has no event (final_multimodal.py:268-305);
     partial -- a batch counts, and its labelled patients enter the C-index, only when >= 2 of them are labelled and one has an event
-    (partial_modality_training.py:438-485)."""
+    (partial_modality_training.py:438-485); simple -- the same rule (simple_fusion.py:314-349 skips batches with < 2 labelled
+    patients before the forward and those without an event after it: in eval mode the skipped forward has no side effect), the
+    C-index through ConcordanceIndex as the eager path."""
     dev = group.device
     for g in members:
         group.engines[g].model.eval()
@@ -437,7 +439,7 @@ def _validate_lockstep_named(group, loaders, style, members, concurrent=1):
     for g, ld in zip(members, loaders):
         a = group.engines[g].acc_eval.tolist()
         if not order[g]:
-            out.append((0, 0.5))
+            out.append((0.0 if style == "simple" else 0, 0.5))
             continue
         lab = ld.c["label"]
         idx = torch.cat([i for i, _ in order[g]])
@@ -449,20 +451,20 @@ def _validate_lockstep_named(group, loaders, style, members, concurrent=1):
             keep = torch.cat([m & bool(u) for (_, m), u in zip(order[g], usable)])
             avg = a[0] / a[1] if a[1] > 0 else 0
         if not bool(keep.any()):
-            out.append((0, 0.5))
+            out.append((0.0 if style == "simple" else 0, 0.5))
             continue
         sel = idx[keep].to(lab.device)
         H, T, E = hz[g][keep.to(dev)], lab[sel, 0].to(dev), lab[sel, 1].to(dev)
-        out.append((avg, losses.calculate_cindex(H, E, T)))
+        out.append((avg, losses.ConcordanceIndex()(H, E.float(), T).item() if style == "simple" else losses.calculate_cindex(H, E, T)))
     return out
 
 
 def validate_lockstep(group, loaders, style, device, members=None, concurrent=1):
     """validate_<style> of the folds `members`, their eval forwards issued as fold-group launches.
-    -> per member (val_loss, c_index).  Loaders that NAME their batches (final / partial styles) take _validate_lockstep_named;
+    -> per member (val_loss, c_index).  Loaders that NAME their batches (final / partial / simple styles) take _validate_lockstep_named;
     concurrent = n: as train_epoch_lockstep, n sub-groups on n HIP streams (that path only)."""
     members = tuple(range(len(group))) if members is None else tuple(members)
-    if style in ("final", "partial") and all(getattr(ld, "lazy", False) for ld in loaders):
+    if style in ("final", "partial", "simple") and all(getattr(ld, "lazy", False) for ld in loaders):
         return _validate_lockstep_named(group, loaders, style, members, concurrent)
     acc = {g: dict(total=0.0, nb=0, hs=[], ts=[], es=[]) for g in members}
     for g in members:

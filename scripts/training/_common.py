@@ -74,7 +74,7 @@ def cv_lockstep(style, models, loaders, group_kw, num_epochs, patience, make_sch
     from multimodal_survival_prediction_amd.training import FusedOptimizer, train_epoch_lockstep, validate_lockstep
     group = FoldGroupEngine(models, **group_kw)
     for tl, vl in loaders:                     # cohort in HBM (or pinned host memory): name the batches, let the group gather them
-        for ld in ((tl, vl) if style in ("final", "partial") else (tl,)):      # (validate_lockstep's named-batch path: final / partial)
+        for ld in ((tl, vl) if style in ("final", "partial", "simple") else (tl,)):      # (validate_lockstep's named-batch path: final / partial / simple)
             if env_int("MMS_LAZY_BATCHES", 1) and (ld.c["image"].is_cuda or ld.c["image"].is_pinned()):
                 ld.lazy = True
                 ld.view = data_mod().gather_view(ld.c, with_valid=(style != "final"))

@@ -289,7 +289,7 @@ def test_lockstep_epoch_from_pinned_host_cohort_matches_device_cohort():
             assert_close(b, a, 1e-6, "running statistics")
 
 
-@pytest.mark.parametrize("style,cls", [("partial", "PartialModalityNet"), ("final", "MultiModalSurvivalNet")])
+@pytest.mark.parametrize("style,cls", [("partial", "PartialModalityNet"), ("final", "MultiModalSurvivalNet"), ("simple", "SimpleFusionModel")])
 def test_validate_lockstep_named_batches_match_eager_path(style, cls):
     """validate_lockstep over lazily NAMED batches (one gather + one graph per lock-step position, Cox values and accumulators on the
     device, one host sync at the end) against its eager path (batches materialised, per-batch losses through losses.cox_loss with a
@@ -303,7 +303,7 @@ def test_validate_lockstep_named_batches_match_eager_path(style, cls):
     group = FoldGroupEngine([p[1] for p in pairs], lr=0.0, weight_decay=1e-4, adamw=False, gate_entropy_weight=0.01)
     splits = [np.arange(22, cohort["n"]), np.arange(20, cohort["n"] - 1)]
     wv = style != "final"
-    eager = training.validate_lockstep(group, [data.BatchLoader(dev_cohort, s, 4, shuffle=False) for s in splits], style, DEV)
+    eager = training.validate_lockstep(group, [data.BatchLoader(dev_cohort, s, 4, shuffle=False, style=style) for s in splits], style, DEV)
     named = training.validate_lockstep(group, [data.BatchLoader(dev_cohort, s, 4, shuffle=False, lazy=True, with_valid=wv) for s in splits],
                                        style, DEV)
     again = training.validate_lockstep(group, [data.BatchLoader(dev_cohort, s, 4, shuffle=False, lazy=True, with_valid=wv) for s in splits],
