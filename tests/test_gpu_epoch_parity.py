@@ -74,15 +74,21 @@ def _cohort(n_extra_val=10, seed=5):
                 label=torch.tensor(np.stack([time, event], 1)), mask=torch.tensor(mask), has_survival=torch.tensor(has), n=n, dims=DIMS)
 
 
-def _pair(cls, seed, rna_dim=None):
+def _ref(cls, seed, rna_dim=None):
+    """The CPU oracle model of a (class, seed) pair -- also what tests/golden/generate_fp64_envelope.py builds (no GPU needed)."""
     from oracle import models as OM
-    from multimodal_survival_prediction_amd import models as HM
     torch.manual_seed(seed)
-    RNA = rna_dim or globals()["RNA"]
-    ref = getattr(OM, cls)(rna_dim=RNA, use_monai=True)
+    ref = getattr(OM, cls)(rna_dim=rna_dim or globals()["RNA"], use_monai=True)
     for m in ref.modules():
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
+    return ref
+
+
+def _pair(cls, seed, rna_dim=None):
+    from multimodal_survival_prediction_amd import models as HM
+    ref = _ref(cls, seed, rna_dim)
+    RNA = rna_dim or globals()["RNA"]
     net = getattr(HM, cls)(rna_dim=RNA)
     net.load_state_dict(ref.state_dict())
     for m in net.modules():
@@ -96,6 +102,74 @@ def _loaders(cohort, style, dev_cohort):
     tr, va = np.arange(22), np.arange(22, cohort["n"])
     mk = lambda c, idx: data.BatchLoader(c, idx, 4, shuffle=False, style=style)
     return mk(cohort, tr), mk(cohort, va), mk(dev_cohort, tr), mk(dev_cohort, va)
+
+
+# ---- fp64 legs of the envelope tests as fixtures ------------------------------------------------------------------------------
+# The fp64 run of the oracle loops is a pure CPU computation of the oracle (no HIP code in it) and, in fp64, reproducible to ~1e-12
+# on any machine: tests/golden/generate_fp64_envelope.py runs it once and commits the per-batch losses; the GPU tests read them
+# instead of spending a CPU epoch of DenseNet121 in fp64 each (the slowest part of the GPU suite).  A fixture is used only when its
+# fingerprint (initial weights, cohort, torch version) matches what the test has in hand; otherwise the leg is computed live.
+_FX_PATH = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden", "fp64_envelope.json")
+
+
+def _fingerprint(model64, tensors):
+    p = sum(float(q.detach().double().abs().sum()) for q in model64.parameters())
+    c = sum(float(torch.as_tensor(t).double().abs().sum()) for t in tensors)
+    return "%.10e|%.10e|torch %s" % (p, c, torch.__version__.split("+")[0])
+
+
+def _fp64_leg(key, fingerprint, compute):
+    import json
+    fx = {}
+    if _os.path.exists(_FX_PATH):
+        with open(_FX_PATH) as f:
+            fx = json.load(f)
+    e = fx.get(key)
+    if e is not None and e["fingerprint"] == fingerprint and not _os.environ.get("MMS_FP64_LIVE"):
+        print("fp64 leg", key, "from", _os.path.basename(_FX_PATH))
+        return e["value"]
+    print("fp64 leg", key, "computed live" + ("" if e is None else " (fixture fingerprint %s != %s)" % (e["fingerprint"], fingerprint)))
+    value = compute()
+    if _os.environ.get("MMS_WRITE_FP64_FIXTURES") == "1":
+        fx[key] = dict(fingerprint=fingerprint, value=value)
+        with open(_FX_PATH, "w") as f:
+            json.dump(fx, f, indent=1, sort_keys=True)
+    return value
+
+
+def _fp64_epoch_leg(style, lr, ref64, cohort, eps=1e-8):
+    """fp64 run of oracle/loops.train_epoch_<style> over the 22-patient training split: -> dict(want64=[...], pb64=[[...], ...])."""
+    from oracle import loops as OLP
+    from multimodal_survival_prediction_amd import data
+    cls, adamw, wd = STYLES[style]
+    opt64 = (torch.optim.AdamW(ref64.parameters(), lr=lr, weight_decay=wd, eps=eps) if adamw
+             else torch.optim.Adam(ref64.parameters(), lr=lr, weight_decay=wd, eps=eps))
+    pb64 = []
+    tr_c = data.BatchLoader(cohort, np.arange(22), 4, shuffle=False, style=style)
+    want64 = getattr(OLP, "train_epoch_" + style)(ref64, _cast_loader(tr_c, torch.float64), opt64, torch.device("cpu"),
+                                                  on_batch=lambda *v: pb64.append([float(x) for x in v]))
+    return dict(want64=[float(x) for x in (want64 if isinstance(want64, tuple) else (want64,))], pb64=pb64)
+
+
+def _config1_inputs(lr):
+    from multimodal_survival_prediction_amd import data
+    cohort = data.make_cohort(n=88, dims=(32, 32, 32), rna_dim=5005, seed=88, complete=True)      # (the volumes are zeros: small grid)
+    cohort["image"].zero_()
+    tr, va = data.kfold_indices(88, 3, seed=42)[0]
+    if lr != 0:
+        tr = tr[:32]          # the envelope variant needs three epochs (fp32 oracle, fp64 oracle, HIP): the first 8 batches of the fold keep the GPU suite short
+    return cohort, tr, va
+
+
+def _fp64_config1_leg(lr, ref64, cohort, tr, va):
+    from oracle import loops as OLP
+    from multimodal_survival_prediction_amd import data
+    cpu = torch.device("cpu")
+    mk = lambda c, idx: data.BatchLoader(c, idx, 4, shuffle=False, style="simple")
+    opt64 = torch.optim.AdamW(ref64.parameters(), lr=lr, weight_decay=1e-3)
+    want64 = OLP.train_epoch_simple(ref64, _cast_loader(mk(cohort, tr), torch.float64), opt64, cpu)
+    vw64 = OLP.validate_simple(ref64, _cast_loader(mk(cohort, va), torch.float64), cpu)
+    return dict(want64=float(want64), vw64=[float(vw64[0]), float(vw64[1])])
 
 
 def _cast_loader(loader, dtype):
@@ -168,10 +242,10 @@ def test_epoch_and_validate_match_oracle_loops(style, lr, eps=1e-8):
         for u, w_ in zip(gm, wm):
             assert abs(u - w_) <= 1e-4 * max(1.0, abs(w_)), (style, got, want)
     elif lr != 0:
-        opt64 = (torch.optim.AdamW(ref64.parameters(), lr=lr, weight_decay=wd, eps=eps) if adamw
-                 else torch.optim.Adam(ref64.parameters(), lr=lr, weight_decay=wd, eps=eps))
-        pb64 = []
-        want64 = getattr(OLP, "train_epoch_" + style)(ref64, _cast_loader(tr_c, torch.float64), opt64, cpu, on_batch=lambda *v: pb64.append(v))
+        leg = _fp64_leg("epoch-%s-%g" % (style, lr), _fingerprint(ref64, [cohort["image"], cohort["rnaseq"], cohort["label"]]),
+                        lambda: _fp64_epoch_leg(style, lr, ref64, cohort, eps))
+        pb64 = [tuple(v) for v in leg["pb64"]]
+        want64 = tuple(leg["want64"]) if len(leg["want64"]) > 1 else leg["want64"][0]
         assert len(pbh) == len(pb32) == len(pb64), (len(pbh), len(pb32), len(pb64))
         env, worst = 0.0, 0.0
         for i, (h, a, x) in enumerate(zip(pbh, pb32, pb64)):
@@ -342,10 +416,8 @@ def test_config1_simple_fusion_ct_stubbed(lr):
     from oracle import loops as OLP
     from multimodal_survival_prediction_amd import data, training
     from multimodal_survival_prediction_amd.training import FusedOptimizer
-    cohort = data.make_cohort(n=88, dims=(32, 32, 32), rna_dim=5005, seed=88, complete=True)      # (the volumes are zeros: small grid)
-    cohort["image"].zero_()
+    cohort, tr, va = _config1_inputs(lr)
     dev_cohort = data.cohort_to(cohort, DEV)
-    tr, va = data.kfold_indices(88, 3, seed=42)[0]
     ref, net = _pair("SimpleFusionModel", 31, rna_dim=5005)
     ref64 = copy.deepcopy(ref).double()
     cpu = torch.device("cpu")
@@ -361,9 +433,9 @@ def test_config1_simple_fusion_ct_stubbed(lr):
         assert got == pytest.approx(want, rel=1e-4)
         assert vg[0] == pytest.approx(vw[0], rel=1e-4) and abs(vg[1] - vw[1]) <= 1e-6          # identical concordant / discordant pair counts
         return
-    opt64 = torch.optim.AdamW(ref64.parameters(), lr=lr, weight_decay=1e-3)
-    want64 = OLP.train_epoch_simple(ref64, _cast_loader(mk(cohort, tr), torch.float64), opt64, cpu)
-    vw64 = OLP.validate_simple(ref64, _cast_loader(mk(cohort, va), torch.float64), cpu)
+    leg = _fp64_leg("config1-%g" % lr, _fingerprint(ref64, [cohort["rnaseq"], cohort["label"], torch.as_tensor(tr)]),
+                    lambda: _fp64_config1_leg(lr, ref64, cohort, tr, va))
+    want64, vw64 = leg["want64"], tuple(leg["vw64"])
     print("config 1 fp64: train", want64, "validate", vw64)
     for u, w_, v in ((got, want, want64), (vg[0], vw[0], vw64[0])):
         print("  fp64 %.7f | fp32 oracle %+.2e | HIP %+.2e" % (v, w_ - v, u - v))
