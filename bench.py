@@ -658,7 +658,8 @@ def main():
     ap.add_argument("--patients", type=int, default=608)
     ap.add_argument("--folds", type=int, default=5)
     ap.add_argument("--lockstep-streams", type=int, default=3,
-                    help="c3: the folds step as this many lock-step sub-groups on as many HIP streams (default 3: 5 folds = 2 + 2 + 1; round 2 ran 3 + 2)")
+                    help="c3: the folds step as this many lock-step sub-groups on as many HIP streams (default 3: 5 folds = 2 + 2 + 1; round 2 ran 3 + 2); "
+                         "more than 3 need GPU_MAX_HW_QUEUES >= streams + 1 in the environment, else two streams share a hardware queue")
     ap.add_argument("--validation-streams", type=int, default=2, help="c3: sub-groups / streams of the validation pass")
     ap.add_argument("--h2d", action="store_true", default=True, help="c3: also time the epoch with the cohort in pinned host memory")
     ap.add_argument("--no-h2d", dest="h2d", action="store_false")

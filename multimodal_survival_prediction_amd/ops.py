@@ -279,6 +279,14 @@ def worker_streams(device, n):
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
     lst = _WORKER_STREAMS.setdefault(key, [])
     part = cu_partition()
+    if n > len(lst):
+        import os, warnings
+        cap = int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4)        # ROCm's cap on hardware queues per device; the null stream takes one
+        if n + 1 > cap and part is None:
+            warnings.warn(f"{n} worker streams + the null stream on GPU_MAX_HW_QUEUES={cap} hardware queues: two streams will share a queue and "
+                          f"serialise (K = 5 epoch, four sub-groups: 1879 patients/s against 2696 with GPU_MAX_HW_QUEUES=5; "
+                          f"profiles/r03_cu_partition_experiments.txt).  Set GPU_MAX_HW_QUEUES >= {n + 1} before the process starts, "
+                          f"or use <= {cap - 1} streams.", RuntimeWarning, stacklevel=2)
     while len(lst) < n:
         if part is None:
             lst.append(torch.cuda.Stream(device=device))
