@@ -309,10 +309,8 @@ def run_config3(args, world, rank, dev):
                   f"{dt / n_ep:.3f} s per epoch", flush=True)
         D.barrier()
         return
-    def subs(n):        # training.train_epoch_lockstep: sub-group sizes of n fold models on this GPU
-        ns = 1 if conc <= 1 or n < 4 else min(conc, n)
-        return tuple(n // ns + (1 if h < n % ns else 0) for h in range(ns))
-    sub_groups = subs(len(mine)) if mine else subs(1)
+    from multimodal_survival_prediction_amd.training import subgroup_sizes
+    sub_groups = subgroup_sizes(len(mine) if mine else 1, conc)       # what training.train_epoch_lockstep stepped on this GPU
     import torch.distributed as tdist
     backend = tdist.get_backend() if tdist.is_initialized() else None
 
@@ -722,9 +720,9 @@ def main():
     args.steps = dflt[0] if args.steps is None else args.steps
     args.warmup = dflt[1] if args.warmup is None else args.warmup
     if args.roofline_only:
-        ns = min(args.lockstep_streams, args.folds) if args.folds >= 4 else 1
-        sub = (tuple(args.folds // ns + (1 if h < args.folds % ns else 0) for h in range(ns)) if args.workload == "c3" and ns > 1
-               else (max(1, min(args.fold_group, 10)) if args.workload != "c3" else args.folds,))
+        from multimodal_survival_prediction_amd.training import subgroup_sizes
+        sub = (subgroup_sizes(args.folds, args.lockstep_streams) if args.workload == "c3"
+               else (max(1, min(args.fold_group, 10)),))
         print(json.dumps(roofline_block(args.batch, tuple(args.volume), dev, sub)), flush=True)
         return
     if args.workload == "c5":

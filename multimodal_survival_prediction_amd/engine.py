@@ -23,6 +23,16 @@ from . import _lib, ops
 _S = _lib.structs
 
 
+
+def check_train_batch(B, bn_world=1):
+    """A training-mode forward on ONE patient: torch's BatchNorm1d (every head of the reference's models has one) raises
+    `ValueError: Expected more than 1 value per channel when training` -- e.g. a DataLoader tail of 1 in the reference's loops.
+    Same error here, instead of the kernels' bare MMS_ERR_ARG."""
+    if B * max(int(bn_world), 1) <= 1:
+        raise ValueError("Expected more than 1 value per channel when training: a batch of 1 patient cannot be normalised by the "
+                         "heads' BatchNorm1d layers (torch raises the same in the reference's train_epoch; choose a batch size / "
+                         "fold split without a tail of 1)")
+
 class _Lin:
     """One nn.Linear application with the neighbouring BN1d/ReLU/Dropout folded in (see InProlog in mmsurv.h)."""
 
@@ -579,6 +589,7 @@ class SurvivalEngine:
         overlapped with the backward; rank-local BatchNorm; rank-local or global_cox risk sets), or with sync_bn=True the exact
         global-batch step (`_ddp_step_syncbn`: SyncBN + replicated heads + global risk set; eager launches)."""
         B = rna.shape[0]
+        check_train_batch(B, ddp_world if sync_bn else 1)
         P = self.plan(B, tuple(ct.shape[-3:]) if ct is not None else None, bn_world=ddp_world if (sync_bn and ddp_world > 1) else 1)
         self.load_batch(P, ct, rna, clinical, mask, time, event, valid)
         if ddp_world > 1 and sync_bn:

@@ -14,7 +14,7 @@ import ctypes
 import torch
 
 from . import _lib, ops
-from .engine import SurvivalEngine
+from .engine import SurvivalEngine, check_train_batch
 
 _S = _lib.structs
 
@@ -284,6 +284,7 @@ class FoldGroupEngine:
             raise ValueError("one batch per member")
         has_enc = self.engines[0].prog["encoder"] is not None
         B = batches[0]["rna"].shape[0]
+        check_train_batch(B)
         dims = tuple(batches[0]["ct"].shape[-3:]) if has_enc else None
         for b in batches:
             if b["rna"].shape[0] != B or (has_enc and tuple(b["ct"].shape[-3:]) != dims):
@@ -334,6 +335,7 @@ class FoldGroupEngine:
         if idx.dim() != 2 or idx.shape[0] != len(members):
             raise ValueError("indices must be [len(members)][B]")
         B = idx.shape[1]
+        check_train_batch(B)
         dims = tuple(cohort["image"].shape[-3:]) if self.engines[0].prog["encoder"] is not None else None
         GP = self.plan(B, dims, members)
         self._gather_indexed(GP, cohort, idx)

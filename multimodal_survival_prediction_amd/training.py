@@ -349,7 +349,7 @@ def train_epoch_lockstep(group, loaders, style, members=None, concurrent=1):
                              skip_if_unusable=_SKIP_UNUSABLE[style])
 
     _run_subgroups(group, loaders, members, concurrent, advance)
-    if concurrent > 1 and len(members) >= 4:
+    if concurrent > 1:
         torch.cuda.synchronize()
     out = []
     for g in members:
@@ -364,19 +364,33 @@ def train_epoch_lockstep(group, loaders, style, members=None, concurrent=1):
     return out
 
 
+def subgroup_sizes(n_members, concurrent):
+    """Sizes of the fixed, contiguous sub-groups n_members lock-step fold models step as on `concurrent` HIP streams: near-equal, at
+    most one sub-group per stream, ONE group when there is a single stream or a single member.  Round 3 measurements (K-fold epoch,
+    patients/s): 5 members 2 + 2 + 1 on three streams 2740 (3 + 2 on two: 2640); 3 members 1 + 1 + 1: 2136, 2 + 1: 2056, one group of
+    3: 1973; 2 members 1 + 1: 1635, one group of 2: 1588 -- what a rank of the K-fold job holds at N = 2 / 4 GPUs.
+    MMS_MIN_SPLIT_MEMBERS (default 2): fewest members that are split at all."""
+    import os
+    min_split = int(os.environ.get("MMS_MIN_SPLIT_MEMBERS", "2"))
+    if concurrent <= 1 or n_members < max(min_split, 2):
+        return (n_members,)
+    nsub = min(int(concurrent), n_members)
+    base, extra = divmod(n_members, nsub)
+    return tuple(base + (1 if h < extra else 0) for h in range(nsub))
+
+
 def _run_subgroups(group, loaders, members, concurrent, advance):
-    """Lock-step iteration of the members' loaders: as one group, or (concurrent = n >= 2 and >= 4 members) as n fixed, contiguous
-    sub-groups of near-equal size, each stepping on its own HIP stream (5 folds on 2 streams: 3 + 2)."""
-    if concurrent <= 1 or len(members) < 4:
+    """Lock-step iteration of the members' loaders: as one group, or as the fixed, contiguous sub-groups of subgroup_sizes(), each
+    stepping on its own HIP stream (5 folds on 3 streams: 2 + 2 + 1)."""
+    sizes = subgroup_sizes(len(members), concurrent)
+    if len(sizes) <= 1:
         for pos in _lockstep(loaders, members):
             advance(pos)
         return
-    nsub = min(int(concurrent), len(members))
+    nsub = len(sizes)
     streams = ops.worker_streams(group.device, nsub)
-    base, extra = divmod(len(members), nsub)
     cuts, o = [], 0
-    for h in range(nsub):
-        n = base + (1 if h < extra else 0)
+    for n in sizes:
         cuts.append((members[o:o + n], loaders[o:o + n]))
         o += n
     cur = torch.cuda.current_stream()

@@ -292,3 +292,17 @@ def test_cu_partitioned_step_matches_unsplit(part, monkeypatch):
     for a, b in zip(A.epoch_stats(), Bg.epoch_stats()):
         assert a["n_batches"] == b["n_batches"] == 3 and a["n_usable"] == b["n_usable"]
         assert abs(a["sum_loss"] - b["sum_loss"]) <= 5e-2 * max(1.0, abs(a["sum_loss"]))
+
+
+def test_training_batch_of_one_raises_like_torch():
+    """A training step on ONE patient: the reference's loops die in torch's BatchNorm1d ("Expected more than 1 value per channel when
+    training"); the engines raise the same ValueError instead of a kernel argument error."""
+    from multimodal_survival_prediction_amd.engine import SurvivalEngine
+    from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
+    ms = [m.to(DEV).train() for m in _models("SimpleFusionModel", 2, 32)]
+    ct, rna = torch.zeros(1, 1, 32, 32, 32, device=DEV), torch.zeros(1, 32, device=DEV)
+    kw = dict(ct=ct, rna=rna, time=torch.ones(1, device=DEV), event=torch.ones(1, device=DEV), valid=torch.ones(1, device=DEV))
+    with pytest.raises(ValueError, match="more than 1 value per channel"):
+        SurvivalEngine(ms[0]).train_step(**kw)
+    with pytest.raises(ValueError, match="more than 1 value per channel"):
+        FoldGroupEngine(ms).train_step([kw, kw])
