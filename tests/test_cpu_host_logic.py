@@ -225,3 +225,18 @@ def test_lockstep_iteration_and_batch_rules():
     b["has_survival"] = [True, False, False]
     assert T._train_kwargs("simple", b) is None and T._train_kwargs("flexible", b) is None     # < 2 labelled: skipped before the forward
     assert T._SKIP_UNUSABLE == {"final": True, "partial": False, "simple": True, "flexible": True, "rnaseq": False}
+
+
+def test_subgroup_sizes_rule(monkeypatch):
+    """training.subgroup_sizes: near-equal contiguous sub-groups, one per stream at most, a single group on one stream / for one member
+    (the rule bench.py's labels and the roofline leg share with train_epoch_lockstep)."""
+    from multimodal_survival_prediction_amd.training import subgroup_sizes as s
+    monkeypatch.delenv("MMS_MIN_SPLIT_MEMBERS", raising=False)
+    assert s(5, 3) == (2, 2, 1) and s(5, 2) == (3, 2) and s(5, 1) == (5,)
+    assert s(3, 3) == (1, 1, 1) and s(3, 2) == (2, 1) and s(2, 3) == (1, 1) and s(1, 3) == (1,)
+    assert s(10, 2) == (5, 5) and s(4, 3) == (2, 1, 1)
+    for n in range(1, 11):
+        for c in range(1, 5):
+            assert sum(s(n, c)) == n and len(s(n, c)) <= c and max(s(n, c)) - min(s(n, c)) <= 1
+    monkeypatch.setenv("MMS_MIN_SPLIT_MEMBERS", "4")          # rounds 1-2: fewer than four members stay one group
+    assert s(3, 3) == (3,) and s(4, 3) == (2, 1, 1)
