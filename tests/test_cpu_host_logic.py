@@ -240,3 +240,24 @@ def test_subgroup_sizes_rule(monkeypatch):
             assert sum(s(n, c)) == n and len(s(n, c)) <= c and max(s(n, c)) - min(s(n, c)) <= 1
     monkeypatch.setenv("MMS_MIN_SPLIT_MEMBERS", "4")          # rounds 1-2: fewer than four members stay one group
     assert s(3, 3) == (3,) and s(4, 3) == (2, 1, 1)
+
+
+def test_cu_partition_env_and_batch_of_one(monkeypatch):
+    """Host-side parsing of MMS_CU_PARTITION (experimental CU-partitioned step) and the batch-of-one rule (torch's BatchNorm1d error)."""
+    from multimodal_survival_prediction_amd import ops
+    from multimodal_survival_prediction_amd.engine import check_train_batch
+    monkeypatch.delenv("MMS_CU_PARTITION", raising=False)
+    assert ops.cu_partition() is None and ops.light_cus("cpu") is None
+    monkeypatch.setenv("MMS_CU_PARTITION", "0")
+    assert ops.cu_partition() is None
+    monkeypatch.setenv("MMS_CU_PARTITION", "8")
+    assert ops.cu_partition() == (8, 2) and ops.light_cus("cpu") == 64
+    monkeypatch.setenv("MMS_CU_PARTITION", "4,1")
+    assert ops.cu_partition() == (4, 1)
+    for bad in ("17,2", "4,0", "4,4"):
+        monkeypatch.setenv("MMS_CU_PARTITION", bad)
+        with pytest.raises(ValueError):
+            ops.cu_partition()
+    check_train_batch(2); check_train_batch(1, bn_world=2)
+    with pytest.raises(ValueError, match="more than 1 value per channel"):
+        check_train_batch(1)
