@@ -192,9 +192,20 @@ static inline int take_out_features() { const int n = tl_out_features; tl_out_fe
 // bits 0-3 conv1 fwd of dense block 1-4 | 4-7 conv2 fwd | 8-11 conv2 bwd-data | 12-15 conv2 bwd-weight | 16-19 conv1 bwd-weight |
 // 20-23 conv1 bwd-data | 24-27 bn_bwd_apply | 28 stem fwd | 29 stem bwd | 30 transitions fwd | 31 transitions bwd | 32 / 33 block-4
 // persistent fwd / bwd | 34 weight pack | 35 gradient unpack
+// Honoured only together with MMS_DEBUG_SKIP_ACK=results-are-wrong, and announced on stderr once per process.
 static inline bool dbg_skip(int bit) {
     const char* e = getenv("MMS_DEBUG_SKIP");
-    return e && ((strtoull(e, nullptr, 0) >> bit) & 1ull);
+    if (!e) return false;
+    const unsigned long long m = strtoull(e, nullptr, 0);
+    if (m == 0) return false;
+    const char* ack = getenv("MMS_DEBUG_SKIP_ACK");
+    static std::once_flag once;
+    if (!ack || strcmp(ack, "results-are-wrong") != 0) {
+        std::call_once(once, [] { fprintf(stderr, "mmsurv: MMS_DEBUG_SKIP ignored (set MMS_DEBUG_SKIP_ACK=results-are-wrong to leave launches out of the step)\n"); });
+        return false;
+    }
+    std::call_once(once, [m] { fprintf(stderr, "mmsurv: MMS_DEBUG_SKIP=0x%llx -- TIMING ABLATION, launches are left out of every step: RESULTS ARE WRONG\n", m); });
+    return (m >> bit) & 1ull;
 }
 #define TRYS(bit, x) do { if (!dbg_skip(bit)) TRY(x); } while (0)
 #define TRY(x) do { int rc_ = (x); if (rc_ != MMS_OK) { fprintf(stderr, "mmsurv: %s -> %d (dn_net.hip:%d)\n", #x, rc_, __LINE__); return rc_; } } while (0)
