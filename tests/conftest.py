@@ -23,7 +23,7 @@ def golden_dir():
 # The GPU suite is ~7 minutes on the build boxes, but a third of it is CPU time of the oracle (DenseNet121-3D epochs in fp32 / fp64,
 # two-rank worker processes) and varies with the host: 416 s and 657 s were measured for the same commit on two leases.  So that a slow
 # host cannot push the run past whatever limit its caller has, the oracle-heavy tests run LAST (every test is self-contained: order
-# is free) and those that would START after MMS_GPU_SUITE_BUDGET_S seconds (default 450; 0 = no budget) are skipped with that reason
+# is free) and those that would START after MMS_GPU_SUITE_BUDGET_S seconds (default 480; 0 = no budget) are skipped with that reason
 # instead of run.  On a host as fast as the build boxes nothing is skipped.
 import time as _time
 
@@ -49,7 +49,7 @@ def pytest_collection_modifyitems(config, items):
 
 
 def pytest_runtest_setup(item):
-    budget = float(os.environ.get("MMS_GPU_SUITE_BUDGET_S", "450"))
+    budget = float(os.environ.get("MMS_GPU_SUITE_BUDGET_S", "480"))
     if budget > 0 and item.get_closest_marker("gpu") is not None and _heavy_rank(item) >= 0:
         elapsed = _time.monotonic() - _SUITE_T0
         if elapsed > budget:
