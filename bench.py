@@ -52,16 +52,16 @@ BLOCKS = ((6, 64), (12, 128), (24, 256), (16, 512))     # (layers, first-layer i
 
 # ---- roofline leg: the dense-layer 3x3x3 convolution family, timed live ------------------------------------------------
 def _stat_reps(M):                 # dn_net.hip make_plan: statistic-accumulator replicas of a level
-    r, rows = 1, int(os.environ.get("MMS_STAT_REP_ROWS", "8192"))
+    r, rows = 1, 8192
     while r < 8 and M // (2 * r) >= rows:
         r *= 2
     return r
 
 
 def _conv3_nsplit(M, ng, gd):      # dn_net.hip conv3_nsplit (scratch assumed large enough)
-    if os.environ.get("MMS_CONV3_SMALL", "") != "0" and 16 + 2 * (gd[1] * gd[2] + gd[2] + 1) <= 120:
+    if 16 + 2 * (gd[1] * gd[2] + gd[2] + 1) <= 120:
         return 1                   # dn_ops.h mms_conv3_small_jn: the all-tap 16-row kernels of dn_c3s.hip, no tap split
-    target = int(os.environ.get("MMS_SPLIT_WGS", "0")) or 256
+    target = 256                   # (default launch-shape options: MmsDnOpts all zero)
     tiles = ((M + 31) // 32) * ng
     if tiles >= 256 and tiles >= target:
         return 1
@@ -76,6 +76,13 @@ def _bwdw_msplit(M, G):            # dn_net.hip dn121_backward_impl: rows per we
     if G >= 4 and M > 1024 and not fills(-(-M // 1024) * G * 9) and fills(-(-M // 512) * G * 9):
         rows = 512
     return (M + rows - 1) // rows if M > 1024 else max((M + rows_s - 1) // rows_s, 1)
+
+
+def _bwdw_multitap(M, G):          # dn_bwd.hip conv3w_mt_ok: which of the two weight-gradient kernels a launch runs on
+    ms = _bwdw_msplit(M, G)
+    chunk = (-(-M // ms) + 31) & ~31
+    w = ms * G * 9
+    return chunk >= 512 and w * 10 >= -(-w // 768) * 768 * 9
 
 
 def measure_conv2_family(B, dims, device, G, reps=20):
@@ -93,8 +100,8 @@ def measure_conv2_family(B, dims, device, G, reps=20):
     D, H, W = dims
     gam, bet = torch.ones(128, device=device), torch.zeros(128, device=device)
     tot = {k: [0.0, 0.0, 0] for k in ("fwd", "bwd_data", "bwd_weight")}
-    b4_one = B * (D // 32) * (H // 32) * (W // 32) <= 16 and os.environ.get("MMS_PERSIST_B4", "1") != "0"
-    b4_bwd = b4_one and os.environ.get("MMS_PERSIST_B4", "2") not in ("0", "1")        # block 4's backward data path is one launch too
+    b4_one = B * (D // 32) * (H // 32) * (W // 32) <= 16 and ops.persistent_b4_fits(device, G)       # (fold_group.FoldGroupEngine._opts_arg)
+    b4_bwd = b4_one                                                                     # block 4's backward data path is one launch too
     w = torch.randn(32, 128, 3, 3, 3, device=device) * 0.03
     wpf, wpb = ops.pack_conv3(w)
     wff, wfb = ops.pack_conv3_frag(w)
@@ -103,7 +110,7 @@ def measure_conv2_family(B, dims, device, G, reps=20):
         M = B * gd[0] * gd[1] * gd[2]
         R = _stat_reps(M)
         ns = _conv3_nsplit(M, G, gd)
-        frag = i < 3 and os.environ.get("MMS_CONV3_SMALL", "") != "0" and 16 + 2 * (gd[1] * gd[2] + gd[2] + 1) <= 120      # dn_net.hip conv3_frag_block
+        frag = i < 3 and 16 + 2 * (gd[1] * gd[2] + gd[2] + 1) <= 120      # dn_net.hip conv3_frag_block
         coords = ops.init_coords(B, gd, device)
         keep, fw, bd, bw = [], [], [], []
         for _ in range(G):
@@ -133,11 +140,11 @@ def measure_conv2_family(B, dims, device, G, reps=20):
             if i == 3 and ((op == "fwd" and b4_one) or (op == "bwd_data" and b4_bwd)):
                 continue
             for _ in range(3):
-                _lib.check(fn(arr, G, ops.stream()), op)
+                _lib.check(fn(arr, G, None, ops.stream()), op)          # (launch-shape options: NULL = the defaults the step runs with)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(reps):
-                _lib.check(fn(arr, G, ops.stream()), op)
+                _lib.check(fn(arr, G, None, ops.stream()), op)
             e1.record()
             torch.cuda.synchronize()
             tot[op][0] += e0.elapsed_time(e1) * 1e-3 / reps * layers
@@ -146,9 +153,19 @@ def measure_conv2_family(B, dims, device, G, reps=20):
     return {op: (t / n, f / n, n) for op, (t, f, n) in tot.items()}
 
 
-_ROOF_NAMES = {"fwd": "mms_conv3_fwd_group = conv3_fwd_mt_kernel (block 1) / conv3s_fwd_kernel (blocks 2-4)",
-               "bwd_data": "mms_conv3_bwd_data_group = tile_gemm_kernel<Conv3BwdDataOp> (block 1) / conv3s_bwd_data_kernel (blocks 2-4)",
-               "bwd_weight": "mms_conv3_bwd_weight_group = conv3_bwdw_mt_kernel / tile_gemm_kernel<Conv3BwdWOp>"}
+def _roof_name(op, B, dims, group_sizes):
+    """The kernels rocprofv3 shows for the launches of an op (what the launchers in csrc/dn_fwd.hip / dn_bwd.hip pick at these sizes)."""
+    if op == "fwd":
+        return "mms_conv3_fwd_group = conv3_fwd_mt_kernel (block 1) / conv3s_fwd_kernel (blocks 2-4)"
+    if op == "bwd_data":
+        return "mms_conv3_bwd_data_group = tile_gemm_kernel<Conv3BwdDataOp> (block 1) / conv3s_bwd_data_kernel (blocks 2-4)"
+    D, H, W = dims
+    ms = [B * (D // 4 >> i) * (H // 4 >> i) * (W // 4 >> i) for i in range(4)]
+    mt = sorted({G for G in group_sizes for M in ms if _bwdw_multitap(M, G)})
+    name = "mms_conv3_bwd_weight_group = tile_gemm_kernel<Conv3BwdWOp>"
+    if mt:
+        name += " (conv3_bwdw_mt_kernel for block 1 of the %s-model launches)" % "/".join(map(str, mt))
+    return name
 
 
 def roofline_block(B, dims, dev, group_sizes):
@@ -170,7 +187,7 @@ def roofline_block(B, dims, dev, group_sizes):
             traffic = j[dom]["avg_hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError, TypeError):
         pass
-    return {"bound": "mfma", "kernel": _ROOF_NAMES[dom] + f"; {fam[dom][3]} launches per lock-step step and sub-group, sub-groups of {'+'.join(map(str, group_sizes))} fold models per launch",
+    return {"bound": "mfma", "kernel": _roof_name(dom, B, dims, group_sizes) + f"; {fam[dom][3]} launches per lock-step step and sub-group, sub-groups of {'+'.join(map(str, group_sizes))} fold models per launch",
             "achieved": f / t / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": f / t / 1e12 / PEAK_FP32_MFMA_TFLOPS,
             "traffic": traffic, "avg_launch_us": t / n * 1e6, "avg_flops_per_launch": f / n,
             "family": {op: {"avg_launch_us": v[0] / v[2] * 1e6, "launches_per_step_and_sub_group": v[3], "achieved": v[1] / v[0] / 1e12,
@@ -348,10 +365,11 @@ def run_config3(args, world, rank, dev):
 
     if rank == 0:
         out = {
-            "metric": "patients/sec per epoch (training epoch of the K-fold job: fwd + Cox + gate entropy + bwd + clip + Adam)",
+            "metric": "patients/sec per epoch (training epoch of the K-fold job: fwd + Cox + gate entropy + bwd + clip + Adam; HBM-resident "
+                      "cohort, batches gathered on the device inside the timed region -- the same epoch fed from pinned host memory over PCIe: config.h2d)",
             "value": value, "unit": "patients/s", "n_gpus": world, "steps": n_ep * steps_per_epoch,
             "warmup": n_warm * steps_per_epoch, "ms_per_step": dt / (n_ep * steps_per_epoch) * 1e3, "higher_is_better": True,
-            "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": None if world == 1 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": ("BASELINE config 3, N=1 leg" if world == 1 else "BASELINE config 3, one 5-fold CV sharded over %d GPUs" % world) +
                             " (the metric's configuration): %d synthetic patients with modality masks "
@@ -466,7 +484,7 @@ def run_config5(args, dev):
         print(f"timed-only (config 5): {B / dt:.1f} patients/s, {dt * 1e3:.3f} ms/step", flush=True)
         return
     out = {"metric": "patients/sec per epoch (training: fwd + Cox + bwd + AdamW)", "value": B / dt, "unit": "patients/s", "n_gpus": 1,
-           "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak",
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": None,
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"BASELINE config 5: RNASeqSurvivalModel (5005-1024-512-256-1), batch {B}, Cox over the {B}-patient risk set, "
                                   "AdamW lr 1e-4 wd 1e-3", "global_batch": B, "parallelism": "single GPU, one step graph",
@@ -517,8 +535,9 @@ def run_config2(args, world, rank, dev):
     cohort = data.cohort_to(cohort_cpu, dev)                      # resident in HBM before the timed region
     folds = data.kfold_indices(cohort["n"], 5, seed=42)
     ddp = args.mode == "ddp" and world > 1
-    F = 1 if ddp else max(1, args.concurrent_folds)
-    G = 1 if ddp else max(1, min(args.fold_group, 10))
+    one = args.mode == "ddp"               # config 4's per-rank problem: ONE model (at N = 1: the same step without its collectives)
+    F = 1 if one else max(1, args.concurrent_folds)
+    G = 1 if one else max(1, min(args.fold_group, 10))
     engines, groups, streams, orders = [], [], [], []          # engines/orders: one per fold model, index f * G + g
     for f in range(F):
         ms = []
@@ -597,7 +616,7 @@ def run_config2(args, world, rank, dev):
         out = {
             "metric": "patients/sec per epoch (training: fwd + Cox + bwd + clip + Adam)",
             "value": world * args.steps * B / dt, "unit": "patients/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if world > 1 else None,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE config 2: MultiModalSurvivalNet (DenseNet121-3D CT %dx%dx%d + RNA-seq 5005 + clinical), "
                                    "109 synthetic complete patients, 5-fold split, batch %d, Adam lr 1e-4 wd 1e-4, clip 1.0" % (dims + (B,)),
@@ -616,13 +635,37 @@ def run_config2(args, world, rank, dev):
     D.barrier()
 
 
+def _visible_gpus():
+    """GPUs this process could use, counted WITHOUT initialising HIP in the launcher parent (its children are started with fork + exec):
+    KFD topology nodes with SIMDs, capped by the *_VISIBLE_DEVICES lists.  0 when the box has no KFD (a CPU box)."""
+    import re
+    base, n = "/sys/class/kfd/kfd/topology/nodes", 0
+    try:
+        nodes = os.listdir(base)
+    except OSError:
+        nodes = []
+    for d in nodes:
+        try:
+            with open(os.path.join(base, d, "properties")) as fh:
+                m = re.search(r"^simd_count\s+(\d+)", fh.read(), re.M)
+        except OSError:
+            continue
+        if m and int(m.group(1)) > 0:
+            n += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip()]))
+    return n
+
+
 def _spawn_ranks(args, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks as children through torch.distributed.run (one process per GPU,
     rendezvous on 127.0.0.1) and return their exit code.  Refuses when fewer than N GPUs are visible -- a --gpus N request never
     yields an n_gpus = 1 line."""
     n = args.gpus
     if not (args.rendezvous_check or args.dry_launch):
-        ndev = torch.cuda.device_count()
+        ndev = _visible_gpus()
         if ndev < n and os.environ.get("MMS_ALLOW_SHARED_GPU") == "1" and os.environ.get("MMS_DIST_BACKEND") == "gloo":
             print(f"bench.py: REHEARSAL -- {n} ranks share {ndev} GPU(s) through gloo; the line is a liveness check, not a measurement", file=sys.stderr)
         elif ndev < n:
@@ -672,9 +715,10 @@ def main():
                          "rocprofv3 --stats summary of this command holds exactly the launches the live measurement times")
     ap.add_argument("--concurrent-folds", type=int, default=2, help="c2: fold groups trained concurrently per GPU")
     ap.add_argument("--fold-group", type=int, default=10, help="c2: fold models advanced in lock-step by ONE launch sequence")
-    ap.add_argument("--global-cox", action="store_true",
-                    help="mode ddp: Cox risk set over the whole global batch (all-gather of hazards/times/events, gradients "
-                         "summed) instead of rank-local risk sets")
+    ap.add_argument("--global-cox", action="store_true", default=True,
+                    help="mode ddp (default): Cox risk set over the whole global batch (all-gather of hazards/times/events, gradients "
+                         "summed) -- with rank-local BatchNorm the mode that can scale; --sync-bn is the exact-global-batch option")
+    ap.add_argument("--local-cox", dest="global_cox", action="store_false", help="mode ddp: rank-local risk sets (gradients averaged)")
     ap.add_argument("--sync-bn", action="store_true", help="mode ddp: BatchNorm statistics over the global batch (SyncBN)")
     ap.add_argument("--ddp-buckets", type=int, default=6, help="mode ddp: gradient all-reduce buckets (reverse-layer order)")
     ap.add_argument("--mode", choices=["fold", "ddp"], default="fold",
@@ -687,8 +731,8 @@ def main():
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # no launcher: become the launcher.  Nothing above has touched the GPU (torch.cuda.device_count() does not initialise it), so
-        # the ranks are plain children; this process only relays their output (rank 0's JSON line) and exit code.
+        # no launcher: become the launcher.  Nothing in this process touches the GPU (the devices are counted from the KFD topology in
+        # sysfs, not through HIP), so the ranks are plain children; this process only relays their output (rank 0's JSON line) and exit code.
         raise SystemExit(_spawn_ranks(args, sys.argv[1:]))
 
     from multimodal_survival_prediction_amd import distributed as D
@@ -714,6 +758,9 @@ def main():
     from multimodal_survival_prediction_amd import _build, _lib
     if not os.path.exists(_lib.lib_path()):
         _build.build()
+    if _lib.load_library().mms_ablation_build() and not args.timed_only:
+        raise SystemExit("bench.py: libmmsurv_hip.so is a timing-ablation build (MMS_CXXFLAGS=-DMMS_ABLATE_* / *_TIMING): only --timed-only "
+                         "diagnostics may run on it, never a bench line")
     if args.mode == "ddp":
         args.workload = "c2"
     dflt = {"c3": (1, 1), "c2": (240, 20), "c5": (200, 10)}[args.workload]

@@ -39,6 +39,39 @@ extern "C" {
 
 typedef struct Dims3 { int D; int H; int W; } Dims3;
 
+/* Launch-shape options of the DenseNet121 drivers (mms_dn121_*) and of the convolution entry points they launch.  Kernel selection is a
+ * function of the ARGUMENTS: the library reads no environment variable and keeps no per-process or per-thread setting.  A zero-filled
+ * block (or a NULL pointer wherever an `opts` argument is taken) selects the defaults -- what the shipped entry points and bench.py run;
+ * the other values exist for A/B measurements and for the parity tests that must reach one particular kernel form.  Never stored: the
+ * block is read during the call only.  Forward and backward calls on one workspace must pass the same values. */
+typedef struct MmsDnOpts {
+    int out_features;      /* width N of class_layers.out ([N][1024] weight, [N] bias; out / dout carry N columns), 0 = 128
+                              (R/scripts/training/simple_fusion.py:163 img_feature_dim); 1 <= N <= 4096 */
+    int persist_b4;        /* dense block 4 with <= 16 rows as ONE launch per pass (csrc/dn_b4.hip): 0 = both passes, 1 = forward only,
+                              -1 = per-layer launches.  The persistent launches need their 8 workgroups per model co-resident: a caller
+                              that may have more of them in flight than the chip has CUs passes -1 */
+    int split_wgs;         /* target workgroups of a tap-split conv2 launch, 0 = 256 */
+    int conv1_ksplit;      /* -1 = never split the conv1 K loop over workgroups (0 = by launch size) */
+    int conv1_small;       /* whole-K 16x16-tile conv1 forward (csrc/dn_c1s.hip): 0 = launches of <= c1s_max_wgs tiles, 1 = whenever the
+                              shape allows, -1 = never */
+    int c1s_max_wgs;       /* 0 = 640 */
+    int conv1_small_bwd;   /* whole-M conv1 backward-data with norm1's backward fused (csrc/dn_c1s.hip): 0 = up to 128 rows, -1 = never */
+    int fuse_apply_rows;   /* most rows for which norm1's backward rides in the conv1 backward-data launch, 0 = 128 (32 with
+                              conv1_small_bwd = -1) */
+    int conv3_small;       /* all-tap 16-row conv2 kernels for small grids (csrc/dn_c3s.hip): 0 = whenever the grid fits (one or two
+                              16-column output tiles per wave by launch size), 1 / 2 = force that number, -1 = never */
+    int c3s_ring;          /* weight-ring depth of their one-tile form: 0 = 6; 4, 6 or 9 */
+    int conv3_mt;          /* multi-tap conv2 forward: 0 = by launch size, 2 / 3 = force it on 64- / 32-row tiles, -1 = never */
+    int conv3_mt32_min;    /* fewest 32-row tiles for it, 0 = 256 */
+    int conv3w_mt;         /* multi-tap conv2 weight gradient: 0 = by launch size, 2 = force, -1 = never */
+    int big_ng;            /* -1 = tile shapes of the 1x1x1 kernels from ONE model's work (arithmetic independent of the group size) */
+    int batch_w;           /* -1 = weight-gradient launches per layer instead of batched over layers at the end of a block */
+    int ms3_rows;          /* rows per conv2 weight-gradient workgroup, 0 = by launch size */
+    int ms1_div;           /* divisor of the conv1 weight-gradient row chunks, 0 = by launch size */
+    int c0_nwg;            /* workgroups of the pooled conv0 weight-gradient kernel, 0 = default */
+    int c0f_nwg;           /* workgroups of the pooled conv0 forward kernel, 0 = default */
+} MmsDnOpts;
+
 /* BatchNorm parameter source. train=1: batch statistics from the fp64 accumulators; train=0: running stats.
  * (torch BatchNorm3d/1d, eps 1e-5, momentum 0.1: R/scripts/training/final_multimodal.py:77-96; MONAI norm="batch")
  * The 3x3x3-convolution entry points (mms_conv3_fwd*, mms_conv3_bwd_weight*) read the block with 16-byte vector loads: every array
@@ -360,6 +393,7 @@ typedef struct LinBigP {
     /* backward */
     const float* dy; int lddy;                      // gradient wrt y (after out_relu)
     float* dw; float* dbias; int msplit;            // accumulated (atomics); rows split over msplit workgroups
+    int core_only;                                  // 1: the 64x64 GEMM-core forms only, never the wide first-layer kernels (A/B measurements)
     float* dbn; int lddbn;                          // [M][K] gradient wrt BN output (has_bn) or wrt x (no BN)
     double* s1; double* s2;                         // [K] sum dbn, sum dbn * xhat (has_bn)
     float* dx; int lddx;                            // mms_bn1d_bwd_apply output
@@ -457,17 +491,16 @@ int mms_clip_adam(const AdamP* p, hipStream_t s);              /* clip by global
  *      params: 364 device pointers in torch named_parameters() order of MONAI DenseNet121;
  *      buffers: 121 x {running_mean, running_var, num_batches_tracked} in module order;
  *      grads: 364 device pointers, ACCUMULATED into (caller zeroes).  D,H,W multiples of 32.            */
+int mms_ablation_build(void);      /* 1: the library was built with a timing-ablation flag (MMS_CXXFLAGS=-DMMS_ABLATE_..., tools/ablate*.sh): launches
+                                      may be left out of the step -- diagnostics only; bench.py refuses to report a value from such a build */
 int mms_dn121_workspace_bytes(int B, int D, int H, int W, size_t* bytes);
 int mms_dn121_region(int B, int D, int H, int W, const char* name, int index, size_t* off, size_t* bytes);
 int mms_dn121_init(void* ws, int B, int D, int H, int W, const void* const* params, const void* const* buffers, hipStream_t s);
-/* Width N of class_layers.out ([N][1024] weight, [N] bias; out / dout carry N columns) for the NEXT mms_dn121_* forward / backward driver
- * call of the calling thread (one-shot: the call after that sees 128 again unless set anew), default 128
- * (R/scripts/training/simple_fusion.py:163 img_feature_dim).  1 <= n <= 4096. */
-int mms_dn121_out_features(int n);
+/* opts: launch-shape options incl. the width of class_layers.out (MmsDnOpts above; NULL = defaults). */
 int mms_dn121_forward(void* ws, int B, int D, int H, int W, const float* x, const void* const* params,
-                      const void* const* buffers, float* out, int ldo, int train, hipStream_t s);
+                      const void* const* buffers, float* out, int ldo, int train, const MmsDnOpts* opts, hipStream_t s);
 int mms_dn121_backward(void* ws, int B, int D, int H, int W, const float* x, const void* const* params,
-                       const float* dout, int lddout, void* const* grads, hipStream_t s);
+                       const float* dout, int lddout, void* const* grads, const MmsDnOpts* opts, hipStream_t s);
 /* ---- data-parallel (one process per GPU) variants of the single-model drivers --------------------------------------------
  * The reference is single-process (R/scripts/training/final_multimodal.py:52,345); BASELINE config 4 shards a global batch over
  * ranks.  Two things then leave the rank: (a) the gradients, all-reduced bucket by bucket while the backward still runs -- the
@@ -481,16 +514,17 @@ int mms_dn121_backward(void* ws, int B, int D, int H, int W, const float* x, con
 typedef int (*mms_sync_fn)(void* user, double* base, int nrep, long rep_stride, int ncols, long pair_stride, hipStream_t s);
 int mms_dn121_init_sync(void* ws, int B, int D, int H, int W, const void* const* params, const void* const* buffers, int bn_world, hipStream_t s);
 int mms_dn121_forward_sync(void* ws, int B, int D, int H, int W, const float* x, const void* const* params,
-                           const void* const* buffers, float* out, int ldo, int bn_world, mms_sync_fn hook, void* user, hipStream_t s);
+                           const void* const* buffers, float* out, int ldo, int bn_world, mms_sync_fn hook, void* user,
+                           const MmsDnOpts* opts, hipStream_t s);
 int mms_dn121_backward_stage(void* ws, int B, int D, int H, int W, const float* x, const void* const* params,
                              const float* dout, int lddout, void* const* grads, int block_hi, int block_lo,
-                             int bn_world, mms_sync_fn hook, void* user, hipStream_t s);
+                             int bn_world, mms_sync_fn hook, void* user, const MmsDnOpts* opts, hipStream_t s);
 int mms_head_bwd_sums(const HeadBwdP* p, hipStream_t s);         /* SyncBN split of mms_head_bwd: masked gradient stash + local sums */
 int mms_head_bwd_apply(const HeadBwdP* p, hipStream_t s);        /* ... norm5 backward with the (all-reduced) sums + class_layers.out gradients */
 /* same, with the per-layer weight-gradient kernels forked onto `side` (caller-created stream and two events): they
  * are off the critical path dslab -> dbn2 -> dbn1 -> dslab, so under graph capture they become parallel branches. */
 int mms_dn121_backward_mt(void* ws, int B, int D, int H, int W, const float* x, const void* const* params,
-                          const float* dout, int lddout, void* const* grads, hipStream_t s, hipStream_t side,
+                          const float* dout, int lddout, void* const* grads, const MmsDnOpts* opts, hipStream_t s, hipStream_t side,
                           hipEvent_t ev_fork, hipEvent_t ev_join);
 
 /* ---- preprocessing upstream of the path, on the GPU (replaces per-item numpy/scipy on the CPU) ----
@@ -507,20 +541,21 @@ int mms_rna_log_zscore(const float* counts, float* out, int n, int g, hipStream_
  * ng <= MMS_MAX_GROUP of them in lock-step: every *_group entry point takes an ARRAY of ng parameter blocks (one per
  * model, identical shapes, any pointers) and issues ONE launch whose grid carries the model index as an extra
  * dimension.  Per-model arithmetic is exactly that of the single-model entry point (which is the ng = 1 case of the
- * same kernel); a batch-4 step of one model cannot fill 256 CUs, a group of them can. */
-int mms_conv0_fwd_group(const Conv0FwdP* p, int ng, hipStream_t s);
+ * same kernel); a batch-4 step of one model cannot fill 256 CUs, a group of them can.
+ * The convolution entry points that have several kernel forms take the launch-shape options (MmsDnOpts; NULL = defaults). */
+int mms_conv0_fwd_group(const Conv0FwdP* p, int ng, const MmsDnOpts* opts, hipStream_t s);
 int mms_pool_fwd_group(const PoolFwdP* p, int ng, hipStream_t s);
-int mms_conv1_fwd_group(const Conv1FwdP* p, int ng, hipStream_t s);
-int mms_conv3_fwd_group(const Conv3FwdP* p, int ng, hipStream_t s);
+int mms_conv1_fwd_group(const Conv1FwdP* p, int ng, const MmsDnOpts* opts, hipStream_t s);
+int mms_conv3_fwd_group(const Conv3FwdP* p, int ng, const MmsDnOpts* opts, hipStream_t s);
 int mms_head_fwd_group(const HeadFwdP* p, int ng, hipStream_t s);
-int mms_conv3_bwd_data_group(const Conv3BwdDataP* p, int ng, hipStream_t s);
-int mms_conv3_bwd_weight_group(const Conv3BwdWP* p, int ng, hipStream_t s);
-int mms_conv1_bwd_data_group(const Conv1BwdP* p, int ng, hipStream_t s);
+int mms_conv3_bwd_data_group(const Conv3BwdDataP* p, int ng, const MmsDnOpts* opts, hipStream_t s);
+int mms_conv3_bwd_weight_group(const Conv3BwdWP* p, int ng, const MmsDnOpts* opts, hipStream_t s);
+int mms_conv1_bwd_data_group(const Conv1BwdP* p, int ng, const MmsDnOpts* opts, hipStream_t s);
 int mms_conv1_bwd_weight_group(const Conv1BwdP* p, int ng, hipStream_t s);
 int mms_bn_bwd_apply_group(const BnBwdApplyP* p, int ng, hipStream_t s);
 int mms_head_bwd_group(const HeadBwdP* p, int ng, hipStream_t s);
 int mms_pool_bwd_group(const PoolBwdP* p, int ng, hipStream_t s);
-int mms_conv0_bwd_weight_group(const Conv0BwdWP* p, int ng, hipStream_t s);
+int mms_conv0_bwd_weight_group(const Conv0BwdWP* p, int ng, const MmsDnOpts* opts, hipStream_t s);
 int mms_pack_conv3_table_group(const void* const* tables_dev, int ng, int nlayers, hipStream_t s);
 int mms_pack_conv3_table_group_ex(const void* const* tables_dev, int ng, int nlayers, uint64_t fragmask, hipStream_t s);   /* bit l set: layer l's two packs in MFMA-fragment order */
 int mms_bn_running_update_group(const void* const* tables_dev, int ng, int n, float momentum, hipStream_t s);
@@ -539,25 +574,10 @@ int mms_clip_adam_group(const AdamP* p, int ng, hipStream_t s);
 /* whole-encoder drivers: entry g of every array describes model g (arguments as mms_dn121_forward / _backward) */
 int mms_dn121_forward_group(int ng, void* const* ws, int B, int D, int H, int W, const float* const* x,
                             const void* const* const* params, const void* const* const* buffers, float* const* out,
-                            int ldo, int train, hipStream_t s);
+                            int ldo, int train, const MmsDnOpts* opts, hipStream_t s);
 int mms_dn121_backward_group(int ng, void* const* ws, int B, int D, int H, int W, const float* const* x,
                              const void* const* const* params, const float* const* dout, int lddout,
-                             void* const* const* grads, hipStream_t s);
-/* Stage variants (round 3): the group step split at dense-block boundaries so that its chip-filling part (stem, early blocks) and its
-   latency-bound part (late blocks, head) can be issued on different HIP streams, e.g. streams with disjoint CU masks
-   (hipExtStreamCreateWithCUMask; fold_group.py, MMS_CU_PARTITION).  The caller orders the stages with events.
-   forward_stage: dense blocks [block_lo, block_hi] (0-based) with their trailing transitions; the statistics zero-fill, the weight
-   packs and the stem belong to block 0, the head (which writes out) and the running-statistics update to block 3.
-   backward_stage: blocks block_hi .. block_lo as mms_dn121_backward_stage; flags bit 0: stop BEFORE the transition / stem below
-   block_lo; bit 1: of block_hi only the transition below it (its dense layers ran in the previous stage); bits 2-3: conv2-gradient
-   unpack -- 0 = the layers processed by this call, 1 = none, 2 = all 58 layers (use on the last stage).
-   Stages of one step in order reproduce mms_dn121_forward_group / _backward_group exactly (same launches, same order). */
-int mms_dn121_forward_stage_group(int ng, void* const* ws, int B, int D, int H, int W, const float* const* x,
-                                  const void* const* const* params, const void* const* const* buffers, float* const* out,
-                                  int ldo, int train, int block_lo, int block_hi, hipStream_t s);
-int mms_dn121_backward_stage_group(int ng, void* const* ws, int B, int D, int H, int W, const float* const* x,
-                                   const void* const* const* params, const float* const* dout, int lddout,
-                                   void* const* const* grads, int block_hi, int block_lo, int flags, hipStream_t s);
+                             void* const* const* grads, const MmsDnOpts* opts, hipStream_t s);
 
 #ifdef __cplusplus
 }

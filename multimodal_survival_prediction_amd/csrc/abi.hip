@@ -4,8 +4,16 @@
 
 #define SZ(T) if (strcmp(name, #T) == 0) return (int)sizeof(T);
 extern "C" int mms_abi_sizeof(const char* name) {
-    SZ(Dims3) SZ(BnSrc) SZ(BnBwd) SZ(Conv1FwdP) SZ(Conv3FwdP) SZ(Conv0FwdP) SZ(PoolFwdP) SZ(HeadFwdP)
+    SZ(Dims3) SZ(MmsDnOpts) SZ(BnSrc) SZ(BnBwd) SZ(Conv1FwdP) SZ(Conv3FwdP) SZ(Conv0FwdP) SZ(PoolFwdP) SZ(HeadFwdP)
     SZ(Conv3BwdDataP) SZ(Conv3BwdWP) SZ(Conv1BwdP) SZ(BnBwdApplyP) SZ(HeadBwdP) SZ(PoolBwdP) SZ(Conv0BwdWP) SZ(InProlog) SZ(LinearFwdP) SZ(LinearBwdP) SZ(GateP) SZ(CoxP) SZ(CindexP) SZ(AdamP) SZ(FbConvP) SZ(FbPoolP) SZ(GatherP) SZ(MixP) SZ(LinBigP)
     return -1;
 }
-extern "C" int mms_abi_version(void) { return 2; }
+extern "C" int mms_abi_version(void) { return 3; }
+// nonzero = a timing-ablation build (MMS_CXXFLAGS=-DMMS_ABLATE_* / -D*_TIMING): its numbers are diagnostics, its results may be wrong
+extern "C" int mms_ablation_build(void) {
+#if defined(MMS_ABLATE_STEP) || defined(MMS_ABLATE_SETUP) || defined(MMS_ABLATE_FLUSH) || defined(B4_TIMING) || defined(C3S_TIMING)
+    return 1;
+#else
+    return 0;
+#endif
+}

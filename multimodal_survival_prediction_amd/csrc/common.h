@@ -24,6 +24,9 @@ template <class P> static inline bool grp_fill(Grp<P>& a, const P* pp, int ng, i
     return true;
 }
 #define MMS_SINGLE(name, T) extern "C" int name(const T* p, hipStream_t s) { return name##_group(p, 1, s); }
+#define MMS_SINGLE_O(name, T) extern "C" int name(const T* p, hipStream_t s) { return name##_group(p, 1, nullptr, s); }      // (launch-shape options: defaults)
+// launch-shape options by value: a NULL pointer means "all defaults" (include/mmsurv.h: MmsDnOpts)
+static inline MmsDnOpts mms_opts(const MmsDnOpts* o) { return o ? *o : MmsDnOpts{}; }
 
 
 // Statistic accumulators may be replicated (fp64 atomics on one address serialise: 256 workgroups adding to the same 64

@@ -191,8 +191,9 @@ __global__ __launch_bounds__(256) void conv3_bwd_data_reduce16_kernel(const Grp<
     }
 }
 
-extern "C" int mms_conv3_bwd_data_group(const Conv3BwdDataP* pp, int ng, hipStream_t s) {
+extern "C" int mms_conv3_bwd_data_group(const Conv3BwdDataP* pp, int ng, const MmsDnOpts* opts, hipStream_t s) {
     if (!pp || ng < 1 || ng > MMS_MAX_GROUP) return MMS_ERR_ARG;
+    const MmsDnOpts o = mms_opts(opts);
     const Conv3BwdDataP& p = *pp;
     if (p.M <= 0 || p.lddz % 4 != 0) return MMS_ERR_ARG;
     for (int g = 1; g < ng; ++g) {
@@ -201,7 +202,7 @@ extern "C" int mms_conv3_bwd_data_group(const Conv3BwdDataP* pp, int ng, hipStre
             (q.partial == nullptr) != (p.partial == nullptr) || q.nsplit != p.nsplit) return MMS_ERR_ARG;
     }
     for (int g = 1; g < ng; ++g) if (pp[g].wfrag != p.wfrag) return MMS_ERR_ARG;
-    if (p.wfrag) return (!p.partial && mms_conv3_small_jn(p.M, ng, p.g)) ? mms_c3s_bwd_data(pp, ng, s) : MMS_ERR_ARG;   // fragment-ordered weights: the small-grid kernel only
+    if (p.wfrag) return (!p.partial && mms_conv3_small_jn(p.M, ng, p.g, o)) ? mms_c3s_bwd_data(pp, ng, o, s) : MMS_ERR_ARG;   // fragment-ordered weights: the small-grid kernel only
     if (p.partial) {
         if (p.nsplit < 1 || p.nsplit > 27 || (p.nsplit - 1) * ((27 + p.nsplit - 1) / p.nsplit) >= 27) return MMS_ERR_ARG;
         int rc = launch_tile_gemm<Conv3BwdDataOp<true>>(pp, ng, dim3((p.M + 31) / 32, 1, p.nsplit), s);
@@ -212,10 +213,10 @@ extern "C" int mms_conv3_bwd_data_group(const Conv3BwdDataP* pp, int ng, hipStre
         else MMS_LAUNCH(conv3_bwd_data_reduce_kernel, dim3((p.M + 3) / 4, 1, ng), dim3(256), 0, s, a);
         return mms_check_launch();
     }
-    if (mms_conv3_small_jn(p.M, ng, p.g)) return mms_c3s_bwd_data(pp, ng, s);      // small grids: 16-row tiles, all taps, no reduce launch
+    if (mms_conv3_small_jn(p.M, ng, p.g, o)) return mms_c3s_bwd_data(pp, ng, o, s);      // small grids: 16-row tiles, all taps, no reduce launch
     return launch_tile_gemm<Conv3BwdDataOp<false>>(pp, ng, dim3((p.M + 31) / 32, 1, 1), s);
 }
-MMS_SINGLE(mms_conv3_bwd_data, Conv3BwdDataP)
+MMS_SINGLE_O(mms_conv3_bwd_data, Conv3BwdDataP)
 
 // ------------------------------------------------------------------------------------------------------
 // conv3 backward-weight: dW[cout][cin][tap] += sum_m a2[m + off(tap)][cin] * dz[m][cout]
@@ -508,19 +509,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         __syncthreads();
     }
 }
-// MMS_CONV3W_MT: 0 = never, 2 = always (tests); default: chunks of >= 512 rows (16 steps to amortise the three-tap flush) whose
+// MmsDnOpts.conv3w_mt: -1 = never, 2 = always (tests); default: chunks of >= 512 rows (16 steps to amortise the three-tap flush) whose
 // 9-per-chunk grid fills >= 90 % of a whole number of rounds of the chip (3 workgroups x 256 CUs).  Measured per launch,
 // block 1 of a fold group (tools/run_mt.sh): 10 models x 8192 rows, 720 workgroups: 247 -> 216 us; 5 models on 512-row chunks,
 // 720: 135 -> 119 us; but 8 models (576 workgroups = 0.75 round): 199 -> 210 us, 4 models on 512-row chunks (576): 108 -> 116 us.
-static inline bool conv3w_mt_ok(int rows_per_chunk, int msplit, int ng) {
-    const char* e = getenv("MMS_CONV3W_MT");
-    if (e && e[0] == '0') return false;
-    if (e && e[0] == '2') return true;
+static inline bool conv3w_mt_ok(int rows_per_chunk, int msplit, int ng, const MmsDnOpts& o) {
+    if (o.conv3w_mt < 0) return false;
+    if (o.conv3w_mt == 2) return true;
     return rows_per_chunk >= 512 && mms_conv3w_mt_fills((long)msplit * ng * 9);
 }
 
-extern "C" int mms_conv3_bwd_weight_group(const Conv3BwdWP* pp, int ng, hipStream_t s) {
+extern "C" int mms_conv3_bwd_weight_group(const Conv3BwdWP* pp, int ng, const MmsDnOpts* opts, hipStream_t s) {
     if (!pp || ng < 1 || ng > MMS_MAX_GROUP) return MMS_ERR_ARG;
+    const MmsDnOpts o = mms_opts(opts);
     const Conv3BwdWP& p = *pp;
     if (p.M <= 0 || p.msplit <= 0 || p.lddz % 4 != 0) return MMS_ERR_ARG;
     if ((((p.M + p.msplit - 1) / p.msplit + 31) & ~31) > 1024) return MMS_ERR_ARG;    // row chunk must fit the LDS mask table
@@ -530,7 +531,7 @@ extern "C" int mms_conv3_bwd_weight_group(const Conv3BwdWP* pp, int ng, hipStrea
         if (q.M != p.M || q.msplit != p.msplit || q.lddz % 4 != 0 || q.g.D != p.g.D || q.g.H != p.g.H || q.g.W != p.g.W ||
             q.dw_tapmajor != p.dw_tapmajor) return MMS_ERR_ARG;
     }
-    if (conv3w_mt_ok(((p.M + p.msplit - 1) / p.msplit + 31) & ~31, p.msplit, ng)) {
+    if (conv3w_mt_ok(((p.M + p.msplit - 1) / p.msplit + 31) & ~31, p.msplit, ng, o)) {
         constexpr int smem = (2 * C3W_STAGE + 2 * 1024) * (int)sizeof(float);        // 53.3 KB: 3 workgroups per CU
         Grp<Conv3BwdWP> a;
         if (!grp_fill(a, pp, ng, 9 * p.msplit)) return MMS_ERR_ARG;
@@ -539,7 +540,7 @@ extern "C" int mms_conv3_bwd_weight_group(const Conv3BwdWP* pp, int ng, hipStrea
     }
     return launch_tile_gemm<Conv3BwdWOp>(pp, ng, dim3(1, 1, 27 * p.msplit), s);
 }
-MMS_SINGLE(mms_conv3_bwd_weight, Conv3BwdWP)
+MMS_SINGLE_O(mms_conv3_bwd_weight, Conv3BwdWP)
 
 // ------------------------------------------------------------------------------------------------------
 // 1x1 conv backward.  Shared pieces: dy(m, n) with the output-side BN backward folded in, a(m, k) recompute.
@@ -716,8 +717,9 @@ static bool conv1_bwd_same(const Conv1BwdP* pp, int ng, bool same_k = true) {
     }
     return true;
 }
-extern "C" int mms_conv1_bwd_data_group(const Conv1BwdP* pp, int ng, hipStream_t s) {
+extern "C" int mms_conv1_bwd_data_group(const Conv1BwdP* pp, int ng, const MmsDnOpts* opts, hipStream_t s) {
     if (!pp || ng < 1 || ng > MMS_MAX_GROUP) return MMS_ERR_ARG;
+    const MmsDnOpts o = mms_opts(opts);
     const Conv1BwdP& p = *pp;
     if (p.M <= 0 || p.K % 32 != 0 || p.N % 32 != 0 || p.ldx % 4 != 0 || p.lddy % 4 != 0) return MMS_ERR_ARG;
     if (p.has_bn_out && p.N != 128) return MMS_ERR_ARG;
@@ -726,14 +728,14 @@ extern "C" int mms_conv1_bwd_data_group(const Conv1BwdP* pp, int ng, hipStream_t
     if (p.fuse_dx) {      // norm1 backward fused into the epilogue: one workgroup must own every row of its 32 channels
         if (p.pool || p.M > 128 || p.fuse_lddx % 4 != 0) return MMS_ERR_ARG;
         bool small = true;
-        for (int g = 0; g < ng; ++g) small = small && mms_conv1_small_bwd_ok(pp[g]);
+        for (int g = 0; g < ng; ++g) small = small && mms_conv1_small_bwd_ok(pp[g], o);
         if (small) return mms_c1s_bwd(pp, ng, s);
         dim3 g(1, (p.K + 31) / 32, 1);
         return p.M <= 32 ? launch_tile_gemm<Conv1BwdDataOp<1, 1, 4, false>>(pp, ng, g, s)
                          : launch_tile_gemm<Conv1BwdDataOp<4, 1, 1, false>>(pp, ng, g, s);
     }
-    const int big_ng = getenv("MMS_BIG_NG") ? atoi(getenv("MMS_BIG_NG")) : 1;      // 1: count the whole group's tiles (0: tests that need ng-independent arithmetic)
-    const bool big = (long)p.M * p.K * (big_ng ? ng : 1) >= 256L * 64 * 64;
+    // tile shape from the whole group's work (MmsDnOpts.big_ng = -1: from one model's -- tests that need ng-independent arithmetic)
+    const bool big = (long)p.M * p.K * (o.big_ng < 0 ? 1 : ng) >= 256L * 64 * 64;
     if (big) {
         dim3 g((p.M + 63) / 64, (p.K + 63) / 64, 1);
         return p.pool ? launch_tile_gemm<Conv1BwdDataOp<2, 2, 1, true>>(pp, ng, g, s)
@@ -744,7 +746,7 @@ extern "C" int mms_conv1_bwd_data_group(const Conv1BwdP* pp, int ng, hipStream_t
     return p.pool ? launch_tile_gemm<Conv1BwdDataOp<1, 1, 4, true>>(pp, ng, g, s)
                   : launch_tile_gemm<Conv1BwdDataOp<1, 1, 4, false>>(pp, ng, g, s);
 }
-MMS_SINGLE(mms_conv1_bwd_data, Conv1BwdP)
+MMS_SINGLE_O(mms_conv1_bwd_data, Conv1BwdP)
 
 // ---- weight: dW[n][k] += sum_m dy[m][n] * a[m][k] ; rows n, cols k, reduce over m (split over grid.z)
 template <bool POOL>
@@ -1423,7 +1425,7 @@ __global__ __launch_bounds__(256) void conv0_bwd_weight_kernel(const Grp<Conv0Bw
   }
 }
 
-extern "C" int mms_conv0_bwd_weight_group(const Conv0BwdWP* pp, int ng, hipStream_t s) {
+extern "C" int mms_conv0_bwd_weight_group(const Conv0BwdWP* pp, int ng, const MmsDnOpts* opts, hipStream_t s) {
     if (!pp || ng < 1 || ng > MMS_MAX_GROUP) return MMS_ERR_ARG;
     const Conv0BwdWP& p = *pp;
     if (p.M <= 0 || p.msplit <= 0) return MMS_ERR_ARG;
@@ -1440,10 +1442,9 @@ extern "C" int mms_conv0_bwd_weight_group(const Conv0BwdWP* pp, int ng, hipStrea
     grp_fill(a, pp, ng, ng);
     // workgroups: 2 per CU (the second hides the first one's staging), but at least 8 boxes of 32 voxels each
     const long boxes = (long)ng * (p.M / 32);
-    const char* e_ = getenv("MMS_C0_NWG");
-    int nwg = e_ ? atoi(e_) : (boxes >= 256L * 8 ? 256 : (int)((boxes + 7) / 8));
+    int nwg = (opts && opts->c0_nwg > 0) ? opts->c0_nwg : (boxes >= 256L * 8 ? 256 : (int)((boxes + 7) / 8));
     if (nwg < 1) nwg = 1;
     MMS_LAUNCH(conv0_bwd_weight_kernel, dim3(nwg, 1, 1), dim3(256), 0, s, a);
     return mms_check_launch();
 }
-MMS_SINGLE(mms_conv0_bwd_weight, Conv0BwdWP)
+MMS_SINGLE_O(mms_conv0_bwd_weight, Conv0BwdWP)

@@ -250,15 +250,14 @@ __global__ __launch_bounds__(256) void conv1s_bwd_kernel(const Grp<Conv1BwdP> gr
 }  // namespace
 
 // Driver-internal launcher (argument checks beyond these are mms_conv1_bwd_data_group's).
-bool mms_conv1_small_bwd_ok(const Conv1BwdP& p) {
-    const char* e = getenv("MMS_CONV1_SMALL_BWD");
-    if (e && e[0] == '0') return false;
+bool mms_conv1_small_bwd_ok(const Conv1BwdP& p, const MmsDnOpts& o) {
+    if (o.conv1_small_bwd < 0) return false;
     return p.fuse_dx && !p.pool && p.has_bn_out && p.N == 128 && p.M >= 1 && p.M <= 128 && p.K % 16 == 0 && p.lddy % 4 == 0 && p.ldy % 4 == 0 &&
            (((uintptr_t)p.dyraw | (uintptr_t)p.y | (uintptr_t)p.w) & 15) == 0 && p.bn_in.train && p.bn_out.train;
 }
 int mms_c1s_bwd(const Conv1BwdP* pp, int ng, hipStream_t s) {
     const Conv1BwdP& p = *pp;
-    for (int g = 0; g < ng; ++g) if (!mms_conv1_small_bwd_ok(pp[g])) return MMS_ERR_ARG;
+    for (int g = 0; g < ng; ++g) if (!mms_conv1_small_bwd_ok(pp[g], MmsDnOpts{})) return MMS_ERR_ARG;
     const int rows16 = (p.M + 15) & ~15;
     const int smem = ((rows16 + 16) * C1SB_P + 5 * 128 + 64) * (int)sizeof(float) + 4 * 2 * 16 * (int)sizeof(double);
     static std::once_flag attr_once;

@@ -342,21 +342,21 @@ int launch_bwd(const Conv3BwdDataP* pp, int ng, hipStream_t s) {
 extern "C" int mms_c3s_timing_buffer(void* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(c3s_ts_buf), &buf, sizeof(buf)) == hipSuccess ? MMS_OK : MMS_ERR_LAUNCH; }
 #endif
 // Driver-internal launchers (argument checks are the callers': mms_conv3_fwd_group / mms_conv3_bwd_data_group).
-int mms_c3s_fwd(const Conv3FwdP* pp, int ng, hipStream_t s) {
-    const bool two = mms_conv3_small_jn(pp->M, ng, pp->g) == 2;
-    // Ring depth of the one-tile form (MMS_C3S_RING = 9 / 6 / 4, fragment-ordered weights only).  Alone on the GPU a launch is as fast with
+int mms_c3s_fwd(const Conv3FwdP* pp, int ng, const MmsDnOpts& o, hipStream_t s) {
+    const bool two = mms_conv3_small_jn(pp->M, ng, pp->g, o) == 2;
+    // Ring depth of the one-tile form (MmsDnOpts.c3s_ring = 9 / 6 / 4, fragment-ordered weights only).  Alone on the GPU a launch is as fast with
     // 9 taps in flight as with 6 (block 3: 9.6 us either way), but the 9-deep kernel holds 200 VGPRs against 168: beside two resident
     // workgroups of another stream's block-1 forward (164 VGPRs each) a SIMD has 176 registers left, so only the 6-deep one can be
     // placed there.  K = 5 epoch on three streams: 2709-2717 (9) / 2736-2751 (6) / 2736-2742 (4) patients/s.
-    static const int ring = getenv("MMS_C3S_RING") ? atoi(getenv("MMS_C3S_RING")) : 6;
+    const int ring = o.c3s_ring > 0 ? o.c3s_ring : 6;
     if (pp->wfrag && !two && ring == 6) return launch_fwd<1, 6, true>(pp, ng, s);
     if (pp->wfrag && !two && ring == 4) return launch_fwd<1, 4, true>(pp, ng, s);
     if (pp->wfrag) return two ? launch_fwd<2, 6, true>(pp, ng, s) : launch_fwd<1, 9, true>(pp, ng, s);
     return two ? launch_fwd<2, 6, false>(pp, ng, s) : launch_fwd<1, 9, false>(pp, ng, s);
 }
-int mms_c3s_bwd_data(const Conv3BwdDataP* pp, int ng, hipStream_t s) {
-    const bool two = mms_conv3_small_jn(pp->M, ng, pp->g) == 2;
-    static const int ring = getenv("MMS_C3S_RING") ? atoi(getenv("MMS_C3S_RING")) : 6;      // 140 / 112 / 96 VGPRs at 9 / 6 / 4
+int mms_c3s_bwd_data(const Conv3BwdDataP* pp, int ng, const MmsDnOpts& o, hipStream_t s) {
+    const bool two = mms_conv3_small_jn(pp->M, ng, pp->g, o) == 2;
+    const int ring = o.c3s_ring > 0 ? o.c3s_ring : 6;      // 140 / 112 / 96 VGPRs at 9 / 6 / 4
     if (pp->wfrag && !two && ring == 6) return launch_bwd<1, 6, true>(pp, ng, s);
     if (pp->wfrag && !two && ring == 4) return launch_bwd<1, 4, true>(pp, ng, s);
     if (pp->wfrag) return two ? launch_bwd<2, 6, true>(pp, ng, s) : launch_bwd<1, 9, true>(pp, ng, s);

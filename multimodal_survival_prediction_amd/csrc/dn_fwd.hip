@@ -131,8 +131,9 @@ struct Conv1FwdOp {
     }
 };
 
-extern "C" int mms_conv1_fwd_group(const Conv1FwdP* pp, int ng, hipStream_t s) {
+extern "C" int mms_conv1_fwd_group(const Conv1FwdP* pp, int ng, const MmsDnOpts* opts, hipStream_t s) {
     if (!pp || ng < 1 || ng > MMS_MAX_GROUP) return MMS_ERR_ARG;
+    const MmsDnOpts o = mms_opts(opts);
     const Conv1FwdP& p = *pp;
     if (p.K % 32 != 0 || p.K > 1024 || p.ldx % 4 != 0 || p.M <= 0) return MMS_ERR_ARG;
     if (p.pool && ((p.in.D | p.in.H | p.in.W) & 1)) return MMS_ERR_ARG;
@@ -141,13 +142,13 @@ extern "C" int mms_conv1_fwd_group(const Conv1FwdP* pp, int ng, hipStream_t s) {
         if (q.M != p.M || q.N != p.N || q.K != p.K || q.ldx % 4 != 0 || q.pool != p.pool || q.in.D != p.in.D || q.in.H != p.in.H ||
             q.in.W != p.in.W) return MMS_ERR_ARG;
     }
-    if (mms_conv1_small_ok(p, ng)) {      // few rows: 16 x 16 tiles over the whole K range from LDS-resident panels (dn_c1s.hip)
+    if (mms_conv1_small_ok(p, ng, o)) {      // few rows: 16 x 16 tiles over the whole K range from LDS-resident panels (dn_c1s.hip)
         for (int g = 0; g < ng; ++g) if (((uintptr_t)pp[g].x | (uintptr_t)pp[g].w) & 15) return MMS_ERR_ARG;
         return mms_c1s_fwd(pp, ng, s);
     }
     // big M: 64x64 tiles, no in-workgroup K split; small M: 32x32 tiles with the 4 waves splitting K
-    const int big_ng = getenv("MMS_BIG_NG") ? atoi(getenv("MMS_BIG_NG")) : 1;      // 1: count the whole group's tiles (0: tests that need ng-independent arithmetic)
-    const bool big = (long)p.M * p.N * (big_ng ? ng : 1) >= 256L * 64 * 64;
+    // tile shape from the whole group's work (MmsDnOpts.big_ng = -1: from one model's -- tests that need ng-independent arithmetic)
+    const bool big = (long)p.M * p.N * (o.big_ng < 0 ? 1 : ng) >= 256L * 64 * 64;
     if (big) {
         dim3 g((p.M + 63) / 64, (p.N + 63) / 64, 1);
         return p.pool ? launch_tile_gemm<Conv1FwdOp<2, 2, 1, true>>(pp, ng, g, s)
@@ -163,7 +164,7 @@ extern "C" int mms_conv1_fwd_group(const Conv1FwdP* pp, int ng, hipStream_t s) {
     return p.pool ? launch_tile_gemm<Conv1FwdOp<1, 1, 4, true>>(pp, ng, g, s)
                   : launch_tile_gemm<Conv1FwdOp<1, 1, 4, false>>(pp, ng, g, s);
 }
-MMS_SINGLE(mms_conv1_fwd, Conv1FwdP)
+MMS_SINGLE_O(mms_conv1_fwd, Conv1FwdP)
 
 // ------------------------------------------------------------------------------------------------------
 // 3x3x3 conv (pad 1): implicit GEMM, K = (tap, cin) = 27*128, one K-step per tap
@@ -422,14 +423,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C3M_TM == 6
 // Tile height by how well the launch fills whole rounds of the chip: 32-row tiles run 3 workgroups per CU (768 per round), 64-row tiles
 // 2 per CU (512 per round).  Measured on block 1 (8192 rows per model), G models per launch, us per launch, per-tap GEMM form / 32 / 64:
 // G=1 36/31/48, G=2 51/44/50, G=3 77/57/73, G=4 105/85/80, G=5 116/90/112, G=8 188/145/145, G=10 223/172/180 -- the 32-row form unless the
-// 64-row tiles fill their rounds clearly better (G = 4).  Below MMS_CONV3_MT32_MIN 32-row tiles: the per-tap GEMM form (Conv3FwdOp).
-// MMS_CONV3_MT: 0 = never, 2 = 64-row form whenever it applies, 3 = 32-row form whenever it applies (tests); returns the tile height or 0.
-static inline int conv3_mt_tile(int M, int ng, const Dims3& g) {
-    const char* e = getenv("MMS_CONV3_MT");
-    if (g.W + 1 > C3M_MAXHALO || (e && e[0] == '0')) return 0;
-    if (e && e[0] == '2') return M >= 1024 ? 64 : 0;
-    if (e && e[0] == '3') return M >= 64 ? 32 : 0;
-    static const int min32 = getenv("MMS_CONV3_MT32_MIN") ? atoi(getenv("MMS_CONV3_MT32_MIN")) : 256;
+// 64-row tiles fill their rounds clearly better (G = 4).  Below MmsDnOpts.conv3_mt32_min (256) 32-row tiles: the per-tap GEMM form (Conv3FwdOp).
+// MmsDnOpts.conv3_mt: -1 = never, 2 = 64-row form whenever it applies, 3 = 32-row form whenever it applies (tests); returns the tile height or 0.
+static inline int conv3_mt_tile(int M, int ng, const Dims3& g, const MmsDnOpts& o) {
+    if (g.W + 1 > C3M_MAXHALO || o.conv3_mt < 0) return 0;
+    if (o.conv3_mt == 2) return M >= 1024 ? 64 : 0;
+    if (o.conv3_mt == 3) return M >= 64 ? 32 : 0;
+    const int min32 = o.conv3_mt32_min > 0 ? o.conv3_mt32_min : 256;
     const long n32 = (long)((M + 31) / 32) * ng, n64 = (long)((M + 63) / 64) * ng;
     if (M < 1024 || n32 < min32) return 0;
     const double f32 = (double)n32 / (double)((n32 + 767) / 768 * 768), f64 = (double)n64 / (double)((n64 + 511) / 512 * 512);
@@ -448,8 +448,9 @@ static int launch_conv3_fwd_mt(const Conv3FwdP* pp, int ng, hipStream_t s) {
     return mms_check_launch();
 }
 
-extern "C" int mms_conv3_fwd_group(const Conv3FwdP* pp, int ng, hipStream_t s) {
+extern "C" int mms_conv3_fwd_group(const Conv3FwdP* pp, int ng, const MmsDnOpts* opts, hipStream_t s) {
     if (!pp || ng < 1 || ng > MMS_MAX_GROUP) return MMS_ERR_ARG;
+    const MmsDnOpts o = mms_opts(opts);
     const Conv3FwdP& p = *pp;
     if (p.M <= 0 || p.ldo % 4 != 0) return MMS_ERR_ARG;
     for (int g = 1; g < ng; ++g) {
@@ -458,9 +459,9 @@ extern "C" int mms_conv3_fwd_group(const Conv3FwdP* pp, int ng, hipStream_t s) {
             q.nsplit != p.nsplit) return MMS_ERR_ARG;
     }
     for (int g = 0; g < ng; ++g) if (!mms_bn_aligned16(pp[g].bn) || pp[g].wfrag != p.wfrag) return MMS_ERR_ARG;   // BatchNorm blocks are read with 16-byte vector loads
-    if (p.wfrag) return (!p.partial && mms_conv3_small_jn(p.M, ng, p.g)) ? mms_c3s_fwd(pp, ng, s) : MMS_ERR_ARG;       // fragment-ordered weights: the small-grid kernel only
-    if (const int tm = p.partial ? 0 : conv3_mt_tile(p.M, ng, p.g)) return tm == 64 ? launch_conv3_fwd_mt<64>(pp, ng, s) : launch_conv3_fwd_mt<32>(pp, ng, s);
-    if (!p.partial && mms_conv3_small_jn(p.M, ng, p.g)) return mms_c3s_fwd(pp, ng, s);      // small grids: 16-row tiles, all taps, no reduce launch
+    if (p.wfrag) return (!p.partial && mms_conv3_small_jn(p.M, ng, p.g, o)) ? mms_c3s_fwd(pp, ng, o, s) : MMS_ERR_ARG;       // fragment-ordered weights: the small-grid kernel only
+    if (const int tm = p.partial ? 0 : conv3_mt_tile(p.M, ng, p.g, o)) return tm == 64 ? launch_conv3_fwd_mt<64>(pp, ng, s) : launch_conv3_fwd_mt<32>(pp, ng, s);
+    if (!p.partial && mms_conv3_small_jn(p.M, ng, p.g, o)) return mms_c3s_fwd(pp, ng, o, s);      // small grids: 16-row tiles, all taps, no reduce launch
     if (p.partial) {
         if (p.nsplit < 1 || p.nsplit > 27) return MMS_ERR_ARG;
         const int tpw = (27 + p.nsplit - 1) / p.nsplit;
@@ -474,7 +475,7 @@ extern "C" int mms_conv3_fwd_group(const Conv3FwdP* pp, int ng, hipStream_t s) {
     }
     return launch_tile_gemm<Conv3FwdOp<false>>(pp, ng, dim3((p.M + 31) / 32, 1, 1), s);
 }
-MMS_SINGLE(mms_conv3_fwd, Conv3FwdP)
+MMS_SINGLE_O(mms_conv3_fwd, Conv3FwdP)
 
 // ------------------------------------------------------------------------------------------------------
 // conv0: Conv3d(1, 64, k7, s2, p3) as implicit GEMM, K = 343 taps
@@ -643,7 +644,7 @@ __global__ __launch_bounds__(256) void conv0_fwd_box_kernel(const Grp<Conv0FwdP>
     }
 }
 
-extern "C" int mms_conv0_fwd_group(const Conv0FwdP* pp, int ng, hipStream_t s) {
+extern "C" int mms_conv0_fwd_group(const Conv0FwdP* pp, int ng, const MmsDnOpts* opts, hipStream_t s) {
     if (!pp || ng < 1 || ng > MMS_MAX_GROUP) return MMS_ERR_ARG;
     const Conv0FwdP& p = *pp;
     if (p.M <= 0) return MMS_ERR_ARG;
@@ -659,13 +660,12 @@ extern "C" int mms_conv0_fwd_group(const Conv0FwdP* pp, int ng, hipStream_t s) {
     Grp<Conv0FwdP> a;
     grp_fill(a, pp, ng, ng);
     const long boxes = (long)ng * (p.M / 64);
-    const char* e_ = getenv("MMS_C0F_NWG");
-    int nwg = e_ ? atoi(e_) : (boxes >= 512L * 4 ? 512 : (boxes >= 256L * 2 ? 256 : (int)boxes));
+    int nwg = (opts && opts->c0f_nwg > 0) ? opts->c0f_nwg : (boxes >= 512L * 4 ? 512 : (boxes >= 256L * 2 ? 256 : (int)boxes));
     if (nwg < 1) nwg = 1;
     MMS_LAUNCH(conv0_fwd_box_kernel, dim3(nwg, 1, 1), dim3(256), 0, s, a);
     return mms_check_launch();
 }
-MMS_SINGLE(mms_conv0_fwd, Conv0FwdP)
+MMS_SINGLE_O(mms_conv0_fwd, Conv0FwdP)
 
 // ------------------------------------------------------------------------------------------------------
 // bn0 + relu + maxpool(3,2,1): one workgroup = 32 pooled voxels x 64 channels

@@ -53,11 +53,11 @@ bool make_plan(Plan& P, int B, int D, int H, int W) {
     for (int b = 1; b < NB; ++b) P.g[b] = Dims3{P.g[b - 1].D / 2, P.g[b - 1].H / 2, P.g[b - 1].W / 2};
     P.M0 = B * P.g0.D * P.g0.H * P.g0.W;
     for (int b = 0; b < NB; ++b) P.M[b] = B * P.g[b].D * P.g[b].H * P.g[b].W;
-    // statistic-accumulator replicas of a level: one per MMS_STAT_REP_ROWS rows (default 8192), at most 8 -- 65536 rows (the stem; block 1
+    // statistic-accumulator replicas of a level: one per 8192 rows, at most 8 -- 65536 rows (the stem; block 1
     // of 128x128x64 volumes) -> 8, block 1 of 64x64x32 volumes (8192 rows) -> 1.  Replicas relieve the producers' fp64 atomics but every
-    // consumer workgroup re-adds them in its prologue: measured on the K = 5 epoch, one replica per 2048 rows (block 1: 4) 2283-2296
-    // patients/s, per 512 rows 2170, per 4096 / 8192 rows or a single replica everywhere 2322-2325.
-    static const int rep_rows = getenv("MMS_STAT_REP_ROWS") ? atoi(getenv("MMS_STAT_REP_ROWS")) : 8192;
+    // consumer workgroup re-adds them in its prologue: measured on the K = 5 epoch (rounds 2-3), one replica per 2048 rows (block 1: 4) 2283-2296
+    // patients/s, per 512 rows 2170, per 4096 / 8192 rows or a single replica everywhere 2322-2325.  (Part of the workspace LAYOUT, so a constant.)
+    constexpr int rep_rows = 8192;
     auto reps = [](int M) { int r = 1; while (r < 8 && M / (2 * r) >= rep_rows) r *= 2; return r; };
     P.R0 = reps(P.M0);
     for (int b = 0; b < NB; ++b) P.R[b] = reps(P.M[b]);
@@ -159,55 +159,45 @@ extern "C" int mms_unpack_conv3_grads(const void*, int, hipStream_t);
 extern "C" int mms_unpack_conv3_grads_group(const float* const*, float* const* const*, int, int, hipStream_t);
 extern "C" int mms_bn_running_update_group(const void* const*, int, int, float, hipStream_t);
 extern "C" int mms_zero_regions_group(void* const*, int, size_t, hipStream_t);
-extern "C" int mms_conv0_fwd_group(const Conv0FwdP*, int, hipStream_t);
+extern "C" int mms_conv0_fwd_group(const Conv0FwdP*, int, const MmsDnOpts*, hipStream_t);
 extern "C" int mms_pool_fwd_group(const PoolFwdP*, int, hipStream_t);
-extern "C" int mms_conv1_fwd_group(const Conv1FwdP*, int, hipStream_t);
-extern "C" int mms_conv3_fwd_group(const Conv3FwdP*, int, hipStream_t);
+extern "C" int mms_conv1_fwd_group(const Conv1FwdP*, int, const MmsDnOpts*, hipStream_t);
+extern "C" int mms_conv3_fwd_group(const Conv3FwdP*, int, const MmsDnOpts*, hipStream_t);
 extern "C" int mms_head_fwd_group(const HeadFwdP*, int, hipStream_t);
-extern "C" int mms_conv3_bwd_data_group(const Conv3BwdDataP*, int, hipStream_t);
-extern "C" int mms_conv3_bwd_weight_group(const Conv3BwdWP*, int, hipStream_t);
-extern "C" int mms_conv1_bwd_data_group(const Conv1BwdP*, int, hipStream_t);
+extern "C" int mms_conv3_bwd_data_group(const Conv3BwdDataP*, int, const MmsDnOpts*, hipStream_t);
+extern "C" int mms_conv3_bwd_weight_group(const Conv3BwdWP*, int, const MmsDnOpts*, hipStream_t);
+extern "C" int mms_conv1_bwd_data_group(const Conv1BwdP*, int, const MmsDnOpts*, hipStream_t);
 extern "C" int mms_conv1_bwd_weight_group(const Conv1BwdP*, int, hipStream_t);
 extern "C" int mms_bn_bwd_apply_group(const BnBwdApplyP*, int, hipStream_t);
 extern "C" int mms_head_bwd_group(const HeadBwdP*, int, hipStream_t);
 extern "C" int mms_head_bwd_sums(const HeadBwdP*, hipStream_t);
 extern "C" int mms_head_bwd_apply(const HeadBwdP*, hipStream_t);
 extern "C" int mms_pool_bwd_group(const PoolBwdP*, int, hipStream_t);
-extern "C" int mms_conv0_bwd_weight_group(const Conv0BwdWP*, int, hipStream_t);
+extern "C" int mms_conv0_bwd_weight_group(const Conv0BwdWP*, int, const MmsDnOpts*, hipStream_t);
 
 // Width of class_layers.out (MONAI DenseNet121 `out_channels`): 128 in the three hot-path models (final_multimodal.py:66-71), a free
-// constructor argument (img_feature_dim) in simple_fusion.py:163 / flexible_multimodal.py.  A per-thread launch attribute rather than a
-// parameter of the seven driver entry points.  ONE-SHOT: it applies to the NEXT mms_dn121_* forward / backward driver call on the calling
-// thread only and falls back to 128 afterwards, so a caller that never sets it can never inherit another model's width.
-static thread_local int tl_out_features = 128;
-extern "C" int mms_dn121_out_features(int n) {
-    if (n < 1 || n > 4096) return MMS_ERR_ARG;
-    tl_out_features = n;
-    return MMS_OK;
-}
-static inline int take_out_features() { const int n = tl_out_features; tl_out_features = 128; return n; }
+// constructor argument (img_feature_dim) in simple_fusion.py:163 / flexible_multimodal.py -- MmsDnOpts.out_features (0 = 128).
+static inline int out_features_of(const MmsDnOpts& o) { return o.out_features > 0 ? o.out_features : 128; }
 
-// MMS_DEBUG_SKIP (64-bit mask, strtoull base 0): TIMING ABLATION ONLY -- the named launches are left out of the step (results are then
-// wrong); what the step gains without a kernel class bounds what optimising that class can gain (tools/ablate_step.sh).
+#ifdef MMS_ABLATE_STEP
+// TIMING-ABLATION BUILDS ONLY (MMS_CXXFLAGS=-DMMS_ABLATE_STEP, tools/ablate_step.sh; never in the shipped library): MMS_DEBUG_SKIP (64-bit
+// mask, strtoull base 0) leaves the named launches out of the step -- results are then wrong; what the step gains without a kernel class
+// bounds what optimising that class can gain.
 // bits 0-3 conv1 fwd of dense block 1-4 | 4-7 conv2 fwd | 8-11 conv2 bwd-data | 12-15 conv2 bwd-weight | 16-19 conv1 bwd-weight |
 // 20-23 conv1 bwd-data | 24-27 bn_bwd_apply | 28 stem fwd | 29 stem bwd | 30 transitions fwd | 31 transitions bwd | 32 / 33 block-4
-// persistent fwd / bwd | 34 weight pack | 35 gradient unpack
-// Honoured only together with MMS_DEBUG_SKIP_ACK=results-are-wrong, and announced on stderr once per process.
+// persistent fwd / bwd
 static inline bool dbg_skip(int bit) {
     const char* e = getenv("MMS_DEBUG_SKIP");
     if (!e) return false;
     const unsigned long long m = strtoull(e, nullptr, 0);
-    if (m == 0) return false;
-    const char* ack = getenv("MMS_DEBUG_SKIP_ACK");
     static std::once_flag once;
-    if (!ack || strcmp(ack, "results-are-wrong") != 0) {
-        std::call_once(once, [] { fprintf(stderr, "mmsurv: MMS_DEBUG_SKIP ignored (set MMS_DEBUG_SKIP_ACK=results-are-wrong to leave launches out of the step)\n"); });
-        return false;
-    }
-    std::call_once(once, [m] { fprintf(stderr, "mmsurv: MMS_DEBUG_SKIP=0x%llx -- TIMING ABLATION, launches are left out of every step: RESULTS ARE WRONG\n", m); });
+    if (m) std::call_once(once, [m] { fprintf(stderr, "mmsurv: MMS_DEBUG_SKIP=0x%llx -- TIMING ABLATION BUILD, launches are left out of every step: RESULTS ARE WRONG\n", m); });
     return (m >> bit) & 1ull;
 }
 #define TRYS(bit, x) do { if (!dbg_skip(bit)) TRY(x); } while (0)
+#else
+#define TRYS(bit, x) TRY(x)
+#endif
 #define TRY(x) do { int rc_ = (x); if (rc_ != MMS_OK) { fprintf(stderr, "mmsurv: %s -> %d (dn_net.hip:%d)\n", #x, rc_, __LINE__); return rc_; } } while (0)
 
 extern "C" int mms_dn121_workspace_bytes(int B, int D, int H, int W, size_t* bytes) {
@@ -301,17 +291,15 @@ extern "C" int mms_dn121_init_sync(void* ws, int B, int D, int H, int W, const v
 // Tap split of the 3x3x3 convolutions (forward and backward-data): a launch should put about `target` workgroups on the
 // 256 CUs.  One model's block with M <= 1024 rows has <= 32 row tiles, so its 27 taps are spread over workgroups and
 // summed by a reduce kernel; a fold group multiplies the tiles by ng and needs less (or no) splitting.
-static int split_target(int) {        // 256 workgroups.  (Round 1 used 864 for a single model: its blocks 2-4 took the 27-way split; they now run on the
-                                      // small-grid kernels, and block 1 of ONE model is faster unsplit on the multi-tap kernel: 890 -> 934 patients/s)
-    const char* e = getenv("MMS_SPLIT_WGS");      // tuning / test override, read at launch (i.e. graph-capture) time
-    const int v = e ? atoi(e) : 0;
-    return v > 0 ? v : 256;
+static int split_target(const MmsDnOpts& o) {        // 256 workgroups.  (Round 1 used 864 for a single model: its blocks 2-4 took the 27-way split; they now run on the
+                                                     // small-grid kernels, and block 1 of ONE model is faster unsplit on the multi-tap kernel: 890 -> 934 patients/s)
+    return o.split_wgs > 0 ? o.split_wgs : 256;      // (MmsDnOpts.split_wgs: tuning / test override)
 }
-static int conv3_nsplit(int M, int ng, long cap_rows, const Dims3& g) {
-    if (mms_conv3_small_jn(M, ng, g)) return 1;       // small grids: the all-tap kernels of dn_c3s.hip (no tap split, no reduce launch)
+static int conv3_nsplit(int M, int ng, long cap_rows, const Dims3& g, const MmsDnOpts& o) {
+    if (mms_conv3_small_jn(M, ng, g, o)) return 1;       // small grids: the all-tap kernels of dn_c3s.hip (no tap split, no reduce launch)
     const long tiles = (long)((M + 31) / 32) * ng;
-    if (tiles >= 256 && tiles >= split_target(ng)) return 1;
-    long ns = (split_target(ng) + tiles - 1) / tiles;
+    if (tiles >= 256 && tiles >= split_target(o)) return 1;
+    long ns = (split_target(o) + tiles - 1) / tiles;
     if (ns > 27) ns = 27;
     if (ns < 1) ns = 1;
     int tpw = (int)((27 + ns - 1) / ns);
@@ -321,18 +309,15 @@ static int conv3_nsplit(int M, int ng, long cap_rows, const Dims3& g) {
 
 // Which dense layers get their conv2 weights packed in MFMA-fragment order (Conv3FwdP.wfrag): those of blocks 1-3 whose launches go to the
 // small-grid kernels of dn_c3s.hip.  Block 4 keeps the classic packs (its persistent kernels, dn_b4.hip, read those; its per-layer fallback
-// path runs the small-grid kernels on them).  A function of the plan and MMS_CONV3_SMALL only, so forward and backward agree.
-static bool conv3_frag_block(const Plan& P, int b, int ng) { return b < NB - 1 && mms_conv3_small_jn(P.M[b], ng, P.g[b]) != 0; }
-static uint64_t conv3_fragmask(const Plan& P, int ng) {
+// path runs the small-grid kernels on them).  A function of the plan and MmsDnOpts.conv3_small only, so forward and backward agree.
+static bool conv3_frag_block(const Plan& P, int b, int ng, const MmsDnOpts& o) { return b < NB - 1 && mms_conv3_small_jn(P.M[b], ng, P.g[b], o) != 0; }
+static uint64_t conv3_fragmask(const Plan& P, int ng, const MmsDnOpts& o) {
     uint64_t m = 0;
     int l = 0;
     for (int b = 0; b < NB; ++b)
-        for (int i = 0; i < LAYERS[b]; ++i, ++l) if (conv3_frag_block(P, b, ng)) m |= 1ull << l;
+        for (int i = 0; i < LAYERS[b]; ++i, ++l) if (conv3_frag_block(P, b, ng, o)) m |= 1ull << l;
     return m;
 }
-
-// MMS_CONV1_KSPLIT=0: never split the conv1 K loop over workgroups (A/B tests; group-vs-single parity tests)
-static bool conv1_ksplit_on() { const char* e = getenv("MMS_CONV1_KSPLIT"); return !(e && e[0] == '0'); }
 
 // One model of a fold group as the drivers see it.
 struct Ctx {
@@ -344,40 +329,32 @@ struct Ctx {
 struct Dp {
     int bn_world = 1; mms_sync_fn hook = nullptr; void* user = nullptr;
     int b_hi = NB - 1, b_lo = 0;
-    // Stage splits of the fold-group step (mms_dn121_*_stage_group: a step's chip-filling part and its latency-bound part on
-    // different, CU-partitioned streams).  Forward: dense blocks [f_lo, f_hi] with their trailing transitions; the statistics
-    // zero-fill, the weight packs and the stem go with block 0, the head and the running-statistics update with block NB-1.
-    // Backward: hi_trans_only = of block b_hi only the transition BELOW it (its dense layers belong to the previous stage);
-    // lo_skip_trans = stop before the transition / stem below block b_lo; unpack: 0 = the conv2 gradients of the blocks whose dense
-    // layers this call processed, 1 = none, 2 = all layers (the caller ran every earlier stage).
-    int f_lo = 0, f_hi = NB - 1;
-    int hi_trans_only = 0, lo_skip_trans = 0, unpack = 0;
 };
 #define SYNC(ptr, nrep, rstride, ncols, pstride) do { if (dp.hook) { int rc_ = dp.hook(dp.user, (ptr), (nrep), (long)(rstride), (ncols), (long)(pstride), s); \
     if (rc_ != MMS_OK) { fprintf(stderr, "mmsurv: statistics all-reduce hook failed (dn_net.hip:%d)\n", __LINE__); return MMS_ERR_LAUNCH; } } } while (0)
 #define FOR_G for (int g = 0; g < ng; ++g)
 
 // Forward of ng models of identical shape in lock-step: every launch below carries all ng parameter blocks.
-static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W, int ldo, int train, hipStream_t s, const Dp& dp = Dp()) {
-    const int nout = take_out_features();
+static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W, int ldo, int train, const MmsDnOpts* opts, hipStream_t s, const Dp& dp = Dp()) {
+    const MmsDnOpts o = mms_opts(opts);
+    const int nout = out_features_of(o);
     Plan P;
-    if (!make_plan(P, B, D, H, W) || ng < 1 || ng > MMS_MAX_GROUP) return MMS_ERR_ARG;
+    if (!make_plan(P, B, D, H, W) || ng < 1 || ng > MMS_MAX_GROUP || nout > 4096 || ldo < nout) return MMS_ERR_ARG;
     if ((dp.hook || dp.bn_world > 1) && (ng != 1 || !train)) return MMS_ERR_ARG;
     const int bw = dp.bn_world;        // BatchNorm statistics are taken over bw * M rows (SyncBN: the hook has summed them over the ranks)
     FOR_G if (!cx[g].ws || !cx[g].x || !cx[g].prm || !cx[g].out) return MMS_ERR_ARG;
-    if (dp.f_lo < 0 || dp.f_hi >= NB || dp.f_lo > dp.f_hi) return MMS_ERR_ARG;
     const void* tabs[MMS_MAX_GROUP];
-    if (train && dp.f_lo == 0) {
+    if (train) {
         void* regs[MMS_MAX_GROUP];
         FOR_G regs[g] = at<void>(cx[g].ws, P.stats_begin);
         TRY(mms_zero_regions_group(regs, ng, P.stats_end - P.stats_begin, s));
     }
     FOR_G tabs[g] = at<void>(cx[g].ws, P.tab_pack);
-    if (dp.f_lo == 0) TRYS(34, mms_pack_conv3_table_group_ex(tabs, ng, NLAYER, conv3_fragmask(P, ng), s));
+    TRY(mms_pack_conv3_table_group_ex(tabs, ng, NLAYER, conv3_fragmask(P, ng, o), s));
     auto st = [&](void* ws, size_t off, int Ctot_, int coff, bool sq) -> double* {
         return train ? at<double>(ws, off) + (sq ? Ctot_ : 0) + coff : nullptr;
     };
-    if (dp.f_lo == 0) {   // stem
+    {   // stem
         Conv0FwdP c0[MMS_MAX_GROUP];
         PoolFwdP pf[MMS_MAX_GROUP];
         FOR_G {
@@ -390,18 +367,16 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
                              st(c.ws, P.st_slab[0], CTOT[0], 0, false), st(c.ws, P.st_slab[0], CTOT[0], 0, true)};
             pf[g].srep = P.R[0]; pf[g].sstride = 2 * CTOT[0];
         }
-        TRYS(28, mms_conv0_fwd_group(c0, ng, s));
+        TRYS(28, mms_conv0_fwd_group(c0, ng, &o, s));
         SYNC(at<double>(cx[0].ws, P.st_y0), P.R0, 2 * 64, 64, 64);
         TRYS(28, mms_pool_fwd_group(pf, ng, s));
         SYNC(at<double>(cx[0].ws, P.st_slab[0]), P.R[0], 2 * CTOT[0], 64, CTOT[0]);
     }
-    // block 4 as ONE launch (dn_b4.hip) when its rows fit a single 16-row MFMA tile (batch 4 on 64x64x32 volumes); MMS_PERSIST_B4=0: off
-    const char* epb = getenv("MMS_PERSIST_B4");
-    const bool b4_one = P.M[3] <= 16 && P.R[3] == 1 && !dp.hook && dp.bn_world == 1 && !(epb && epb[0] == '0');
+    // block 4 as ONE launch (dn_b4.hip) when its rows fit a single 16-row MFMA tile (batch 4 on 64x64x32 volumes); MmsDnOpts.persist_b4 = -1: off
+    const bool b4_one = P.M[3] <= 16 && P.R[3] == 1 && !dp.hook && dp.bn_world == 1 && o.persist_b4 >= 0;
     int l = 0;
     for (int b = 0; b < NB; ++b) {
         int C = C0[b];
-        if (b < dp.f_lo || b > dp.f_hi) { l += LAYERS[b]; continue; }      // another stage's block
         if (b == 3 && b4_one) {
             B4FwdP q[MMS_MAX_GROUP];
             void* regs[MMS_MAX_GROUP];
@@ -421,10 +396,10 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
             const int ip = IDX.layer[l];
             Conv1FwdP c1[MMS_MAX_GROUP];
             Conv3FwdP c3[MMS_MAX_GROUP];
-            const int ns3 = conv3_nsplit(P.M[b], ng, P.partial_rows, P.g[b]);
+            const int ns3 = conv3_nsplit(P.M[b], ng, P.partial_rows, P.g[b], o);
             // conv1 at small M is a chain of dependent K-steps on a handful of workgroups: one K-step per workgroup instead
             int ks1 = 1;
-            if (conv1_ksplit_on() && (long)((P.M[b] + 31) / 32) * 4 * ng <= 128 && C >= 256 && (long)((C + 127) / 128) * P.M[b] <= P.partial_rows)
+            if (o.conv1_ksplit >= 0 && (long)((P.M[b] + 31) / 32) * 4 * ng <= 128 && C >= 256 && (long)((C + 127) / 128) * P.M[b] <= P.partial_rows)
                 ks1 = (C + 127) / 128;
             FOR_G {
                 const Ctx& c = cx[g];
@@ -438,11 +413,11 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
                                   slab + C, CTOT[b], mk_bn(c.ws, P.st_y1[l], 128, c.prm, ip + 3, c.buf, IDX.bn_layer2[l], P.M[b] * bw, train, P.R[b]),
                                   st(c.ws, P.st_slab[b], CTOT[b], C, false), st(c.ws, P.st_slab[b], CTOT[b], C, true),
                                   ns3 > 1 ? at<float>(c.ws, P.partial) : nullptr, ns3};
-                c3[g].srep = P.R[b]; c3[g].sstride = 2 * CTOT[b]; c3[g].wfrag = conv3_frag_block(P, b, ng) ? 1 : 0;
+                c3[g].srep = P.R[b]; c3[g].sstride = 2 * CTOT[b]; c3[g].wfrag = conv3_frag_block(P, b, ng, o) ? 1 : 0;
             }
-            TRYS(b, mms_conv1_fwd_group(c1, ng, s));
+            TRYS(b, mms_conv1_fwd_group(c1, ng, &o, s));
             SYNC(at<double>(cx[0].ws, P.st_y1[l]), P.R[b], 2 * 128, 128, 128);
-            TRYS(4 + b, mms_conv3_fwd_group(c3, ng, s));
+            TRYS(4 + b, mms_conv3_fwd_group(c3, ng, &o, s));
             SYNC(at<double>(cx[0].ws, P.st_slab[b]) + C, P.R[b], 2 * CTOT[b], 32, CTOT[b]);
         }
         if (b < 3) {
@@ -456,11 +431,10 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
                                  st(c.ws, P.st_slab[b + 1], CTOT[b + 1], 0, false), st(c.ws, P.st_slab[b + 1], CTOT[b + 1], 0, true), 1, P.g[b]};
                 t[g].srep = P.R[b + 1]; t[g].sstride = 2 * CTOT[b + 1];
             }
-            TRYS(30, mms_conv1_fwd_group(t, ng, s));
+            TRYS(30, mms_conv1_fwd_group(t, ng, &o, s));
             SYNC(at<double>(cx[0].ws, P.st_slab[b + 1]), P.R[b + 1], 2 * CTOT[b + 1], CTOT[b] / 2, CTOT[b + 1]);
         }
     }
-    if (dp.f_hi < NB - 1) return MMS_OK;            // the head belongs to the stage that runs the last block
     HeadFwdP hd[MMS_MAX_GROUP];
     FOR_G {
         const Ctx& c = cx[g];
@@ -479,9 +453,11 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
 
 // Backward of the training-mode forward that last ran on these workspaces.  grads are ACCUMULATED into
 // (caller zeroes them, e.g. one hipMemsetAsync over a flat gradient buffer).  dout: [B][128] per model.
-static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W, int lddout, hipStream_t s, hipStream_t side,
+static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W, int lddout, const MmsDnOpts* opts, hipStream_t s, hipStream_t side,
                                hipEvent_t ev_fork, hipEvent_t ev_join, const Dp& dp = Dp()) {
-    const int nout = take_out_features();
+    const MmsDnOpts o = mms_opts(opts);
+    const int nout = out_features_of(o);
+    if (nout > 4096 || lddout < nout) return MMS_ERR_ARG;
     hipStream_t sw = side ? side : s;       // stream of the weight-gradient kernels
     bool side_pending = false;
     Plan P;
@@ -492,7 +468,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
     const int bnw = dp.bn_world;
     const bool sync = dp.hook != nullptr || bnw > 1;
     auto bbsrc = [&](void* ws, size_t off, int stride, int nrep) { return BnBwd{at<double>(ws, off), at<double>(ws, off) + stride, nrep, 2 * stride}; };
-    if (dp.b_hi == NB - 1 && !dp.hi_trans_only) {
+    if (dp.b_hi == NB - 1) {
         HeadBwdP hb[MMS_MAX_GROUP];
         FOR_G {
             const Ctx& c = cx[g];
@@ -514,15 +490,14 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
     // deferred and issued batched over layers -- as many (model, layer) members per launch as the group entry points carry --
     // once the block's chain is through: dz_l = dslab[:, C_l:C_l+32] is final from the moment layer l has been processed (earlier
     // layers only add into columns < C_l), y1 / the statistic accumulators are per layer, and dbn_mid is per layer there.
-    // MMS_BATCH_W=0 restores one launch pair per layer.
-    const char* ebw = getenv("MMS_BATCH_W");
-    const bool batch_w = !(ebw && ebw[0] == '0') && !side;      // (fine under SyncBN too: the sums the weight kernels read are all-reduced by then)
+    // MmsDnOpts.batch_w = -1 restores one launch pair per layer.
+    const bool batch_w = o.batch_w >= 0 && !side;      // (fine under SyncBN too: the sums the weight kernels read are all-reduced by then)
     Conv3BwdWP bwq[MMS_MAX_GROUP];
     Conv1BwdP c1q[MMS_MAX_GROUP];
     int nq = 0;
     auto flush_w = [&](int b) -> int {
         if (nq == 0) return MMS_OK;
-        TRYS(12 + b, mms_conv3_bwd_weight_group(bwq, nq, s));
+        TRYS(12 + b, mms_conv3_bwd_weight_group(bwq, nq, &o, s));
         TRYS(16 + b, mms_conv1_bwd_weight_group(c1q, nq, s));
         nq = 0;
         return MMS_OK;
@@ -535,19 +510,14 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
         const bool defer = batch_w && b > 0 && 2 * ng <= MMS_MAX_GROUP;
         // block 4 (<= 32 rows, one MFMA row tile): norm1's backward rides in conv1_bwd_data's epilogue (Conv1BwdP.fuse_dx), no
         // mms_bn_bwd_apply launch.  (Measured at 128 rows -- block 3, 128 x 32 tiles -- the fused form is slower than the two
-        // launches it replaces: 25 us against 8.8 + 6.7 us, rocprofv3 kernel stats; MMS_FUSE_APPLY=128 selects it anyway.)
+        // launches it replaces: 25 us against 8.8 + 6.7 us, rocprofv3 kernel stats; MmsDnOpts.fuse_apply_rows = 128 selects it anyway.)
         // Round 3: up to 128 rows the whole-M kernel of dn_c1s.hip (one workgroup per 16 channels, every row) takes the fused form --
-        // one launch instead of conv1_bwd_data + bn_bwd_apply, no statistic atomics; MMS_CONV1_SMALL_BWD=0 restores the rule above.
-        const char* efa = getenv("MMS_FUSE_APPLY");
-        const char* esb = getenv("MMS_CONV1_SMALL_BWD");
-        const int fuse_rows = efa ? atoi(efa) : ((esb && esb[0] == '0') ? 32 : 128);
+        // one launch instead of conv1_bwd_data + bn_bwd_apply, no statistic atomics; MmsDnOpts.conv1_small_bwd = -1 restores the rule above.
+        const int fuse_rows = o.fuse_apply_rows > 0 ? o.fuse_apply_rows : (o.conv1_small_bwd < 0 ? 32 : 128);
         const bool fuse_apply = M <= fuse_rows && M <= 128 && !sync;      // SyncBN: the sums leave the workgroup (all-reduce) before they are applied
         // block 4 with <= 16 rows: the whole data path of the block's backward as ONE launch (dn_b4.hip); the loop below then only queues
-        // the layers' weight-gradient members.  MMS_PERSIST_B4: 0 = off (both passes), 1 = forward only; default both.
-        const char* epb = getenv("MMS_PERSIST_B4");
-        const bool dense = !(dp.hi_trans_only && b == dp.b_hi);       // false: this block's dense layers ran in the previous stage
-        if (!dense) l -= LAYERS[b];
-        const bool b4_bwd = dense && b == 3 && M <= 16 && P.R[3] == 1 && !sync && dp.bn_world == 1 && defer && fuse_apply && !(epb && (epb[0] == '0' || epb[0] == '1'));
+        // the layers' weight-gradient members.  MmsDnOpts.persist_b4: -1 = off (both passes), 1 = forward only; default both.
+        const bool b4_bwd = b == 3 && M <= 16 && P.R[3] == 1 && !sync && dp.bn_world == 1 && defer && fuse_apply && o.persist_b4 == 0;
         if (b4_bwd) {
             B4BwdP q[MMS_MAX_GROUP];
             FOR_G {
@@ -562,25 +532,25 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
             }
             TRYS(33, mms_b4_bwd_group(q, ng, s));
         }
-        for (int i = dense ? LAYERS[b] - 1 : -1; i >= 0; --i) {
+        for (int i = LAYERS[b] - 1; i >= 0; --i) {
             --l; C -= 32;
             const int ip = IDX.layer[l];
             Conv3BwdDataP bd[MMS_MAX_GROUP];
             Conv3BwdWP bw[MMS_MAX_GROUP];
             Conv1BwdP c1[MMS_MAX_GROUP];
             BnBwdApplyP ap[MMS_MAX_GROUP];
-            const int ns3 = conv3_nsplit(M, ng, P.partial_rows, P.g[b]);
+            const int ns3 = conv3_nsplit(M, ng, P.partial_rows, P.g[b], o);
             // rows per weight-gradient workgroup: every chunk flushes 27 x 16 KB of fp32 atomics, so groups (which bring their own
             // parallelism) take chunks twice as long -- half the fabric writes (PMC WRITE_SIZE) for the same FLOPs
             const int ngw = defer ? MMS_MAX_GROUP / ng * ng : ng;        // (model, layer) members per weight-gradient launch
-            const char* e3 = getenv("MMS_MS3_ROWS");
-            int rows3 = e3 ? atoi(e3) : (ngw >= 4 ? 1024 : 512);
+            const bool e3 = o.ms3_rows > 0;
+            int rows3 = e3 ? o.ms3_rows : (ngw >= 4 ? 1024 : 512);
             const int rows3s = e3 ? 128 : (ngw >= 4 ? 256 : 128);
             // 512-row chunks when that (and not the default) puts the launch on the multi-tap kernel with a well-filled grid (5-model groups)
             if (!e3 && ngw >= 4 && M > 1024 && !mms_conv3w_mt_fills((long)((M + 1023) / 1024) * ngw * 9) && mms_conv3w_mt_fills((long)((M + 511) / 512) * ngw * 9)) rows3 = 512;
             int ms3 = M > 1024 ? (M + rows3 - 1) / rows3 : (M + rows3s - 1) / rows3s; if (ms3 < 1) ms3 = 1;
             int ms1 = M > 1024 ? M / 256 : M / 128; if (ms1 < 1) ms1 = 1; if (ms1 > 32) ms1 = 32;
-            { const char* e = getenv("MMS_MS1_DIV"); const int dv = e ? atoi(e) : (ngw >= 4 ? 2 : 1); if (dv > 1) { ms1 = ms1 / dv; if (ms1 < 1) ms1 = 1; } }   // groups: half the chunks (fewer atomic flushes)
+            { const int dv = o.ms1_div > 0 ? o.ms1_div : (ngw >= 4 ? 2 : 1); if (dv > 1) { ms1 = ms1 / dv; if (ms1 < 1) ms1 = 1; } }   // groups: half the chunks (fewer atomic flushes)
             FOR_G {
                 const Ctx& c = cx[g];
                 float* slab = at<float>(c.ws, P.slab[b]);
@@ -592,7 +562,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
                                       at<float>(c.ws, P.y1[l]), bn2, dmid,
                                       at<double>(c.ws, P.bb_y1[l]), at<double>(c.ws, P.bb_y1[l]) + 128,
                                       ns3 > 1 ? at<float>(c.ws, P.partial) : nullptr, ns3};
-                bd[g].srep = P.R[b]; bd[g].sstride = 2 * 128; bd[g].wfrag = conv3_frag_block(P, b, ng) ? 1 : 0;
+                bd[g].srep = P.R[b]; bd[g].sstride = 2 * 128; bd[g].wfrag = conv3_frag_block(P, b, ng, o) ? 1 : 0;
                 bw[g] = Conv3BwdWP{at<float>(c.ws, P.y1[l]), at<int>(c.ws, P.coords[b]), P.g[b], M, bn2, dslab + C, CTOT[b],
                                    at<float>(c.ws, P.dwp[l]), ms3, 1};
                 Conv1BwdP& q = c1[g];
@@ -617,7 +587,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
                 side_pending = false;
             }
             if (!b4_bwd) {
-                TRYS(8 + b, mms_conv3_bwd_data_group(bd, ng, s));
+                TRYS(8 + b, mms_conv3_bwd_data_group(bd, ng, &o, s));
                 SYNC(at<double>(cx[0].ws, P.bb_y1[l]), P.R[b], 2 * 128, 128, 128);
             }
             if (defer) {
@@ -627,7 +597,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
                 if (side) {
                     if (hipEventRecord(ev_fork, s) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess) return MMS_ERR_LAUNCH;
                 }
-                TRYS(12 + b, mms_conv3_bwd_weight_group(bw, ng, sw));
+                TRYS(12 + b, mms_conv3_bwd_weight_group(bw, ng, &o, sw));
                 TRYS(16 + b, mms_conv1_bwd_weight_group(c1, ng, sw));
                 if (side) {
                     if (hipEventRecord(ev_join, side) != hipSuccess) return MMS_ERR_LAUNCH;
@@ -635,7 +605,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
                 }
             }
             if (b4_bwd) continue;
-            TRYS(20 + b, mms_conv1_bwd_data_group(c1, ng, s));
+            TRYS(20 + b, mms_conv1_bwd_data_group(c1, ng, &o, s));
             SYNC(at<double>(cx[0].ws, P.bb_in[l]), P.R[b], 2 * 1024, C, 1024);
             if (!fuse_apply) TRYS(24 + b, mms_bn_bwd_apply_group(ap, ng, s));
         }
@@ -644,7 +614,6 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
             if (hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) return MMS_ERR_LAUNCH;
             side_pending = false;
         }
-        if (dp.lo_skip_trans && b == dp.b_lo) continue;        // the transition / stem below this block opens the next stage
         if (b > 0) {   // transition b-1 -> b
             const int t = b - 1, ip = IDX.trans[t], Kp = CTOT[t], Mp = P.M[t];
             int ms1 = M / 256; if (ms1 < 1) ms1 = 1; if (ms1 > 32) ms1 = 32;
@@ -669,7 +638,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
                                     Mp, Kp, bnt, bbsrc(c.ws, P.bb_tr[t], 1024, P.R[t]), 0, c.grd[ip], c.grd[ip + 1]};
             }
             TRYS(31, mms_conv1_bwd_weight_group(c1, ng, s));
-            TRYS(31, mms_conv1_bwd_data_group(c1, ng, s));
+            TRYS(31, mms_conv1_bwd_data_group(c1, ng, &o, s));
             SYNC(at<double>(cx[0].ws, P.bb_tr[t]), P.R[t], 2 * 1024, Kp, 1024);
             TRYS(31, mms_bn_bwd_apply_group(ap, ng, s));
         } else {       // stem
@@ -687,7 +656,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
             }
             TRYS(29, mms_pool_bwd_group(pb, ng, s));
             SYNC(at<double>(cx[0].ws, P.bb_y0), P.R0, 2 * 64, 64, 64);
-            TRYS(29, mms_conv0_bwd_weight_group(cw, ng, s));
+            TRYS(29, mms_conv0_bwd_weight_group(cw, ng, &o, s));
         }
     }
     if (side && side_pending) {
@@ -697,9 +666,8 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
         // (the dwp regions are consecutive takes)
         static_assert(NLAYER == 58, "UnpackGroup is sized for DenseNet121");
         int l0 = 0, nl = 0;
-        for (int b = 0; b < NB; ++b) { if (b < dp.b_lo) l0 += LAYERS[b]; else if (b <= dp.b_hi && !(dp.hi_trans_only && b == dp.b_hi)) nl += LAYERS[b]; }
-        if (dp.unpack == 2) { l0 = 0; nl = NLAYER; }
-        if (dp.unpack == 1 || nl == 0) return MMS_OK;
+        for (int b = 0; b < NB; ++b) { if (b < dp.b_lo) l0 += LAYERS[b]; else if (b <= dp.b_hi) nl += LAYERS[b]; }
+        if (nl == 0) return MMS_OK;
         const float* scr[MMS_MAX_GROUP];
         float* dwt[MMS_MAX_GROUP][NLAYER];
         float* const* dwp_[MMS_MAX_GROUP];
@@ -709,85 +677,61 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
             for (int i = 0; i < nl; ++i) dwt[g][i] = cx[g].grd[IDX.layer[l0 + i] + 5];
             dwp_[g] = dwt[g];
         }
-        TRYS(35, mms_unpack_conv3_grads_group(scr, dwp_, ng, nl, s));
+        TRY(mms_unpack_conv3_grads_group(scr, dwp_, ng, nl, s));
     }
     return MMS_OK;
 }
 
 extern "C" int mms_dn121_forward(void* ws, int B, int D, int H, int W, const float* x, const void* const* params_,
-                                 const void* const* buffers, float* out, int ldo, int train, hipStream_t s) {
+                                 const void* const* buffers, float* out, int ldo, int train, const MmsDnOpts* opts, hipStream_t s) {
     Ctx c{ws, x, (const float* const*)params_, buffers, out, nullptr, nullptr};
-    return dn121_forward_impl(&c, 1, B, D, H, W, ldo, train, s);
+    return dn121_forward_impl(&c, 1, B, D, H, W, ldo, train, opts, s);
 }
 extern "C" int mms_dn121_backward(void* ws, int B, int D, int H, int W, const float* x, const void* const* params,
-                                  const float* dout, int lddout, void* const* grads, hipStream_t s) {
+                                  const float* dout, int lddout, void* const* grads, const MmsDnOpts* opts, hipStream_t s) {
     Ctx c{ws, x, (const float* const*)params, nullptr, nullptr, dout, (float* const*)grads};
-    return dn121_backward_impl(&c, 1, B, D, H, W, lddout, s, nullptr, nullptr, nullptr);
+    return dn121_backward_impl(&c, 1, B, D, H, W, lddout, opts, s, nullptr, nullptr, nullptr);
 }
 extern "C" int mms_dn121_backward_mt(void* ws, int B, int D, int H, int W, const float* x, const void* const* params,
-                                     const float* dout, int lddout, void* const* grads, hipStream_t s, hipStream_t side,
+                                     const float* dout, int lddout, void* const* grads, const MmsDnOpts* opts, hipStream_t s, hipStream_t side,
                                      hipEvent_t ev_fork, hipEvent_t ev_join) {
     if (!side || !ev_fork || !ev_join) return MMS_ERR_ARG;
     Ctx c{ws, x, (const float* const*)params, nullptr, nullptr, dout, (float* const*)grads};
-    return dn121_backward_impl(&c, 1, B, D, H, W, lddout, s, side, ev_fork, ev_join);
+    return dn121_backward_impl(&c, 1, B, D, H, W, lddout, opts, s, side, ev_fork, ev_join);
 }
 
 // Data-parallel variants of the single-model drivers (one process per GPU; include/mmsurv.h).
 extern "C" int mms_dn121_forward_sync(void* ws, int B, int D, int H, int W, const float* x, const void* const* params_,
                                       const void* const* buffers, float* out, int ldo, int bn_world, mms_sync_fn hook, void* user,
-                                      hipStream_t s) {
+                                      const MmsDnOpts* opts, hipStream_t s) {
     if (bn_world < 1) return MMS_ERR_ARG;
     Ctx c{ws, x, (const float* const*)params_, buffers, out, nullptr, nullptr};
     Dp dp; dp.bn_world = bn_world; dp.hook = hook; dp.user = user;
-    return dn121_forward_impl(&c, 1, B, D, H, W, ldo, 1, s, dp);
+    return dn121_forward_impl(&c, 1, B, D, H, W, ldo, 1, opts, s, dp);
 }
 extern "C" int mms_dn121_backward_stage(void* ws, int B, int D, int H, int W, const float* x, const void* const* params,
                                         const float* dout, int lddout, void* const* grads, int block_hi, int block_lo,
-                                        int bn_world, mms_sync_fn hook, void* user, hipStream_t s) {
+                                        int bn_world, mms_sync_fn hook, void* user, const MmsDnOpts* opts, hipStream_t s) {
     if (bn_world < 1) return MMS_ERR_ARG;
     Ctx c{ws, x, (const float* const*)params, nullptr, nullptr, dout, (float* const*)grads};
     Dp dp; dp.bn_world = bn_world; dp.hook = hook; dp.user = user; dp.b_hi = block_hi; dp.b_lo = block_lo;
-    return dn121_backward_impl(&c, 1, B, D, H, W, lddout, s, nullptr, nullptr, nullptr, dp);
+    return dn121_backward_impl(&c, 1, B, D, H, W, lddout, opts, s, nullptr, nullptr, nullptr, dp);
 }
 
 // Fold-group drivers: model g of the group is described by the g-th entry of each array (all models share B, D, H, W).
 extern "C" int mms_dn121_forward_group(int ng, void* const* ws, int B, int D, int H, int W, const float* const* x,
                                        const void* const* const* params, const void* const* const* buffers, float* const* out,
-                                       int ldo, int train, hipStream_t s) {
+                                       int ldo, int train, const MmsDnOpts* opts, hipStream_t s) {
     if (ng < 1 || ng > MMS_MAX_GROUP || !ws || !x || !params || !out) return MMS_ERR_ARG;
     Ctx c[MMS_MAX_GROUP];
     FOR_G c[g] = Ctx{ws[g], x[g], (const float* const*)params[g], buffers ? buffers[g] : nullptr, out[g], nullptr, nullptr};
-    return dn121_forward_impl(c, ng, B, D, H, W, ldo, train, s);
-}
-// Stage variants of the two group drivers (Dp above): the fold-group step split at a dense-block boundary so that its chip-filling
-// part (stem, early blocks, optimiser) and its latency-bound part (late blocks, heads) can run on different HIP streams -- e.g.
-// streams with disjoint CU masks (fold_group.py, MMS_CU_PARTITION).  flags: bit 0 = lo_skip_trans, bit 1 = hi_trans_only,
-// bits 2-3 = unpack mode.
-extern "C" int mms_dn121_forward_stage_group(int ng, void* const* ws, int B, int D, int H, int W, const float* const* x,
-                                             const void* const* const* params, const void* const* const* buffers, float* const* out,
-                                             int ldo, int train, int block_lo, int block_hi, hipStream_t s) {
-    if (ng < 1 || ng > MMS_MAX_GROUP || !ws || !x || !params || !out) return MMS_ERR_ARG;
-    Ctx c[MMS_MAX_GROUP];
-    FOR_G c[g] = Ctx{ws[g], x[g], (const float* const*)params[g], buffers ? buffers[g] : nullptr, out[g], nullptr, nullptr};
-    Dp dp; dp.f_lo = block_lo; dp.f_hi = block_hi;
-    return dn121_forward_impl(c, ng, B, D, H, W, ldo, train, s, dp);
-}
-extern "C" int mms_dn121_backward_stage_group(int ng, void* const* ws, int B, int D, int H, int W, const float* const* x,
-                                              const void* const* const* params, const float* const* dout, int lddout,
-                                              void* const* const* grads, int block_hi, int block_lo, int flags, hipStream_t s) {
-    if (ng < 1 || ng > MMS_MAX_GROUP || !ws || !x || !params || !dout || !grads) return MMS_ERR_ARG;
-    Ctx c[MMS_MAX_GROUP];
-    FOR_G c[g] = Ctx{ws[g], x[g], (const float* const*)params[g], nullptr, nullptr, dout[g], (float* const*)grads[g]};
-    Dp dp; dp.b_hi = block_hi; dp.b_lo = block_lo;
-    dp.lo_skip_trans = flags & 1; dp.hi_trans_only = (flags >> 1) & 1; dp.unpack = (flags >> 2) & 3;
-    if (dp.unpack > 2) return MMS_ERR_ARG;
-    return dn121_backward_impl(c, ng, B, D, H, W, lddout, s, nullptr, nullptr, nullptr, dp);
+    return dn121_forward_impl(c, ng, B, D, H, W, ldo, train, opts, s);
 }
 extern "C" int mms_dn121_backward_group(int ng, void* const* ws, int B, int D, int H, int W, const float* const* x,
                                         const void* const* const* params, const float* const* dout, int lddout,
-                                        void* const* const* grads, hipStream_t s) {
+                                        void* const* const* grads, const MmsDnOpts* opts, hipStream_t s) {
     if (ng < 1 || ng > MMS_MAX_GROUP || !ws || !x || !params || !dout || !grads) return MMS_ERR_ARG;
     Ctx c[MMS_MAX_GROUP];
     FOR_G c[g] = Ctx{ws[g], x[g], (const float* const*)params[g], nullptr, nullptr, dout[g], (float* const*)grads[g]};
-    return dn121_backward_impl(c, ng, B, D, H, W, lddout, s, nullptr, nullptr, nullptr);
+    return dn121_backward_impl(c, ng, B, D, H, W, lddout, opts, s, nullptr, nullptr, nullptr);
 }

@@ -14,35 +14,33 @@ static inline bool mms_conv3w_mt_fills(long workgroups) {
 // [m0 - halo, m0 + 16 + halo), halo = H*W + W + 1, staged in LDS once -- no tap split, no reduce launch.  Applies when that window fits
 // (dense blocks 2-4 of 64x64x32 volumes, blocks 3-4 of 128x128x64 volumes).  Returns 0 (not applicable / MMS_CONV3_SMALL=0) or the
 // number of 16-column output tiles per wave: 2, or 1 (output channels split over blockIdx.y) when the launch has few row tiles
-// (MMS_CONV3_SMALL=1 / 2 force that number: tests).
+// (MmsDnOpts.conv3_small = 1 / 2 force that number, -1 = never: tests).
 #define MMS_C3S_MAXROWS 120
-static inline int mms_conv3_small_jn(int M, int ng, const Dims3& g) {
-    const char* e = getenv("MMS_CONV3_SMALL");
-    if ((e && e[0] == '0') || M <= 0) return 0;
+static inline int mms_conv3_small_jn(int M, int ng, const Dims3& g, const MmsDnOpts& o) {
+    if (o.conv3_small < 0 || M <= 0) return 0;
     const long halo = (long)g.H * g.W + g.W + 1;
     if (16 + 2 * halo > MMS_C3S_MAXROWS) return 0;
-    if (e && (e[0] == '1' || e[0] == '2')) return e[0] - '0';
+    if (o.conv3_small == 1 || o.conv3_small == 2) return o.conv3_small;
     const long tiles = (long)((M + 15) / 16) * ng;
     return tiles > 128 ? 2 : 1;
 }
 // Small-launch 1x1x1 convolution forward (dn_c1s.hip): 16 x 16 output tiles, the whole K range per workgroup, both operand panels in LDS -- no
-// K split over workgroups, no ticket.  Taken for un-pooled launches with at most MMS_C1S_MAX_WGS tiles (default 640: dense block 3 of every
+// K split over workgroups, no ticket.  Taken for un-pooled launches with at most MmsDnOpts.c1s_max_wgs tiles (default 640: dense block 3 of every
 // fold group, block 2 of a single model -- measured per launch at 3 models: block 3 (192 tiles) 13.5 -> 8.8 us, block 2 (1536 tiles: three
-// rounds of two workgroups per CU) 14.9 -> 20.7 us; one model: block 2 (512 tiles) 12.3 -> 8.9 us); MMS_CONV1_SMALL=0 disables it (A/B, the
-// K-split tests), =1 forces it whenever the shape allows.
-static inline bool mms_conv1_small_ok(const Conv1FwdP& p, int ng) {
-    const char* e = getenv("MMS_CONV1_SMALL");
-    if ((e && e[0] == '0') || p.pool || p.K % 32 != 0 || p.K > 1024 || p.K < 32 || p.ldx % 4 != 0) return false;
-    if (e && e[0] == '1') return true;
-    static const long maxwg = getenv("MMS_C1S_MAX_WGS") ? atol(getenv("MMS_C1S_MAX_WGS")) : 640;
+// rounds of two workgroups per CU) 14.9 -> 20.7 us; one model: block 2 (512 tiles) 12.3 -> 8.9 us); MmsDnOpts.conv1_small = -1 disables it (A/B, the
+// K-split tests), 1 forces it whenever the shape allows.
+static inline bool mms_conv1_small_ok(const Conv1FwdP& p, int ng, const MmsDnOpts& o) {
+    if (o.conv1_small < 0 || p.pool || p.K % 32 != 0 || p.K > 1024 || p.K < 32 || p.ldx % 4 != 0) return false;
+    if (o.conv1_small > 0) return true;
+    const long maxwg = o.c1s_max_wgs > 0 ? o.c1s_max_wgs : 640;
     return (long)((p.M + 15) / 16) * ((p.N + 15) / 16) * ng <= maxwg;
 }
 int mms_c1s_fwd(const Conv1FwdP* pp, int ng, hipStream_t s);
-// whole-M backward-data + fused norm1 backward (dn_c1s.hip): MMS_CONV1_SMALL_BWD=0 keeps the tile-GEMM forms
-bool mms_conv1_small_bwd_ok(const Conv1BwdP& p);
+// whole-M backward-data + fused norm1 backward (dn_c1s.hip): MmsDnOpts.conv1_small_bwd = -1 keeps the tile-GEMM forms
+bool mms_conv1_small_bwd_ok(const Conv1BwdP& p, const MmsDnOpts& o);
 int mms_c1s_bwd(const Conv1BwdP* pp, int ng, hipStream_t s);
-int mms_c3s_fwd(const Conv3FwdP* pp, int ng, hipStream_t s);
-int mms_c3s_bwd_data(const Conv3BwdDataP* pp, int ng, hipStream_t s);
+int mms_c3s_fwd(const Conv3FwdP* pp, int ng, const MmsDnOpts& o, hipStream_t s);
+int mms_c3s_bwd_data(const Conv3BwdDataP* pp, int ng, const MmsDnOpts& o, hipStream_t s);
 
 // ---- dense block 4 as one launch per pass (dn_b4.hip); internal to the network drivers ------------------------------------------
 struct B4Layer {               // device table entry, one per dense layer of block 4 (built by mms_dn121_init)

@@ -524,8 +524,7 @@ extern "C" int mms_linear_big_fwd(const LinBigP* pp, hipStream_t s) {
     const LinBigP& p = *pp;
     const bool xa = x_aligned(p), wa = w_vec(p);
     const bool plain = !p.has_bn && !(p.train && (p.drop_mask || p.drop_p > 0.f));
-    const char* e = getenv("MMS_LINBIG_WIDE");           // 0: GEMM-core form only (A/B measurements, tests)
-    if (plain && xa && wa && p.M >= 256 && p.N >= 128 && p.K >= 512 && !(e && e[0] == '0')) {
+    if (plain && xa && wa && p.M >= 256 && p.N >= 128 && p.K >= 512 && !p.core_only) {
         constexpr int smem = 2 * LFW_STAGE * (int)sizeof(float);             // 73.7 KB: 2 workgroups per CU
         static std::once_flag attr_once;
         std::call_once(attr_once, [&] { hipFuncSetAttribute((const void*)lin_fwd_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem); });
@@ -547,8 +546,7 @@ extern "C" int mms_linear_big_bwd_w(const LinBigP* pp, hipStream_t s) {
     if (!pp || !args_ok(*pp) || !pp->dy || !pp->dw || pp->msplit <= 0 || pp->lddy < pp->N) return MMS_ERR_ARG;
     const LinBigP& p = *pp;
     const bool plain = !p.has_bn && !(p.train && (p.drop_mask || p.drop_p > 0.f));
-    const char* e = getenv("MMS_LINBIG_WIDE");           // 0: GEMM-core form only (A/B measurements, tests)
-    if (plain && x_aligned(p) && p.N >= 128 && p.K >= 128 && p.M >= 256 && !(e && e[0] == '0')) {
+    if (plain && x_aligned(p) && p.N >= 128 && p.K >= 128 && p.M >= 256 && !p.core_only) {
         constexpr int smem = 2 * LBW_STAGE * (int)sizeof(float);             // 67.6 KB: 2 workgroups per CU
         static std::once_flag attr_once;
         std::call_once(attr_once, [&] { hipFuncSetAttribute((const void*)lin_bwdw_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem); });

@@ -91,6 +91,11 @@ class DenseNet121(nn.Module):
                 nn.init.constant_(m.bias, 0)
         self._eng = None      # engine state: (key, workspace, tables)
         self._gflat = None
+        self.dn_opts = {}     # launch-shape options of this module's eager path (fields of MmsDnOpts, include/mmsurv.h; {} = defaults)
+
+    def _opts(self):
+        from . import ops
+        return ops.dn_opts(self.dn_opts, out_features=self.class_layers.out.out_features)      # (incl. the width of class_layers.out)
 
     # ---- engine plumbing -------------------------------------------------------------------------
     def _tables(self, x):
@@ -128,9 +133,9 @@ class DenseNet121(nn.Module):
         nout = self.class_layers.out.out_features
         out = torch.empty(B, nout, device=x.device, dtype=torch.float32)
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        e["lib"].mms_dn121_out_features(nout)          # one-shot driver attribute: class_layers.out's width
         _lib.check(e["lib"].mms_dn121_forward(e["ws"].data_ptr(), B, D, H, W, x.data_ptr(), e["ptab"], e["btab"],
-                                              out.data_ptr(), out.stride(0), 1 if self.training else 0, st), "mms_dn121_forward")
+                                              out.data_ptr(), out.stride(0), 1 if self.training else 0, ctypes.byref(self._opts()), st),
+                   "mms_dn121_forward")
         return out
 
     def _grad_table(self):
@@ -163,9 +168,8 @@ class DenseNet121(nn.Module):
         gtab = self._grad_table()
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         dout = dout.contiguous().float()
-        e["lib"].mms_dn121_out_features(self.class_layers.out.out_features)
         _lib.check(e["lib"].mms_dn121_backward(e["ws"].data_ptr(), B, D, H, W, x.data_ptr(), e["ptab"],
-                                               dout.data_ptr(), dout.stride(0), gtab, st), "mms_dn121_backward")
+                                               dout.data_ptr(), dout.stride(0), gtab, ctypes.byref(self._opts()), st), "mms_dn121_backward")
 
     def workspace_region(self, name, index=0, dtype=torch.float32):
         """Diagnostic view of a named workspace region (tests)."""

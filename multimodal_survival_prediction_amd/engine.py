@@ -118,12 +118,15 @@ class _Plan:
 
 class SurvivalEngine:
     def __init__(self, model, adamw=None, lr=1e-4, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0,
-                 gate_entropy_weight=0.01, cox_ties=None, _slots=None):
-        """_slots (used by FoldGroupEngine): dict(gflat=[n] fp32, sumsq=[1] fp64, entropy=[1] fp32) views of group-wide
+                 gate_entropy_weight=0.01, cox_ties=None, dn_opts=None, _slots=None):
+        """dn_opts: launch-shape options of the encoder drivers (dict of MmsDnOpts fields, include/mmsurv.h; None = defaults).
+        _slots (used by FoldGroupEngine): dict(gflat=[n] fp32, sumsq=[1] fp64, entropy=[1] fp32) views of group-wide
         buffers, so the per-step zeroing of a whole fold group is three memsets."""
         self.lib = _lib.load_library()
         self.model = model
         self.prog = head_program(model)
+        # MmsDnOpts of every encoder driver call of this engine (the width of class_layers.out rides in it)
+        self.dn_opts = ops.dn_opts(dict(dn_opts or {}), out_features=self.prog.get("enc_width", 128))
         p0 = next(model.parameters())
         if not p0.is_cuda:
             raise RuntimeError("SurvivalEngine: move the model to the GPU first (model.to('cuda')); no CPU fallback")
@@ -370,6 +373,16 @@ class SurvivalEngine:
         return ops.inprolog(L.pro_bn, train=train, drop_p=p, drop_mask=mask, rng=self.rng, stream_id=idx + 1)
 
     # ---- launches (all on torch's current stream; capturable) ---------------------------------------
+    def _opts_arg(self):
+        """`const MmsDnOpts*` of this engine's driver calls.  The block-4 persistent kernels (csrc/dn_b4.hip) hand data between 8
+        co-resident workgroups per model and one such launch per worker stream may be in flight: if those workgroups could outnumber
+        the CUs, the per-layer path is taken instead (decided here, at launch = graph-capture time, and passed as an ARGUMENT)."""
+        o = self.dn_opts
+        if o.persist_b4 == 0 and not ops.persistent_b4_fits(self.device, 1):
+            o = ops.dn_opts(o, persist_b4=-1)
+        self._opts_live = o          # (keeps the block alive for the duration of the call)
+        return ctypes.byref(o)
+
     def _forward(self, P, train):
         st = ops.stream()
         lib, prog = self.lib, self.prog
@@ -377,11 +390,12 @@ class SurvivalEngine:
         if P.has_enc:
             feats = P.buf["feats"]
             out = feats[:, prog["ct_cols"]:]
-            fwd = lib.mms_fb_forward if P.fallback else lib.mms_dn121_forward
-            if not P.fallback:
-                lib.mms_dn121_out_features(prog.get("enc_width", 128))      # one-shot driver attribute: class_layers.out's width
-            _lib.check(fwd(P.ws.data_ptr(), B, D, H, W, P.ct.data_ptr(), P.ptab, P.btab, out.data_ptr(),
-                           feats.stride(0), 1 if train else 0, st), "encoder forward")
+            if P.fallback:
+                _lib.check(lib.mms_fb_forward(P.ws.data_ptr(), B, D, H, W, P.ct.data_ptr(), P.ptab, P.btab, out.data_ptr(),
+                                              feats.stride(0), 1 if train else 0, st), "mms_fb_forward")
+            else:
+                _lib.check(lib.mms_dn121_forward(P.ws.data_ptr(), B, D, H, W, P.ct.data_ptr(), P.ptab, P.btab, out.data_ptr(),
+                                                 feats.stride(0), 1 if train else 0, self._opts_arg(), st), "mms_dn121_forward")
         if P.big:
             if train:
                 P.big_stats.zero_()
@@ -439,25 +453,23 @@ class SurvivalEngine:
         B, (D, H, W) = P.B, P.dims
         dfe = P.dbuf["feats"]
         dct = dfe[:, prog["ct_cols"]:]
-        if not P.fallback:
-            lib.mms_dn121_out_features(prog.get("enc_width", 128))
         if stage is not None or hook is not None or P.bn_world > 1:
             hi, lo = stage if stage is not None else (3, 0)
             _lib.check(lib.mms_dn121_backward_stage(P.ws.data_ptr(), B, D, H, W, P.ct.data_ptr(), P.ptab, dct.data_ptr(), dfe.stride(0),
-                                                    P.gtab, hi, lo, P.bn_world, hook, None, st), "mms_dn121_backward_stage")
+                                                    P.gtab, hi, lo, P.bn_world, hook, None, self._opts_arg(), st), "mms_dn121_backward_stage")
             return
         # The weight-gradient fork (mms_dn121_backward_mt) is off by default: measured, it neither helps a single chain
         # (graph branches run mostly serially) nor concurrent fold models (it takes hardware queues away from them).
         if os.environ.get("MMS_SIDE_STREAM") != "1" and not P.fallback:
             _lib.check(lib.mms_dn121_backward(P.ws.data_ptr(), B, D, H, W, P.ct.data_ptr(), P.ptab, dct.data_ptr(),
-                                              dfe.stride(0), P.gtab, st), "mms_dn121_backward")
+                                              dfe.stride(0), P.gtab, self._opts_arg(), st), "mms_dn121_backward")
             return
         if P.fallback:
             _lib.check(lib.mms_fb_backward(P.ws.data_ptr(), B, D, H, W, P.ct.data_ptr(), P.ptab, dct.data_ptr(),
                                            dfe.stride(0), P.gtab, st), "mms_fb_backward")
             return
         _lib.check(lib.mms_dn121_backward_mt(P.ws.data_ptr(), B, D, H, W, P.ct.data_ptr(), P.ptab, dct.data_ptr(),
-                                             dfe.stride(0), P.gtab, st, ctypes.c_void_p(self.side_stream.cuda_stream),
+                                             dfe.stride(0), P.gtab, self._opts_arg(), st, ctypes.c_void_p(self.side_stream.cuda_stream),
                                              ctypes.c_void_p(self.ev_fork.cuda_event), ctypes.c_void_p(self.ev_join.cuda_event)),
                    "mms_dn121_backward_mt")
 
@@ -756,9 +768,8 @@ class SurvivalEngine:
         cc = prog["ct_cols"]
         self.gflat.zero_(); self.sumsq.zero_()
         feats = P.buf["feats"]
-        lib.mms_dn121_out_features(prog.get("enc_width", 128))
         _lib.check(lib.mms_dn121_forward_sync(P.ws.data_ptr(), B, Dd, H, W, P.ct.data_ptr(), P.ptab, P.btab, feats[:, cc:].data_ptr(),
-                                              feats.stride(0), world, hook, None, st), "mms_dn121_forward_sync")
+                                              feats.stride(0), world, hook, None, self._opts_arg(), st), "mms_dn121_forward_sync")
 
         def gather(dst, src):
             tmp = torch.empty(world * src.shape[0], *src.shape[1:], device=self.device)
@@ -835,7 +846,7 @@ class SurvivalEngine:
                 if int(P.b4_err.item()) != 0:
                     P.b4_err.zero_()
                     raise RuntimeError("mmsurv: a hand-off of the block-4 persistent kernel timed out (too many persistent launches in "
-                                       "flight at once?); the results since the last check are invalid -- rerun with MMS_PERSIST_B4=0")
+                                       "flight at once?); the results since the last check are invalid -- rerun with dn_opts={'persist_b4': -1}")
 
     def epoch_stats(self):
         """-> dict(sum_loss, n_usable, sum_entropy, n_batches) (one device->host sync); checks the block-4 time-out word (check_b4)."""

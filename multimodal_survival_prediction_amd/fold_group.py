@@ -62,6 +62,8 @@ class FoldGroupEngine:
         kinds = {e.prog["kind"] for e in self.engines}
         if len(kinds) != 1:
             raise ValueError("fold-group models must be of one class, got %s" % sorted(kinds))
+        if len({bytes(e.dn_opts) for e in self.engines}) != 1:
+            raise ValueError("fold-group models must share one encoder shape (class_layers.out width) and launch options")
         self.plans = {}
 
     def __len__(self):
@@ -117,9 +119,8 @@ class FoldGroupEngine:
         prog = GP.eng[0].prog
         if GP.has_enc:
             B, (D, H, W) = GP.B, GP.dims
-            lib.mms_dn121_out_features(prog.get("enc_width", 128))      # per-thread driver attribute: class_layers.out's width
             _lib.check(lib.mms_dn121_forward_group(ng, GP.ws, B, D, H, W, GP.x, GP.params, GP.buffers, GP.out, GP.ld,
-                                                   1 if train else 0, st), "mms_dn121_forward_group")
+                                                   1 if train else 0, self._opts_arg(GP), st), "mms_dn121_forward_group")
         self._forward_heads(GP, train)
 
     def _forward_heads(self, GP, train):
@@ -144,36 +145,13 @@ class FoldGroupEngine:
             for e in GP.eng:
                 e.gflat.zero_(); e.sumsq.zero_(); e.entropy.zero_()
 
-    def _train_body(self, GP, skip_if_unusable, part=None):
-        """zero-grad -> forward -> Cox -> backward -> clip -> Adam for every member, one launch sequence.
-        part = (stage, S): one of the three stages of the CU-partitioned step (ops.cu_partition) -- "h1": zero-grad + encoder forward
-        up to dense block S-1 (with its transition); "l": encoder blocks S.., heads, loss, backward down to block S's dense layers;
-        "h2": the rest of the backward, clip, Adam.  The three in order issue exactly the launches of the unsplit body."""
+    def _train_body(self, GP, skip_if_unusable):
+        """zero-grad -> forward -> Cox -> backward -> clip -> Adam for every member, one launch sequence."""
         st = ops.stream()
         lib, ng = self.lib, GP.ng
         prog = GP.eng[0].prog
-        if part is not None:
-            stage, S = part
-            B, (D, H, W) = GP.B, GP.dims
-            lib.mms_dn121_out_features(prog.get("enc_width", 128))
-            if stage == "h1":
-                self._zero(GP)
-                _lib.check(lib.mms_dn121_forward_stage_group(ng, GP.ws, B, D, H, W, GP.x, GP.params, GP.buffers, GP.out, GP.ld, 1, 0, S - 1, st),
-                           "mms_dn121_forward_stage_group")
-                return
-            if stage == "h2":
-                _lib.check(lib.mms_dn121_backward_stage_group(ng, GP.ws, B, D, H, W, GP.x, GP.params, GP.dout, GP.ld, GP.grads, S, 0,
-                                                              2 | (2 << 2), st), "mms_dn121_backward_stage_group")
-                ad = GP.adam[bool(skip_if_unusable)]
-                _lib.check(lib.mms_grad_sumsq_group(ad, ng, st), "mms_grad_sumsq_group")
-                _lib.check(lib.mms_clip_adam_group(ad, ng, st), "mms_clip_adam_group")
-                return
-            _lib.check(lib.mms_dn121_forward_stage_group(ng, GP.ws, B, D, H, W, GP.x, GP.params, GP.buffers, GP.out, GP.ld, 1, S, 3, st),
-                       "mms_dn121_forward_stage_group")
-            self._forward_heads(GP, True)
-        else:
-            self._zero(GP)
-            self._forward(GP, True)
+        self._zero(GP)
+        self._forward(GP, True)
         _lib.check(lib.mms_cox_fwd_bwd_group(GP.cox, ng, st), "mms_cox_fwd_bwd_group")
         n_pre = prog["n_pre"]
         for i in range(len(GP.lin_bwd) - 1, n_pre - 1, -1):
@@ -184,15 +162,9 @@ class FoldGroupEngine:
             _lib.check(lib.mms_missing_mix_bwd_group(GP.mix, ng, st), "mms_missing_mix_bwd_group")
         for i in range(n_pre - 1, -1, -1):
             _lib.check(lib.mms_linear_bwd_group(GP.lin_bwd[i], ng, st), "mms_linear_bwd_group")
-        if part is not None:
-            lib.mms_dn121_out_features(prog.get("enc_width", 128))
-            _lib.check(lib.mms_dn121_backward_stage_group(ng, GP.ws, B, D, H, W, GP.x, GP.params, GP.dout, GP.ld, GP.grads, 3, S,
-                                                          1 | (1 << 2), st), "mms_dn121_backward_stage_group")
-            return
         if GP.has_enc:
             B, (D, H, W) = GP.B, GP.dims
-            lib.mms_dn121_out_features(prog.get("enc_width", 128))
-            _lib.check(lib.mms_dn121_backward_group(ng, GP.ws, B, D, H, W, GP.x, GP.params, GP.dout, GP.ld, GP.grads, st),
+            _lib.check(lib.mms_dn121_backward_group(ng, GP.ws, B, D, H, W, GP.x, GP.params, GP.dout, GP.ld, GP.grads, self._opts_arg(GP), st),
                        "mms_dn121_backward_group")
         ad = GP.adam[bool(skip_if_unusable)]
         _lib.check(lib.mms_grad_sumsq_group(ad, ng, st), "mms_grad_sumsq_group")
@@ -211,55 +183,19 @@ class FoldGroupEngine:
                 for b, b0 in zip(e.model.buffers(), s[6]):
                     b.copy_(b0)
 
-    def _guard_persistent_b4(self, GP):
-        """The block-4 persistent kernels (csrc/dn_b4.hip) hand data between 8 co-resident workgroups per model; a launch of them per
-        worker stream may be in flight at once.  If those workgroups could outnumber the CUs, take the per-layer path instead (read at
-        capture time by the drivers) rather than rely on the kernels' bounded spin + time-out word."""
-        import os
-        if GP.has_enc and "MMS_PERSIST_B4" not in os.environ:
-            cus = ops.light_cus(self.device) or torch.cuda.get_device_properties(self.device).multi_processor_count
-            if 8 * GP.ng * ops.max_worker_streams() > cus:
-                os.environ["MMS_PERSIST_B4"] = "0"
-
-    def _train_partitioned(self, GP, skip_if_unusable, light, S):
-        """The training step as three graphs on two CU-masked streams: h1 and h2 on the current (heavy-partition) stream, l on its
-        light-partition partner, ordered by two events.  While l runs, the heavy partition is free for the other sub-groups' h1 / h2
-        -- and l's small kernels do not queue behind those chip-filling launches for CU slots (tools/micro/cu_mask_streams.py: a chain
-        of tiny kernels beside another stream's chip-filling kernels runs 24x slower unmasked, at full speed on its own CUs)."""
-        key = ("train3", bool(skip_if_unusable), S)
-        if key not in GP.graphs:
-            self._guard_persistent_b4(GP)
-            snap = self._snapshot(GP.eng)
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                for stage in ("h1", "l", "h2"):
-                    self._train_body(GP, skip_if_unusable, (stage, S))
-            torch.cuda.current_stream().wait_stream(s)
-            torch.cuda.synchronize()
-            self._restore(GP.eng, snap)
-            gs = []
-            for stage in ("h1", "l", "h2"):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self._train_body(GP, skip_if_unusable, (stage, S))
-                gs.append(g)
-            GP.graphs[key] = (gs, torch.cuda.Event(), torch.cuda.Event())
-            self._restore(GP.eng, snap)
-        (g1, gl, g2), e1, e2 = GP.graphs[key]
-        heavy = torch.cuda.current_stream()
-        g1.replay()
-        e1.record(heavy)
-        light.wait_event(e1)
-        with torch.cuda.stream(light):
-            gl.replay()
-            e2.record(light)
-        heavy.wait_event(e2)
-        g2.replay()
+    def _opts_arg(self, GP):
+        """`const MmsDnOpts*` of the group's driver calls (the members share one block: same class, same options).  The block-4
+        persistent kernels (csrc/dn_b4.hip) hand data between 8 co-resident workgroups per model and one such launch per worker stream
+        may be in flight: if those workgroups could outnumber the CUs, the per-layer path is taken -- decided at launch (= graph-capture)
+        time from the number of worker streams the process has created, and passed to the drivers as an ARGUMENT."""
+        o = GP.eng[0].dn_opts
+        if o.persist_b4 == 0 and not ops.persistent_b4_fits(self.device, GP.ng):
+            o = ops.dn_opts(o, persist_b4=-1)
+        GP.opts_live = o
+        return ctypes.byref(o)
 
     def _graph(self, GP, key, body):
         if key not in GP.graphs:
-            self._guard_persistent_b4(GP)
             snap = self._snapshot(GP.eng)
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
@@ -341,11 +277,6 @@ class FoldGroupEngine:
         self._gather_indexed(GP, cohort, idx)
         if not use_graph:
             self._train_body(GP, skip_if_unusable)
-            return
-        part = ops.cu_partition() if GP.has_enc else None
-        light = ops.light_partner(torch.cuda.current_stream()) if part is not None else None
-        if light is not None:
-            self._train_partitioned(GP, skip_if_unusable, light, part[1])
             return
         self._graph(GP, ("train", bool(skip_if_unusable)), lambda: self._train_body(GP, skip_if_unusable)).replay()
 

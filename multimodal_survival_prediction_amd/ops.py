@@ -28,9 +28,37 @@ def bnsrc(gamma, beta, count, train, sum=None, sumsq=None, rmean=None, rvar=None
                          1.0 / float(count), float(eps), 1 if train else 0)
 
 
-def call(name, p):
+def dn_opts(base=None, **kw):
+    """MmsDnOpts (include/mmsurv.h): launch-shape options of the DenseNet121 drivers and convolution entry points.  All-zero = the
+    defaults; the library reads no environment variable, so this block is the only way to select a kernel form (A/B measurements, the
+    parity tests that must reach one form).  base: another block or a dict to start from."""
+    S = _S()["MmsDnOpts"]
+    names = {f[0] for f in S._fields_}
+    o = S()
+    if isinstance(base, dict):
+        kw = dict(base, **kw)
+    elif base is not None:
+        ctypes.memmove(ctypes.byref(o), ctypes.byref(base), ctypes.sizeof(S))
+    for k, v in kw.items():
+        if k not in names:
+            raise AttributeError("MmsDnOpts has no field %r (include/mmsurv.h)" % k)
+        setattr(o, k, int(v))
+    return o
+
+
+def opts_ref(o):
+    """ctypes argument for a `const MmsDnOpts*` parameter: NULL (defaults) for None."""
+    return None if o is None else ctypes.byref(o)
+
+
+def call(name, p, opts=None):
+    """Single-model entry point name(p, stream); with opts: its fold-group form name_group(p, 1, opts, stream) (the entry points that
+    have several kernel forms take the launch-shape options there)."""
     lib = _lib.load_library()
-    _lib.check(getattr(lib, name)(ctypes.byref(p), stream()), name)
+    if opts is None:
+        _lib.check(getattr(lib, name)(ctypes.byref(p), stream()), name)
+    else:
+        _lib.check(getattr(lib, name + "_group")(ctypes.byref(p), 1, ctypes.byref(opts), stream()), name + "_group")
 
 
 def init_coords(B, dims, device):
@@ -41,21 +69,21 @@ def init_coords(B, dims, device):
 
 
 def conv1_fwd(x, K, w, y, bn, M, osum=None, osumsq=None, pool=False, in_dims=(0, 0, 0), partial=None, ksplit=0,
-              counters=None):
+              counters=None, opts=None):
     """x: [Min, ldx] slab (first K columns); w: [N, K]; y: [M, ldy] view (column offset applied by slicing).
     partial/ksplit/counters: split the K loop over workgroups with a last-arriver fixup (Conv1FwdP in mmsurv.h)."""
     p = _S()["Conv1FwdP"](ptr(x), x.stride(0), M, K, ptr(w), w.shape[0], ptr(y), y.stride(0), bn,
                           ptr(osum), ptr(osumsq), 1 if pool else 0, dims3(in_dims), 0, 0, ptr(partial), ksplit, ptr(counters))
-    call("mms_conv1_fwd", p)
+    call("mms_conv1_fwd", p, opts)
 
 
-def conv3_fwd(y1, coords, dims, wp, out, bn, osum=None, osumsq=None, partial=None, nsplit=27, wfrag=False):
+def conv3_fwd(y1, coords, dims, wp, out, bn, osum=None, osumsq=None, partial=None, nsplit=27, wfrag=False, opts=None):
     """wfrag: wp is the fragment-ordered pack (pack_conv3_frag) -- small grids only (Conv3FwdP.wfrag in mmsurv.h)."""
     M = y1.shape[0]
     p = _S()["Conv3FwdP"](ptr(y1), ptr(coords), dims3(dims), M, ptr(wp), ptr(out), out.stride(0), bn,
                           ptr(osum), ptr(osumsq), ptr(partial), nsplit)
     p.wfrag = 1 if wfrag else 0
-    call("mms_conv3_fwd", p)
+    call("mms_conv3_fwd", p, opts)
 
 
 def conv0_fwd(x, in_dims, out_dims, coords, w, y, osum=None, osumsq=None):
@@ -95,22 +123,22 @@ def bnbwd(s1, s2):
     return _S()["BnBwd"](ptr(s1), ptr(s2))
 
 
-def conv3_bwd_data(dz, coords, dims, wpb, y1, bn, dbn, s1, s2, partial=None, nsplit=27, wfrag=False):
+def conv3_bwd_data(dz, coords, dims, wpb, y1, bn, dbn, s1, s2, partial=None, nsplit=27, wfrag=False, opts=None):
     p = _S()["Conv3BwdDataP"](ptr(dz), dz.stride(0), ptr(coords), dims3(dims), y1.shape[0], ptr(wpb), ptr(y1), bn,
                               ptr(dbn), ptr(s1), ptr(s2), ptr(partial), nsplit)
     p.wfrag = 1 if wfrag else 0
-    call("mms_conv3_bwd_data", p)
+    call("mms_conv3_bwd_data", p, opts)
 
 
-def conv3_bwd_weight(y1, coords, dims, bn, dz, dw, msplit=1, tapmajor=False):
+def conv3_bwd_weight(y1, coords, dims, bn, dz, dw, msplit=1, tapmajor=False, opts=None):
     p = _S()["Conv3BwdWP"](ptr(y1), ptr(coords), dims3(dims), y1.shape[0], bn, ptr(dz), dz.stride(0), ptr(dw), msplit,
                            1 if tapmajor else 0)
-    call("mms_conv3_bwd_weight", p)
+    call("mms_conv3_bwd_weight", p, opts)
 
 
 def conv1_bwd(which, dyraw, M, N, x, K, bn_in, w, dw, dbn, s1, s2, y=None, bn_out=None, bb_out=None, pool=False,
               in_dims=(0, 0, 0), msplit=1, dgamma_out=None, dbeta_out=None, fuse_dx=None, fuse_accumulate=True, fuse_dgamma=None,
-              fuse_dbeta=None):
+              fuse_dbeta=None, opts=None):
     S = _S()
     p = S["Conv1BwdP"]()
     p.dyraw, p.lddy = ptr(dyraw), dyraw.stride(0)
@@ -131,7 +159,10 @@ def conv1_bwd(which, dyraw, M, N, x, K, bn_in, w, dw, dbn, s1, s2, y=None, bn_ou
     if fuse_dx is not None:          # norm1 backward in the data kernel's epilogue (Conv1BwdP.fuse_dx, M <= 128)
         p.fuse_dx, p.fuse_lddx, p.fuse_accumulate = ptr(fuse_dx), fuse_dx.stride(0), 1 if fuse_accumulate else 0
         p.fuse_dgamma, p.fuse_dbeta = ptr(fuse_dgamma), ptr(fuse_dbeta)
-    call("mms_conv1_bwd_weight" if which == "weight" else "mms_conv1_bwd_data", p)
+    if which == "weight":
+        call("mms_conv1_bwd_weight", p)
+    else:
+        call("mms_conv1_bwd_data", p, opts)
 
 
 def bn_bwd_apply(dbn, x, dx, M, C, bn, bb, accumulate, dgamma, dbeta):
@@ -220,55 +251,6 @@ def adam_params(p_, g, m, v, hyper, sumsq, step, skip_flag=None, adamw=False, ac
 _WORKER_STREAMS = {}
 
 
-def cu_partition():
-    """MMS_CU_PARTITION="k[,S]": split the step of a fold sub-group over two CU-masked HIP streams -- the chip-filling part (stem, dense
-    blocks before S, optimiser) on a stream that owns all but k CUs of every XCD, the latency-bound part (dense blocks S.. and the
-    heads) on a stream that owns the other k (fold_group.FoldGroupEngine).  -> (k, S) or None (unset / 0 = off).  S defaults to 2
-    (0-based: dense blocks 3-4 and the heads are the light part)."""
-    import os
-    v = os.environ.get("MMS_CU_PARTITION", "")
-    if not v or v.split(",")[0] in ("0", ""):
-        return None
-    f = v.split(",")
-    k, S = int(f[0]), (int(f[1]) if len(f) > 1 else 2)
-    if not (1 <= k <= 16 and 1 <= S <= 3):
-        raise ValueError("MMS_CU_PARTITION=k[,S]: 1 <= k <= 16 CUs per XCD for the light part, first light block 1 <= S <= 3")
-    return k, S
-
-
-_HIP = None
-_LIGHT = {}
-
-
-def _masked_stream(device, bits, ncu):
-    """HIP stream restricted to the CUs named by `bits` (hipExtStreamCreateWithCUMask; bit i = CU i // 8 of XCD i % 8 on MI355X,
-    tools/micro/cu_mask_probe.hip; an XCD without any bit set would run UNMASKED, so every mask here names CUs of all XCDs)."""
-    global _HIP
-    if _HIP is None:
-        _HIP = ctypes.CDLL("libamdhip64.so")
-    nwords = (ncu + 31) // 32
-    arr = (ctypes.c_uint32 * nwords)()
-    for b in bits:
-        arr[b // 32] |= 1 << (b % 32)
-    st = ctypes.c_void_p()
-    with torch.cuda.device(device):
-        rc = _HIP.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(nwords), arr)
-    if rc != 0 or not st.value:
-        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
-    return torch.cuda.ExternalStream(st.value, device=device)
-
-
-def light_partner(stream):
-    """The light-partition stream paired with a heavy-partition worker stream (None when the partition is off or the stream is not one
-    of worker_streams())."""
-    return _LIGHT.get(int(stream.cuda_stream))
-
-
-def light_cus(device):
-    part = cu_partition()
-    return None if part is None else 8 * part[0]
-
-
 def worker_streams(device, n):
     """The process-wide HIP streams that concurrent fold (sub-)groups step on: created once, in a fixed order, and shared by every
     consumer (training epoch, validation pass, the benchmark's legs).  HIP multiplexes streams onto a few hardware queues in the order
@@ -278,33 +260,25 @@ def worker_streams(device, n):
     device = torch.device(device)
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
     lst = _WORKER_STREAMS.setdefault(key, [])
-    part = cu_partition()
     if n > len(lst):
         import os, warnings
         cap = int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4)        # ROCm's cap on hardware queues per device; the null stream takes one
-        if n + 1 > cap and part is None:
+        if n + 1 > cap:
             warnings.warn(f"{n} worker streams + the null stream on GPU_MAX_HW_QUEUES={cap} hardware queues: two streams will share a queue and "
                           f"serialise (K = 5 epoch, four sub-groups: 1879 patients/s against 2696 with GPU_MAX_HW_QUEUES=5; "
                           f"profiles/r03_cu_partition_experiments.txt).  Set GPU_MAX_HW_QUEUES >= {n + 1} before the process starts, "
                           f"or use <= {cap - 1} streams.", RuntimeWarning, stacklevel=2)
     while len(lst) < n:
-        if part is None:
-            lst.append(torch.cuda.Stream(device=device))
-        else:       # CU-partitioned pair: the worker stream owns all but k CUs of every XCD, its partner the other k
-            import os
-            ncu = torch.cuda.get_device_properties(device).multi_processor_count
-            nl = 8 * part[0]
-            dbg = os.environ.get("MMS_CU_PARTITION_DEBUG", "")        # diagnosis: "nomask" = the split on two ordinary streams; "nosplit" = masked worker streams, unsplit step
-            if dbg == "nomask":
-                heavy, light = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
-            else:
-                drop = {8 * len(lst)} if "distinct" in dbg else set()      # diagnosis: a different mask per worker stream (one CU of XCD 0 fewer)
-                heavy = _masked_stream(device, [b for b in range(0, ncu - nl) if b not in drop], ncu)
-                light = _masked_stream(device, range(ncu - nl, ncu), ncu)
-            if "nosplit" not in dbg:
-                _LIGHT[int(heavy.cuda_stream)] = light
-            lst.append(heavy)
+        lst.append(torch.cuda.Stream(device=device))
     return lst[:n]
+
+
+def persistent_b4_fits(device, ng):
+    """Whether the block-4 persistent launches of ng lock-step models per worker stream can all be co-resident: 8 workgroups per model
+    and one launch per worker stream in flight, against the device's CU count (the kernels' bounded spin + time-out word stay as the
+    backstop).  The rule shared by SurvivalEngine and FoldGroupEngine."""
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    return 8 * ng * max_worker_streams() <= cus
 
 
 def max_worker_streams():

@@ -17,11 +17,11 @@ class FusedOptimizer:
     """Handle for the engine-resident Adam/AdamW state (drop-in where the scripts build `optim.Adam(...)`)."""
 
     def __init__(self, model, lr=1e-4, weight_decay=1e-4, adamw=False, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0,
-                 gate_entropy_weight=0.01, cox_ties=None):
+                 gate_entropy_weight=0.01, cox_ties=None, dn_opts=None):
         # (a model that already belongs to a FoldGroupEngine keeps that engine: this object is then just the handle
         # the LR schedulers talk to -- pass the same hyper-parameters to the group's constructor)
         self.engine = engine_of(model, lr=lr, weight_decay=weight_decay, adamw=adamw, betas=betas, eps=eps,
-                                max_norm=max_norm, gate_entropy_weight=gate_entropy_weight, cox_ties=cox_ties)
+                                max_norm=max_norm, gate_entropy_weight=gate_entropy_weight, cox_ties=cox_ties, dn_opts=dn_opts)
         self.param_groups = [dict(lr=lr, weight_decay=weight_decay)]
 
     def set_lr(self, lr):

@@ -19,16 +19,16 @@ def golden_dir():
     return GOLDEN
 
 
-# ---- GPU suite time budget -----------------------------------------------------------------------------------------------------
-# The GPU suite is ~7 minutes on the build boxes, but a third of it is CPU time of the oracle (DenseNet121-3D epochs in fp32 / fp64,
-# two-rank worker processes) and varies with the host: 416 s and 657 s were measured for the same commit on two leases.  So that a slow
-# host cannot push the run past whatever limit its caller has, the oracle-heavy tests run LAST (every test is self-contained: order
-# is free) and those that would START after MMS_GPU_SUITE_BUDGET_S seconds (default 480; 0 = no budget) are skipped with that reason
-# instead of run.  On a host as fast as the build boxes nothing is skipped.
+# ---- GPU suite order ---------------------------------------------------------------------------------------------------------------
+# The GPU suite is ~7 minutes on the build boxes, but a third of it is CPU time of the oracle (DenseNet121-3D epochs in fp32, two-rank
+# worker processes) and varies with the host.  The oracle-heavy tests run LAST (every test is self-contained: order is free), so that a
+# run cut short by its caller has the quick op-level evidence first.  No test is ever skipped by the clock: a parity test runs or fails.
+# MMS_GPU_SUITE_BUDGET_S (opt-in, default 0 = off) makes an oracle-heavy test that would START after that many seconds FAIL with that
+# reason -- for callers who prefer a red run to one killed at their own limit.
 import time as _time
 
 _SUITE_T0 = _time.monotonic()
-_HEAVY = (          # most important first: they are the last to be cut
+_HEAVY = (          # most important first
     "test_epoch_and_validate_match_oracle_loops", "test_lockstep_epoch_matches_oracle_loops",
     "test_ddp_", "entry_point",
     "test_config1_simple_fusion_ct_stubbed", "test_gradient_error_vs_fp64", "test_config4_volume_shape_parity",
@@ -49,9 +49,9 @@ def pytest_collection_modifyitems(config, items):
 
 
 def pytest_runtest_setup(item):
-    budget = float(os.environ.get("MMS_GPU_SUITE_BUDGET_S", "480"))
+    budget = float(os.environ.get("MMS_GPU_SUITE_BUDGET_S", "0"))
     if budget > 0 and item.get_closest_marker("gpu") is not None and _heavy_rank(item) >= 0:
         elapsed = _time.monotonic() - _SUITE_T0
         if elapsed > budget:
-            pytest.skip("GPU suite time budget: %.0f s elapsed > MMS_GPU_SUITE_BUDGET_S = %.0f s (oracle-heavy test; run it alone or raise "
-                        "the budget)" % (elapsed, budget))
+            pytest.fail("GPU suite time budget exceeded: %.0f s elapsed > MMS_GPU_SUITE_BUDGET_S = %.0f s -- this parity test was NOT run"
+                        % (elapsed, budget), pytrace=False)

@@ -30,3 +30,10 @@ def uncl(m, B, dims):
 
 def stats(device, C):
     return torch.zeros(C, dtype=torch.float64, device=device), torch.zeros(C, dtype=torch.float64, device=device)
+
+
+# Launch-shape options (MmsDnOpts, include/mmsurv.h) under which a model's arithmetic does not depend on how many models share its
+# launches: no group-size dependent tap split / tile shapes / kernel forms / row chunks.  Group-vs-single comparisons that must be
+# tight pass these to BOTH sides; the default options are compared in tests/test_gpu_fold_group.py::test_group_default_options.
+GROUP_INDEPENDENT_OPTS = dict(split_wgs=1000000, conv1_ksplit=-1, conv1_small=-1, conv3_mt=-1, big_ng=-1, ms3_rows=512, conv3w_mt=-1,
+                              ms1_div=1)

@@ -76,31 +76,42 @@ CHILD = textwrap.dedent('''
     ptab = (VP * 364)(*[base] * 364)
     btab = (VP * 363)(*[base] * 363)
     fw = lib.mms_dn121_forward
-    fw.argtypes = [VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, VP, VP, VP, VP, ctypes.c_int, ctypes.c_int, VP]
-    assert fw(None, 4, 64, 64, 32, base, ptab, btab, base, 288, 1, None) == -1
-    assert fw(base, 4, 64, 64, 31, base, ptab, btab, base, 288, 1, None) == -1
-    rc = fw(base, 4, 64, 64, 32, base, ptab, btab, base, 288, 1, None)
+    fw.argtypes = [VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, VP, VP, VP, VP, ctypes.c_int, ctypes.c_int, VP, VP]
+    assert fw(None, 4, 64, 64, 32, base, ptab, btab, base, 288, 1, None, None) == -1
+    assert fw(base, 4, 64, 64, 31, base, ptab, btab, base, 288, 1, None, None) == -1
+    opts = (ctypes.c_int * 64)()                  # MmsDnOpts (all-int block): out_features (first field) wider than the output pitch
+    assert lib.mms_abi_sizeof(b"MmsDnOpts") <= ctypes.sizeof(opts)
+    opts[0] = 512
+    assert fw(base, 4, 64, 64, 32, base, ptab, btab, base, 288, 1, ctypes.addressof(opts), None) == -1
+    opts[0] = 5000
+    assert fw(base, 4, 64, 64, 32, base, ptab, btab, base, 8192, 1, ctypes.addressof(opts), None) == -1
+    rc = fw(base, 4, 64, 64, 32, base, ptab, btab, base, 288, 1, None, None)
     assert rc == -2, rc          # no device visible (the parent hides them): a clean launch failure
     bw = lib.mms_dn121_backward
-    bw.argtypes = [VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, VP, VP, VP, ctypes.c_int, VP, VP]
-    assert bw(base, 4, 64, 64, 32, base, ptab, None, 288, ptab, None) == -1
-    rc = bw(base, 4, 64, 64, 32, base, ptab, base, 288, ptab, None)
+    bw.argtypes = [VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, VP, VP, VP, ctypes.c_int, VP, VP, VP]
+    assert bw(base, 4, 64, 64, 32, base, ptab, None, 288, ptab, None, None) == -1
+    rc = bw(base, 4, 64, 64, 32, base, ptab, base, 288, ptab, None, None)
     assert rc == -2, rc
     fg = lib.mms_dn121_forward_group
-    fg.argtypes = [ctypes.c_int, VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, VP, VP, VP, VP, ctypes.c_int, ctypes.c_int, VP]
+    fg.argtypes = [ctypes.c_int, VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, VP, VP, VP, VP, ctypes.c_int, ctypes.c_int, VP, VP]
     for ng in (0, 11):
-        assert fg(ng, None, 4, 64, 64, 32, None, None, None, None, 288, 1, None) == -1
+        assert fg(ng, None, 4, 64, 64, 32, None, None, None, None, 288, 1, None, None) == -1
     wsv = (VP * 10)(*[base] * 10)
     pv = (VP * 10)(*[ctypes.addressof(ptab)] * 10)
     bv = (VP * 10)(*[ctypes.addressof(btab)] * 10)
-    rc = fg(10, wsv, 4, 64, 64, 32, wsv, pv, bv, wsv, 288, 1, None)
+    rc = fg(10, wsv, 4, 64, 64, 32, wsv, pv, bv, wsv, 288, 1, None, None)
     assert rc == -2, rc
     # 4. small-op launchers: null / inconsistent parameter blocks
-    for name in ("mms_cox_fwd_bwd_group", "mms_gate_fwd_group", "mms_linear_fwd_group", "mms_clip_adam_group", "mms_conv3_fwd_group"):
+    for name in ("mms_cox_fwd_bwd_group", "mms_gate_fwd_group", "mms_linear_fwd_group", "mms_clip_adam_group"):
         fn = getattr(lib, name)
         fn.argtypes = [VP, ctypes.c_int, VP]
         assert fn(base, 0, None) == -1, name
         assert fn(base, 11, None) == -1, name
+    for name in ("mms_conv3_fwd_group", "mms_conv1_fwd_group", "mms_conv3_bwd_data_group", "mms_conv3_bwd_weight_group"):      # (p, ng, opts, stream)
+        fn = getattr(lib, name)
+        fn.argtypes = [VP, ctypes.c_int, VP, VP]
+        assert fn(base, 0, None, None) == -1, name
+        assert fn(base, 11, None, None) == -1, name
     print("ASAN_CHILD_OK")
 ''')
 

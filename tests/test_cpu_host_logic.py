@@ -242,22 +242,22 @@ def test_subgroup_sizes_rule(monkeypatch):
     assert s(3, 3) == (3,) and s(4, 3) == (2, 1, 1)
 
 
-def test_cu_partition_env_and_batch_of_one(monkeypatch):
-    """Host-side parsing of MMS_CU_PARTITION (experimental CU-partitioned step) and the batch-of-one rule (torch's BatchNorm1d error)."""
+def test_batch_of_one_rule_and_launch_options():
+    """The batch-of-one rule (torch's BatchNorm1d error) and the host side of the launch-shape options: ops.dn_opts builds the MmsDnOpts
+    block of include/mmsurv.h (unknown field names are refused, not silently dropped); nothing in the package reads a launch-shape
+    environment variable any more."""
     from multimodal_survival_prediction_amd import ops
     from multimodal_survival_prediction_amd.engine import check_train_batch
-    monkeypatch.delenv("MMS_CU_PARTITION", raising=False)
-    assert ops.cu_partition() is None and ops.light_cus("cpu") is None
-    monkeypatch.setenv("MMS_CU_PARTITION", "0")
-    assert ops.cu_partition() is None
-    monkeypatch.setenv("MMS_CU_PARTITION", "8")
-    assert ops.cu_partition() == (8, 2) and ops.light_cus("cpu") == 64
-    monkeypatch.setenv("MMS_CU_PARTITION", "4,1")
-    assert ops.cu_partition() == (4, 1)
-    for bad in ("17,2", "4,0", "4,4"):
-        monkeypatch.setenv("MMS_CU_PARTITION", bad)
-        with pytest.raises(ValueError):
-            ops.cu_partition()
+    o = ops.dn_opts(dict(split_wgs=512), persist_b4=-1, out_features=64)
+    assert (o.split_wgs, o.persist_b4, o.out_features, o.conv3_small) == (512, -1, 64, 0)
+    o2 = ops.dn_opts(o, conv3_small=2)
+    assert (o2.split_wgs, o2.persist_b4, o2.conv3_small) == (512, -1, 2) and o.conv3_small == 0
+    with pytest.raises(AttributeError):
+        ops.dn_opts(no_such_option=1)
+    assert ops.opts_ref(None) is None
+    import glob
+    src = "".join(open(p).read() for p in glob.glob(os.path.join(ROOT, "multimodal_survival_prediction_amd", "csrc", "*.h*")))
+    assert "getenv(\"MMS_DEBUG_SKIP\")" in src and src.count("getenv(") == 1        # the one read sits behind #ifdef MMS_ABLATE_STEP (ablation builds)
     check_train_batch(2); check_train_batch(1, bn_world=2)
     with pytest.raises(ValueError, match="more than 1 value per channel"):
         check_train_batch(1)

@@ -154,9 +154,9 @@ def test_densenet_backward_flip_free(B, dims, signs):
 
 @pytest.mark.parametrize("B,dims,train", [(4, (64, 64, 32), True), (3, (64, 64, 32), True), (2, (64, 64, 32), False), (8, (32, 32, 32), True),
                                           (1, (64, 64, 64), True)])
-def test_block4_persistent_kernel_equals_per_layer_path(B, dims, train, monkeypatch):
+def test_block4_persistent_kernel_equals_per_layer_path(B, dims, train):
     """Dense block 4 as ONE launch (csrc/dn_b4.hip: cluster of 8 workgroups, LDS-resident slab, two in-launch hand-offs per layer) against
-    the per-layer launch sequence it replaces (MMS_PERSIST_B4=0), same weights and input: features, every saved activation the
+    the per-layer launch sequence it replaces (MmsDnOpts.persist_b4 = -1), same weights and input: features, every saved activation the
     backward reads (block-4 slab, y1 of its 16 layers), the BatchNorm statistics (through the running statistics) -- ragged row
     counts (12, 8 rows), a 1x1x1 grid (one live tap) and the eval-mode forward included."""
     ref, net = _make(4)
@@ -164,7 +164,7 @@ def test_block4_persistent_kernel_equals_per_layer_path(B, dims, train, monkeypa
     net.train(train)
     outs = {}
     for flag in ("0", "1"):
-        monkeypatch.setenv("MMS_PERSIST_B4", flag)
+        net.dn_opts = dict(persist_b4=-1 if flag == "0" else 1)
         net.load_state_dict(ref.state_dict())            # same running statistics before each run
         with torch.no_grad():
             y = net(x)
@@ -186,10 +186,10 @@ def test_block4_persistent_kernel_equals_per_layer_path(B, dims, train, monkeypa
 
 
 @pytest.mark.parametrize("B,dims", [(4, (64, 64, 32)), (3, (64, 64, 32)), (8, (32, 32, 32)), (1, (64, 64, 64))])
-def test_block4_persistent_backward_equals_per_layer_path(B, dims, monkeypatch):
+def test_block4_persistent_backward_equals_per_layer_path(B, dims):
     """The data path of dense block 4's backward as ONE launch (csrc/dn_b4.hip b4_bwd_kernel: conv2 backward-data, norm2 backward,
     conv1 backward-data, norm1 backward of the 16 layers, two in-launch hand-offs per layer) against the per-layer launch sequence
-    (MMS_PERSIST_B4=1: forward only), same weights, input and output gradient: every parameter gradient of the network (block 4's directly;
+    (MmsDnOpts.persist_b4 = 1: forward only), same weights, input and output gradient: every parameter gradient of the network (block 4's directly;
     blocks 1-3 and the stem through the gradient that leaves the block) -- ragged row counts (12 rows), a 1x1x1 grid (one live tap) and a
     2x2x2 grid (27 live taps, 7 per wave) included.  The ReLU masks come from the saved forward activations, identical in both paths, so
     there is no flip lottery: 1e-5 of each block-4 tensor's maximum, 1e-4 upstream."""
@@ -199,7 +199,7 @@ def test_block4_persistent_backward_equals_per_layer_path(B, dims, monkeypatch):
     net.train()
     grads = {}
     for flag in ("1", "2"):
-        monkeypatch.setenv("MMS_PERSIST_B4", flag)
+        net.dn_opts = dict(persist_b4=1 if flag == "1" else 0)
         net.load_state_dict(ref.state_dict())
         net.zero_grad(set_to_none=True)
         net(x).backward(dout)

@@ -20,22 +20,23 @@ def _d(t):
     return t.detach().to(DEV).contiguous()
 
 
-@pytest.mark.parametrize("B,dims,C,Ctot,ms", [(2, (4, 4, 2), 64, 256, 1), (4, (8, 8, 4), 96, 256, 4), (3, (2, 2, 1), 512, 1024, 1),
-                                              (4, (4, 4, 2), 352, 1024, 1), (4, (2, 2, 1), 992, 1024, 1),     # blocks 3 / 4 at batch 4 (128 / 16 rows)
-                                              (2, (16, 16, 8), 224, 256, 16),
-                                              # shapes that take the multi-tap forward kernel in the layer's forward: ragged last tile, W = 16
-                                              (3, (7, 7, 8), 64, 256, 4), (2, (8, 16, 16), 96, 256, 8)])
-# small: MMS_CONV3_SMALL for the unsplit conv2 launches (None = default: the all-tap 16-row kernels of dn_c3s.hip on every grid here whose
+_DL_SHAPES = [(2, (4, 4, 2), 64, 256, 1), (4, (8, 8, 4), 96, 256, 4), (3, (2, 2, 1), 512, 1024, 1),
+              (4, (4, 4, 2), 352, 1024, 1), (4, (2, 2, 1), 992, 1024, 1),     # blocks 3 / 4 at batch 4 (128 / 16 rows)
+              (2, (16, 16, 8), 224, 256, 16),
+              # shapes that take the multi-tap forward kernel in the layer's forward: ragged last tile, W = 16
+              (3, (7, 7, 8), 64, 256, 4), (2, (8, 16, 16), 96, 256, 8)]
+# small: MmsDnOpts.conv3_small for the unsplit conv2 launches (None = default: the all-tap 16-row kernels of dn_c3s.hip on every grid here whose
 # neighbourhood window fits -- all but 16x16x8, 7x7x8, 8x16x16; "0" = tile-GEMM form; "1" / "2" = one / two 16-column tiles per wave)
-# "f1" / "f2": the same with the weights in MFMA-fragment order (wfrag -- what the network driver feeds those kernels)
-@pytest.mark.parametrize("split,small", [(0, None), (0, "0"), (0, "1"), (0, "2"), (0, "f1"), (0, "f2"), (27, None), (3, None)])
-def test_dense_layer_backward(ops, B, dims, C, Ctot, ms, split, small, monkeypatch):
+# "f1" / "f2": the same with the weights in MFMA-fragment order (wfrag -- what the network driver feeds those kernels; small grids only)
+_DL_FORMS = [(0, None), (0, "0"), (0, "1"), (0, "2"), (0, "f1"), (0, "f2"), (27, None), (3, None)]
+_small_grid = lambda dims: 16 + 2 * (dims[1] * dims[2] + dims[2] + 1) <= 120
+
+
+@pytest.mark.parametrize("B,dims,C,Ctot,ms,split,small", [a + f for a in _DL_SHAPES for f in _DL_FORMS if not (f[1] and f[1][0] == "f" and not _small_grid(a[1]))])
+def test_dense_layer_backward(ops, B, dims, C, Ctot, ms, split, small):
     """One _DenseLayer: norm1-relu-conv1-norm2-relu-conv2 + cat; gradient w.r.t. every parameter and the input slab."""
     frag = small is not None and small[0] == "f"
-    if frag and 16 + 2 * (dims[1] * dims[2] + dims[2] + 1) > 120:
-        pytest.skip("fragment-ordered weights: small grids only")
-    if small is not None:
-        monkeypatch.setenv("MMS_CONV3_SMALL", small[-1])
+    o = ops.dn_opts(**({"conv3_small": {"0": -1, "1": 1, "2": 2}[small[-1]]} if small is not None else {}))
     torch.manual_seed(0)
     M = B * dims[0] * dims[1] * dims[2]
     x = (torch.randn(B, C, *dims) * 1.3 + 0.2).requires_grad_(True)
@@ -60,25 +61,23 @@ def test_dense_layer_backward(ops, B, dims, C, Ctot, ms, split, small, monkeypat
     bn1 = ops.bnsrc(g1, b1, M, True, sx, qx)
     y1d = torch.empty(M, 128, device=DEV)
     s1y, q1y = stats(DEV, 128)
-    ops.conv1_fwd(slab, C, w1, y1d, bn1, M, s1y, q1y)
+    ops.conv1_fwd(slab, C, w1, y1d, bn1, M, s1y, q1y, opts=o)
     bn2 = ops.bnsrc(g2, b2, M, True, s1y, q1y)
     if frag:
         wpf, wpb = ops.pack_conv3_frag(w2)
-    ops.conv3_fwd(y1d, coords, dims, wpf, slab[:, C:C + 32], bn2, wfrag=frag)
+    ops.conv3_fwd(y1d, coords, dims, wpf, slab[:, C:C + 32], bn2, wfrag=frag, opts=o)
     assert_close(slab[:, C:C + 32], cl(z), 1e-4, "fwd z")
     # backward chain, in the driver's order
     dbn_mid = torch.empty(M, 128, device=DEV)
     a1, a2 = stats(DEV, 128)
     part = torch.empty(27 * M * 128, device=DEV) if split else None
-    ops.conv3_bwd_data(dslab[:, C:C + 32], coords, dims, wpb, y1d, bn2, dbn_mid, a1, a2, part, split or 27, wfrag=frag)
+    ops.conv3_bwd_data(dslab[:, C:C + 32], coords, dims, wpb, y1d, bn2, dbn_mid, a1, a2, part, split or 27, wfrag=frag, opts=o)
     dw2 = torch.zeros_like(w2)
-    monkeypatch.setenv("MMS_CONV3W_MT", "0")            # one-tap GEMM form
-    ops.conv3_bwd_weight(y1d, coords, dims, bn2, dslab[:, C:C + 32], dw2, ms)
-    monkeypatch.setenv("MMS_CONV3W_MT", "2")            # multi-tap form (three kw taps per workgroup), both gradient layouts
+    ops.conv3_bwd_weight(y1d, coords, dims, bn2, dslab[:, C:C + 32], dw2, ms, opts=ops.dn_opts(conv3w_mt=-1))            # one-tap GEMM form
+    mt = ops.dn_opts(conv3w_mt=2)                       # multi-tap form (three kw taps per workgroup), both gradient layouts
     dw2m, dw2t = torch.zeros_like(w2), torch.zeros(27, 32, 128, device=DEV)
-    ops.conv3_bwd_weight(y1d, coords, dims, bn2, dslab[:, C:C + 32], dw2m, ms)
-    ops.conv3_bwd_weight(y1d, coords, dims, bn2, dslab[:, C:C + 32], dw2t, ms, tapmajor=True)
-    monkeypatch.delenv("MMS_CONV3W_MT")
+    ops.conv3_bwd_weight(y1d, coords, dims, bn2, dslab[:, C:C + 32], dw2m, ms, opts=mt)
+    ops.conv3_bwd_weight(y1d, coords, dims, bn2, dslab[:, C:C + 32], dw2t, ms, tapmajor=True, opts=mt)
     dw1 = torch.zeros_like(w1)
     dg2, db2, dg1, db1 = (torch.zeros(128, device=DEV), torch.zeros(128, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV))
     dbn_in = torch.empty(M, Ctot, device=DEV)
@@ -90,20 +89,18 @@ def test_dense_layer_backward(ops, B, dims, C, Ctot, ms, split, small, monkeypat
     dslab_f = dslab.clone()
     ops.bn_bwd_apply(dbn_in, slab, dslab, M, C, bn1, ops.bnbwd(e1, e2), True, dg1, db1)
     # small-M blocks: norm1 backward fused into conv1 backward-data (no dbn scratch, no apply launch) -- the whole-M kernel of
-    # dn_c1s.hip (default) and the tile-GEMM epilogue form (MMS_CONV1_SMALL_BWD=0)
-    for form in (("1", "0") if M <= 128 else ()):
-        monkeypatch.setenv("MMS_CONV1_SMALL_BWD", form)
+    # dn_c1s.hip (default) and the tile-GEMM epilogue form (MmsDnOpts.conv1_small_bwd = -1)
+    for form in ((0, -1) if M <= 128 else ()):
         dslab_g = dslab_f.clone()
         dg1f, db1f = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
         f1, f2 = stats(DEV, 1024)
         ops.conv1_bwd("data", dbn_mid, M, 128, slab, C, bn1, w1, dw1, torch.empty(M, Ctot, device=DEV), f1, f2,
-                      fuse_dx=dslab_g, fuse_dgamma=dg1f, fuse_dbeta=db1f, **kw)
+                      fuse_dx=dslab_g, fuse_dgamma=dg1f, fuse_dbeta=db1f, opts=ops.dn_opts(conv1_small_bwd=form), **kw)
         torch.cuda.synchronize()
         assert_close(dslab_g[:, :C], cl(x.grad), 1e-4, f"dx (fused norm1 backward, form {form})")
         assert_close(dg1f, n1.weight.grad, 1e-4, "dgamma1 (fused)"); assert_close(db1f, n1.bias.grad, 1e-4, "dbeta1 (fused)")
         assert torch.equal(dslab_g[:, C:], dslab[:, C:])
         assert float(f1.abs().sum()) == 0.0        # neither form touches the statistic accumulators
-    monkeypatch.delenv("MMS_CONV1_SMALL_BWD", raising=False)
     torch.cuda.synchronize()
     assert_close(dw2, c2.weight.grad, 1e-4, "dW conv2")
     assert_close(dw2m, c2.weight.grad, 1e-4, "dW conv2 (multi-tap kernel)")

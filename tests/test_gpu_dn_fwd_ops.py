@@ -23,9 +23,9 @@ def _bn_ref(x, g, b, train, rm=None, rv=None):
                                            (4, (8, 8, 4), 480, 128, 512), (4, (2, 2, 1), 992, 128, 1024),
                                            (1, (4, 4, 2), 256, 128, 1024)])
 @pytest.mark.parametrize("train", [True, False])
-@pytest.mark.parametrize("small", ["0", "1"])      # MMS_CONV1_SMALL: tile-GEMM forms / the 16 x 16 whole-K kernel of dn_c1s.hip (round 3)
-def test_conv1_fwd(ops, B, dims, K, N, ld, train, small, monkeypatch):
-    monkeypatch.setenv("MMS_CONV1_SMALL", small)
+@pytest.mark.parametrize("small", [-1, 1])      # MmsDnOpts.conv1_small: tile-GEMM forms / the 16 x 16 whole-K kernel of dn_c1s.hip (round 3)
+def test_conv1_fwd(ops, B, dims, K, N, ld, train, small):
+    o = ops.dn_opts(conv1_small=small)
     torch.manual_seed(0)
     M = B * dims[0] * dims[1] * dims[2]
     x = torch.randn(B, K, *dims) * 1.5 + 0.3
@@ -42,7 +42,7 @@ def test_conv1_fwd(ops, B, dims, K, N, ld, train, small, monkeypatch):
     os_, oq = stats(DEV, N)
     keep = (g.to(DEV), b.to(DEV), rm.to(DEV), rv.to(DEV))
     bn = ops.bnsrc(keep[0], keep[1], M, train, s, q, keep[2], keep[3])
-    ops.conv1_fwd(slab, K, w.to(DEV), y, bn, M, os_ if train else None, oq if train else None)
+    ops.conv1_fwd(slab, K, w.to(DEV), y, bn, M, os_ if train else None, oq if train else None, opts=o)
     torch.cuda.synchronize()
     assert_close(y, cl(ref), 1e-4, "conv1 y")
     if train:
@@ -51,11 +51,11 @@ def test_conv1_fwd(ops, B, dims, K, N, ld, train, small, monkeypatch):
 
 
 @pytest.mark.parametrize("M,K,ksplit", [(128, 640, 5), (16, 992, 8), (100, 288, 3), (128, 256, 2)])
-def test_conv1_fwd_ksplit(ops, M, K, ksplit, monkeypatch):
+def test_conv1_fwd_ksplit(ops, M, K, ksplit):
     """K loop split over workgroups + last-arriver fixup (no second launch): same y and statistics as the unsplit kernel;
-    repeated launches reuse the self-re-arming ticket counters.  (MMS_CONV1_SMALL=0: the tile-GEMM forms under test; the same
+    repeated launches reuse the self-re-arming ticket counters.  (MmsDnOpts.conv1_small = -1: the tile-GEMM forms under test; the same
     shapes -- ragged rows, K not a multiple of 64 -- go through the small-launch kernel at the end.)"""
-    monkeypatch.setenv("MMS_CONV1_SMALL", "0")
+    gemm, small = ops.dn_opts(conv1_small=-1), ops.dn_opts(conv1_small=1)
     torch.manual_seed(3)
     N, ld = 128, 1024
     slab = torch.randn(M, ld, device=DEV) * 1.5 + 0.3
@@ -64,21 +64,20 @@ def test_conv1_fwd_ksplit(ops, M, K, ksplit, monkeypatch):
     s, q = slab[:, :K].double().sum(0).contiguous(), (slab[:, :K].double() ** 2).sum(0).contiguous()
     bn = ops.bnsrc(g, b, M, True, s, q)
     y0 = torch.zeros(M, N, device=DEV); s0, q0 = stats(DEV, N)
-    ops.conv1_fwd(slab, K, w, y0, bn, M, s0, q0)
+    ops.conv1_fwd(slab, K, w, y0, bn, M, s0, q0, opts=gemm)
     partial = torch.full((ksplit * M * N,), float("nan"), device=DEV)
     counters = torch.zeros(64, dtype=torch.int32, device=DEV)
     for rep in range(3):
         y1 = torch.zeros(M, N, device=DEV); s1, q1 = stats(DEV, N)
-        ops.conv1_fwd(slab, K, w, y1, bn, M, s1, q1, partial=partial, ksplit=ksplit, counters=counters)
+        ops.conv1_fwd(slab, K, w, y1, bn, M, s1, q1, partial=partial, ksplit=ksplit, counters=counters, opts=gemm)
         torch.cuda.synchronize()
         assert int(counters.abs().sum()) == 0                    # re-armed
         assert_close(y1, y0, 2e-6, "ksplit y")
         assert_close(s1, s0, 1e-6, "ksplit sum"); assert_close(q1, q0, 1e-6, "ksplit sumsq")
     a = torch.relu((slab[:, :K].double() - (s / M)) / torch.sqrt(q / M - (s / M) ** 2 + 1e-5) * g.double() + b.double())
     assert_close(y1, a @ w.double().t(), 1e-4, "ksplit y vs fp64 reference")
-    monkeypatch.setenv("MMS_CONV1_SMALL", "1")
     y2 = torch.zeros(M, N, device=DEV); s2, q2 = stats(DEV, N)
-    ops.conv1_fwd(slab, K, w, y2, bn, M, s2, q2)
+    ops.conv1_fwd(slab, K, w, y2, bn, M, s2, q2, opts=small)
     torch.cuda.synchronize()
     assert_close(y2, a @ w.double().t(), 1e-4, "small-launch kernel y vs fp64 reference")
     assert_close(s2, s0, 1e-5, "small-launch sum"); assert_close(q2, q0, 1e-5, "small-launch sumsq")
@@ -107,23 +106,27 @@ def test_transition_fwd(ops, B, dims, K):
     assert_close(os_, cl(ref).double().sum(0), 1e-4, "transition sum")
 
 
-# (no tap split + W <= 16: MMS_CONV3_MT=2 takes the 64-row multi-tap kernel for M >= 1024 rows (cases 1 and 6-8; 7 = ragged last tile),
-# MMS_CONV3_MT=3 its 32-row form for every case with M >= 64 (ragged tiles, 2x2x1 and 5x3x2 grids included))
-@pytest.mark.parametrize("B,dims", [(4, (16, 16, 8)), (2, (8, 8, 4)), (4, (4, 4, 2)), (4, (2, 2, 1)), (3, (5, 3, 2)),
-                                    (4, (8, 8, 4)), (3, (7, 7, 8)), (2, (8, 16, 16))])
-@pytest.mark.parametrize("train", [True, False])
-# small: MMS_CONV3_SMALL -- None = default (the all-tap 16-row kernels of dn_c3s.hip wherever the rows' neighbourhood window fits: every grid
-# here except 16x16x8, 7x7x8, 8x16x16), "0" = off (tile-GEMM form), "1" / "2" = force one / two 16-column output tiles per wave
-# "f1" / "f2": the same with the weights in MFMA-fragment order (Conv3FwdP.wfrag -- what the network driver feeds those kernels)
-@pytest.mark.parametrize("split,mt,small", [(0, "2", None), (0, "2", "0"), (0, "2", "1"), (0, "2", "2"), (0, "2", "f1"), (0, "2", "f2"), (0, "3", None),
-                                            (27, "2", None), (3, "2", None), (5, "2", None)])
-def test_conv3_fwd(ops, B, dims, train, split, mt, small, monkeypatch):
-    monkeypatch.setenv("MMS_CONV3_MT", mt)      # take a multi-tap kernel whenever the shape allows it (default: by tile count)
-    frag = small is not None and small[0] == "f"
-    if frag and 16 + 2 * (dims[1] * dims[2] + dims[2] + 1) > 120:
-        pytest.skip("fragment-ordered weights: small grids only")
+# (no tap split + W <= 16: MmsDnOpts.conv3_mt = 2 takes the 64-row multi-tap kernel for M >= 1024 rows (cases 1 and 6-8; 7 = ragged last tile),
+# conv3_mt = 3 its 32-row form for every case with M >= 64 (ragged tiles, 2x2x1 and 5x3x2 grids included))
+_C3_GRIDS = [(4, (16, 16, 8)), (2, (8, 8, 4)), (4, (4, 4, 2)), (4, (2, 2, 1)), (3, (5, 3, 2)), (4, (8, 8, 4)), (3, (7, 7, 8)), (2, (8, 16, 16))]
+# small: MmsDnOpts.conv3_small -- None = default (the all-tap 16-row kernels of dn_c3s.hip wherever the rows' neighbourhood window fits: every
+# grid here except 16x16x8, 7x7x8, 8x16x16), "0" = off (tile-GEMM form), "1" / "2" = force one / two 16-column output tiles per wave
+# "f1" / "f2": the same with the weights in MFMA-fragment order (Conv3FwdP.wfrag -- what the network driver feeds those kernels; small grids only)
+_C3_FORMS = [(0, 2, None), (0, 2, "0"), (0, 2, "1"), (0, 2, "2"), (0, 2, "f1"), (0, 2, "f2"), (0, 3, None), (27, 2, None), (3, 2, None), (5, 2, None)]
+_small_grid = lambda dims: 16 + 2 * (dims[1] * dims[2] + dims[2] + 1) <= 120
+
+
+def _c3_opts(ops, small, **kw):
     if small is not None:
-        monkeypatch.setenv("MMS_CONV3_SMALL", small[-1])
+        kw["conv3_small"] = {"0": -1, "1": 1, "2": 2}[small[-1]]
+    return ops.dn_opts(**kw)
+
+
+@pytest.mark.parametrize("B,dims,split,mt,small", [g + f for g in _C3_GRIDS for f in _C3_FORMS if not (f[2] and f[2][0] == "f" and not _small_grid(g[1]))])
+@pytest.mark.parametrize("train", [True, False])
+def test_conv3_fwd(ops, B, dims, train, split, mt, small):
+    o = _c3_opts(ops, small, conv3_mt=mt)      # take a multi-tap kernel whenever the shape allows it (default: by tile count)
+    frag = small is not None and small[0] == "f"
     torch.manual_seed(2)
     M = B * dims[0] * dims[1] * dims[2]
     y1 = torch.randn(B, 128, *dims) + 0.1
@@ -142,7 +145,7 @@ def test_conv3_fwd(ops, B, dims, train, split, mt, small, monkeypatch):
     os_, oq = stats(DEV, 32)
     part = torch.empty(27 * M * 32, device=DEV) if split else None      # tap-split path: partial tiles + reduce kernel
     ops.conv3_fwd(y1d, coords, dims, ops.pack_conv3_frag(wd)[0] if frag else wpf, slab[:, 64:96], bn, os_ if train else None, oq if train else None, part,
-                  split or 27, wfrag=frag)
+                  split or 27, wfrag=frag, opts=o)
     torch.cuda.synchronize()
     assert_close(slab[:, 64:96], cl(ref), 1e-4, "conv3 out")
     assert float(slab[:, :64].abs().max()) == 0.0 and float(slab[:, 96:].abs().max()) == 0.0

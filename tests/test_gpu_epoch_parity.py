@@ -19,9 +19,9 @@ Two variants per style.
       measured here for the CPU oracle against its own fp64 run (2.2e-3 on the fourth batch, 5.2e-3 on the fifth) -- so agreement at 1e-4
       cannot be asked of an fp32 implementation there.  How far a correct one may drift is measured, not assumed: the oracle loop runs a
       second time in fp64 (exact for this purpose); every per-batch loss of the HIP epoch, its returned means and its BatchNorm running
-      statistics must lie within 8x the fp32 oracle's own distance from the fp64 run (running maximum over the batches so far: the drift
-      grows along the epoch) + 1e-5.  The factor is not 2 because the distances are single draws of a chaotic quantity: per-batch ratios
-      between the two fp32 implementations of 2.05 (partial) and 4.9 (simple) were measured on identical inputs.  (Raising Adam's eps to
+      statistics must lie within ENV_FACTOR x the fp32 oracle's own distance from the fp64 run (running maximum over the batches so far:
+      the drift grows along the epoch) + 1e-5.  The factor is not 1 because the distances are single draws of a chaotic quantity; it is
+      set to twice the worst HIP / oracle drift ratio recorded over the fixtures (profiles/r04_envelope_ratios.txt), not fitted higher.  (Raising Adam's eps to
       1e-3 -- which turns lr * sign(g) moves of noise-level gradient entries into negligible ones -- did NOT remove the drift: 1.5e-3 on the
       fourth batch; it is the update of the real gradient entries through 121 training-mode BatchNorm layers that is this sensitive.)
       Net effect: the returned means are bounded at ~1e-2 absolute by evidence, where the previous round accepted 3e-2 relative without.
@@ -39,6 +39,19 @@ from test_gpu_densenet import structured_volumes
 
 import os as _os
 DIMS, RNA = tuple(int(v) for v in _os.environ.get("MMS_TEST_DIMS", "64,64,32").split(",")), 96
+# How far the HIP path may sit from the fp64 run, in units of the fp32 CPU oracle's own distance from it: 2 x the worst ratio recorded on
+# the MI355X over every envelope test of the suite (profiles/r04_envelope_ratios.txt: worst 2.6 -> 6; rounds 2-3 used 8).
+ENV_FACTOR = 6.0
+
+
+def _record_ratio(test, what, ratio):
+    """Worst HIP / oracle drift ratios go to stdout and, on the GPU box, to gpurun_out/envelope_ratios.txt (-> profiles/)."""
+    line = "%s | %s | %.3f" % (test, what, ratio)
+    print("  envelope ratio:", line)
+    d = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "gpurun_out")
+    if _os.path.isdir(d):
+        with open(_os.path.join(d, "envelope_ratios.txt"), "a") as fh:
+            fh.write(line + "\n")
 
 
 def _cohort(n_extra_val=10, seed=5):
@@ -108,14 +121,31 @@ def _loaders(cohort, style, dev_cohort):
 # The fp64 run of the oracle loops is a pure CPU computation of the oracle (no HIP code in it) and, in fp64, reproducible to ~1e-12
 # on any machine: tests/golden/generate_fp64_envelope.py runs it once and commits the per-batch losses; the GPU tests read them
 # instead of spending a CPU epoch of DenseNet121 in fp64 each (the slowest part of the GPU suite).  A fixture is used only when its
-# fingerprint (initial weights, cohort, torch version) matches what the test has in hand; otherwise the leg is computed live.
+# fingerprint (initial weights, cohort, hyper-parameters, the oracle's own source text, torch version) matches what the test has in
+# hand; otherwise the leg is computed live.
 _FX_PATH = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden", "fp64_envelope.json")
 
 
-def _fingerprint(model64, tensors):
-    p = sum(float(q.detach().double().abs().sum()) for q in model64.parameters())
-    c = sum(float(torch.as_tensor(t).double().abs().sum()) for t in tensors)
-    return "%.10e|%.10e|torch %s" % (p, c, torch.__version__.split("+")[0])
+def _fingerprint(model64, tensors, hyper=""):
+    """sha256 over everything the fp64 leg depends on: the initial weights and the input tensors BYTE by byte (order-sensitive), the
+    hyper-parameter string, the text of oracle/*.py (an edited oracle loop invalidates the fixture) and the torch version."""
+    import hashlib
+    h = hashlib.sha256()
+    for q in model64.parameters():
+        h.update(q.detach().double().contiguous().numpy().tobytes())
+    for t in tensors:
+        h.update(torch.as_tensor(t).detach().double().contiguous().numpy().tobytes())
+    h.update(hyper.encode())
+    odir = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "oracle")
+    for name in sorted(n for n in _os.listdir(odir) if n.endswith(".py")):
+        with open(_os.path.join(odir, name), "rb") as fh:
+            h.update(name.encode()); h.update(fh.read())
+    return "%s|torch %s" % (h.hexdigest()[:32], torch.__version__.split("+")[0])
+
+
+def _hyper(style, lr, eps=1e-8, B=4, extra=""):
+    cls, adamw, wd = STYLES[style]
+    return "style=%s cls=%s adamw=%s lr=%g wd=%g eps=%g B=%d dropout=0 %s" % (style, cls, adamw, lr, wd, eps, B, extra)
 
 
 def _fp64_leg(key, fingerprint, compute):
@@ -137,18 +167,31 @@ def _fp64_leg(key, fingerprint, compute):
     return value
 
 
-def _fp64_epoch_leg(style, lr, ref64, cohort, eps=1e-8):
-    """fp64 run of oracle/loops.train_epoch_<style> over the 22-patient training split: -> dict(want64=[...], pb64=[[...], ...])."""
+def _fp64_epoch_leg(style, lr, ref64, cohort, eps=1e-8, split=None, buffers=False):
+    """fp64 run of oracle/loops.train_epoch_<style> over the 22-patient training split (or `split`): -> dict(want64=[...], pb64=[[...], ...]
+    [, buf64 = {BatchNorm running statistic: values} of the heads and of the encoder's first and last BatchNorm])."""
     from oracle import loops as OLP
     from multimodal_survival_prediction_amd import data
     cls, adamw, wd = STYLES[style]
     opt64 = (torch.optim.AdamW(ref64.parameters(), lr=lr, weight_decay=wd, eps=eps) if adamw
              else torch.optim.Adam(ref64.parameters(), lr=lr, weight_decay=wd, eps=eps))
     pb64 = []
-    tr_c = data.BatchLoader(cohort, np.arange(22), 4, shuffle=False, style=style)
+    tr_c = data.BatchLoader(cohort, np.arange(22) if split is None else split, 4, shuffle=False, style=style)
     want64 = getattr(OLP, "train_epoch_" + style)(ref64, _cast_loader(tr_c, torch.float64), opt64, torch.device("cpu"),
                                                   on_batch=lambda *v: pb64.append([float(x) for x in v]))
-    return dict(want64=[float(x) for x in (want64 if isinstance(want64, tuple) else (want64,))], pb64=pb64)
+    out = dict(want64=[float(x) for x in (want64 if isinstance(want64, tuple) else (want64,))], pb64=pb64)
+    if buffers:
+        out["buf64"] = {k: [float(x) for x in b.reshape(-1)] for k, b in ref64.named_buffers() if _kept_buffer(k)}
+    return out
+
+
+def _kept_buffer(k):
+    """The running statistics a lock-step envelope leg stores (the fixture stays small): every head BatchNorm1d, the stem's norm0 and the
+    encoder's last BatchNorm (norm5: downstream of all 120 others)."""
+    return "num_batches" not in k and (not k.startswith("ct_encoder") or ".norm0." in k or ".norm5." in k)
+
+
+LOCKSTEP_SPLITS = [np.arange(22), np.concatenate([np.arange(4, 22), np.arange(0, 2)])]       # second fold: other batches, no ragged tail
 
 
 def _config1_inputs(lr):
@@ -210,12 +253,11 @@ def test_epoch_and_validate_match_oracle_loops(style, lr, eps=1e-8):
     opt_ref = (torch.optim.AdamW(ref.parameters(), lr=lr, weight_decay=wd, eps=eps) if adamw
                else torch.optim.Adam(ref.parameters(), lr=lr, weight_decay=wd, eps=eps))
     fo = FusedOptimizer(net, lr=lr, weight_decay=wd, adamw=adamw, eps=eps)
-    strict = False
     cpu = torch.device("cpu")
     tol = 1e-4
     if lr != 0:
         import copy
-        ref64 = copy.deepcopy(ref).double() if not strict else None      # BEFORE the fp32 oracle steps: same initial weights
+        ref64 = copy.deepcopy(ref).double()                      # BEFORE the fp32 oracle steps: same initial weights
         _, net2 = _pair(cls, 11)                                 # a second HIP model, stepped batch by batch for the per-batch losses
     pb32 = []
     want = getattr(OLP, "train_epoch_" + style)(ref, tr_c, opt_ref, cpu, on_batch=lambda *v: pb32.append(v))
@@ -233,16 +275,8 @@ def test_epoch_and_validate_match_oracle_loops(style, lr, eps=1e-8):
                 continue                                         # forward only (:267-268): no loss term
             pbh.append(r if isinstance(r, tuple) else (r,))
         gm, wm = [(v if isinstance(v, tuple) else (v,)) for v in (got, want)]
-    if strict:
-        assert len(pbh) == len(pb32), (len(pbh), len(pb32))
-        for i, (h, a) in enumerate(zip(pbh, pb32)):
-            for u, w_ in zip(h, a):
-                print("  batch %d: fp32 oracle %.7f | HIP %+.2e" % (i, w_, u - w_))
-                assert abs(float(u) - float(w_)) <= 1e-4 * max(1.0, abs(float(w_))), (style, i, h, a)
-        for u, w_ in zip(gm, wm):
-            assert abs(u - w_) <= 1e-4 * max(1.0, abs(w_)), (style, got, want)
-    elif lr != 0:
-        leg = _fp64_leg("epoch-%s-%g" % (style, lr), _fingerprint(ref64, [cohort["image"], cohort["rnaseq"], cohort["label"]]),
+    if lr != 0:
+        leg = _fp64_leg("epoch-%s-%g" % (style, lr), _fingerprint(ref64, [cohort["image"], cohort["rnaseq"], cohort["label"]], _hyper(style, lr, eps)),
                         lambda: _fp64_epoch_leg(style, lr, ref64, cohort, eps))
         pb64 = [tuple(v) for v in leg["pb64"]]
         want64 = tuple(leg["want64"]) if len(leg["want64"]) > 1 else leg["want64"][0]
@@ -253,11 +287,11 @@ def test_epoch_and_validate_match_oracle_loops(style, lr, eps=1e-8):
             for u, v, w_ in zip(h, x, a):
                 print("  batch %d: fp64 %.7f | fp32 oracle %+.2e | HIP %+.2e | running max of the oracle's distance %.2e" % (i, v, w_ - v, u - v, env))
                 worst = max(worst, abs(float(u) - float(v)) / (env + 1e-30) if env > 1e-5 else 0.0)
-                assert abs(float(u) - float(v)) <= 8.0 * env + 1e-5 * max(1.0, abs(float(v))), (style, i, h, a, x)
-        print("  largest HIP / oracle drift ratio over the epoch: %.2f" % worst)
+                assert abs(float(u) - float(v)) <= ENV_FACTOR * env + 1e-5 * max(1.0, abs(float(v))), (style, i, h, a, x)
+        _record_ratio("test_epoch_and_validate_match_oracle_loops[%s]" % style, "per-batch losses, worst over the epoch", worst)
         xm = want64 if isinstance(want64, tuple) else (want64,)
         for u, w_, v in zip(gm, wm, xm):                         # the returned epoch means, same criterion
-            assert abs(u - v) <= 8.0 * max(env, abs(w_ - v)) + 1e-5 * max(1.0, abs(v)), (style, got, want, want64)
+            assert abs(u - v) <= ENV_FACTOR * max(env, abs(w_ - v)) + 1e-5 * max(1.0, abs(v)), (style, got, want, want64)
     if style == "final":
         # :249-262: every batch counts in the mean, the no-event batch with loss 0 (and no update)
         assert st["n_batches"] == 6 and st["n_usable"] == 5
@@ -270,12 +304,10 @@ def test_epoch_and_validate_match_oracle_loops(style, lr, eps=1e-8):
         # :257-268: batch 2 never reaches the engine, batch 1 runs the forward only
         assert st["n_batches"] == 5 and st["n_usable"] == 4
         assert lr != 0 or got == pytest.approx(want, rel=tol)
-    if strict:
-        _check_buffers(ref, net, 1e-4)
-        return
     if lr != 0:
-        # BatchNorm running statistics after the epoch: within 8x the fp32 oracle's own distance from the fp64 run (+ 1e-4 of the buffer's scale)
+        # BatchNorm running statistics after the epoch: within ENV_FACTOR x the fp32 oracle's own distance from the fp64 run (+ 1e-4 of the buffer's scale)
         b64 = dict(ref64.named_buffers())
+        wb = 0.0
         for (k, b), (_, c) in zip(ref.named_buffers(), net.named_buffers()):
             if "num_batches" in k:
                 assert int(b) == int(c), (k, int(b), int(c))
@@ -283,7 +315,10 @@ def test_epoch_and_validate_match_oracle_loops(style, lr, eps=1e-8):
             x = b64[k]
             sc_ = float(x.abs().max()) + 1e-30
             e_hip, e_f32 = float((c.cpu().double() - x).abs().max()) / sc_, float((b.double() - x).abs().max()) / sc_
-            assert e_hip <= 8.0 * e_f32 + 1e-4, (k, e_hip, e_f32)
+            assert e_hip <= ENV_FACTOR * e_f32 + 1e-4, (k, e_hip, e_f32)
+            if e_f32 > 1e-4:
+                wb = max(wb, e_hip / e_f32)
+        _record_ratio("test_epoch_and_validate_match_oracle_loops[%s]" % style, "running statistics, worst buffer (oracle drift > 1e-4)", wb)
         return
     _check_buffers(ref, net, 1e-4)
     # validate: (avg_loss, c_index) with the reference's inclusion rules
@@ -308,17 +343,21 @@ def test_epoch_and_validate_match_oracle_loops(style, lr, eps=1e-8):
     assert_close(g, w, 1e-4, "held-out hazards after one epoch")
 
 
-@pytest.mark.parametrize("lr", [0.0])
+@pytest.mark.parametrize("lr", [0.0, 1e-4])
 def test_lockstep_epoch_matches_oracle_loops(lr):
-    """The path the entry points and bench.py run: train_epoch_lockstep / validate_lockstep of a FoldGroupEngine (two fold models,
-    lazily named batches gathered on the GPU) -- each fold against the oracle's train_epoch_partial / validate_partial."""
+    """The path the entry points and bench.py run: train_epoch_lockstep / validate_lockstep of a FoldGroupEngine (two fold models on
+    the DEFAULT launch options, lazily named batches gathered on the GPU) -- each fold against the oracle's train_epoch_partial /
+    validate_partial.  lr = 0: 1e-4 and identical pair counts.  lr = 1e-4 (the scripts' value): the returned epoch means and the
+    BatchNorm running statistics within ENV_FACTOR x the fp32 oracle's own distance from its fp64 run (module docstring)."""
+    import copy
     from oracle import loops as OLP
     from multimodal_survival_prediction_amd import data, training
     from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
     cohort = _cohort()
     dev_cohort = data.cohort_to(cohort, DEV)
     pairs = [_pair("PartialModalityNet", 21), _pair("PartialModalityNet", 22)]
-    splits = [np.arange(22), np.concatenate([np.arange(4, 22), np.arange(0, 2)])]       # second fold: other batches, no ragged tail
+    refs64 = [copy.deepcopy(p[0]).double() for p in pairs] if lr != 0 else None
+    splits = LOCKSTEP_SPLITS
     group = FoldGroupEngine([p[1] for p in pairs], lr=lr, weight_decay=1e-4, adamw=False, gate_entropy_weight=0.01)
     tl = [data.BatchLoader(dev_cohort, s, 4, shuffle=False, lazy=True, with_valid=True) for s in splits]
     vl = [data.BatchLoader(dev_cohort, np.arange(22, cohort["n"]), 4, shuffle=False) for _ in splits]
@@ -326,14 +365,36 @@ def test_lockstep_epoch_matches_oracle_loops(lr):
     vgot = training.validate_lockstep(group, vl, "partial", DEV)
     for f, ((ref, net), s) in enumerate(zip(pairs, splits)):
         opt = torch.optim.Adam(ref.parameters(), lr=lr, weight_decay=1e-4)
-        tol = 1e-4 if lr == 0 else 3e-2
         want = OLP.train_epoch_partial(ref, data.BatchLoader(cohort, s, 4, shuffle=False), opt, torch.device("cpu"))
-        vwant = OLP.validate_partial(ref, data.BatchLoader(cohort, np.arange(22, cohort["n"]), 4, shuffle=False), torch.device("cpu"))
-        print("fold", f, "oracle", want, vwant, "hip", got[f], vgot[f])
-        assert got[f][0] == pytest.approx(want[0], rel=tol) and got[f][1] == pytest.approx(want[1], rel=tol)
-        _check_buffers(ref, net, 1e-4 if lr == 0 else 6e-2)
+        print("fold", f, "oracle", want, "hip", got[f], vgot[f])
         if lr == 0:
+            vwant = OLP.validate_partial(ref, data.BatchLoader(cohort, np.arange(22, cohort["n"]), 4, shuffle=False), torch.device("cpu"))
+            assert got[f][0] == pytest.approx(want[0], rel=1e-4) and got[f][1] == pytest.approx(want[1], rel=1e-4)
+            _check_buffers(ref, net, 1e-4)
             assert vgot[f][0] == pytest.approx(vwant[0], rel=1e-4) and abs(vgot[f][1] - vwant[1]) <= 1e-6
+            continue
+        leg = _fp64_leg("lockstep-partial-f%d-%g" % (f, lr),
+                        _fingerprint(refs64[f], [cohort["image"], cohort["rnaseq"], cohort["label"], torch.as_tensor(s)], _hyper("partial", lr)),
+                        lambda: _fp64_epoch_leg("partial", lr, refs64[f], cohort, split=s, buffers=True))
+        worst = 0.0
+        for u, w_, v in zip(got[f], want, leg["want64"]):
+            print("  fold %d mean: fp64 %.7f | fp32 oracle %+.2e | HIP %+.2e" % (f, v, w_ - v, u - v))
+            assert abs(u - v) <= ENV_FACTOR * abs(w_ - v) + 1e-5 * max(1.0, abs(v)), (f, got[f], want, leg["want64"])
+            if abs(w_ - v) > 1e-5:
+                worst = max(worst, abs(u - v) / abs(w_ - v))
+        _record_ratio("test_lockstep_epoch_matches_oracle_loops", "fold %d epoch means" % f, worst)
+        wb = 0.0
+        for (k, b), (_, c) in zip(ref.named_buffers(), net.named_buffers()):
+            if "num_batches" in k:
+                assert int(b) == int(c), (k, int(b), int(c))
+            elif k in leg["buf64"]:
+                x = torch.tensor(leg["buf64"][k], dtype=torch.float64).reshape(b.shape)
+                sc_ = float(x.abs().max()) + 1e-30
+                e_hip, e_f32 = float((c.cpu().double() - x).abs().max()) / sc_, float((b.double() - x).abs().max()) / sc_
+                assert e_hip <= ENV_FACTOR * e_f32 + 1e-4, (k, e_hip, e_f32)
+                if e_f32 > 1e-4:
+                    wb = max(wb, e_hip / e_f32)
+        _record_ratio("test_lockstep_epoch_matches_oracle_loops", "fold %d running statistics (heads, norm0, norm5)" % f, wb)
 
 
 def test_lockstep_epoch_from_pinned_host_cohort_matches_device_cohort():
@@ -345,7 +406,7 @@ def test_lockstep_epoch_from_pinned_host_cohort_matches_device_cohort():
     from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
     cohort = _cohort()
     assert float((cohort["mask"][:, 0] == 0).sum()) > 0 and float((cohort["mask"][:, 1] == 0).sum()) > 0      # the zero-fill branch is exercised
-    splits = [np.arange(22), np.concatenate([np.arange(4, 22), np.arange(0, 2)])]
+    splits = LOCKSTEP_SPLITS
     outs = []
     for place in (lambda c: data.cohort_to(c, DEV), data.cohort_pin):
         src = place(dict(cohort))
@@ -411,7 +472,7 @@ def test_config1_simple_fusion_ct_stubbed(lr):
     """BASELINE config 1 at its own width: simple_fusion.py, 88 synthetic complete patients, RNA-seq 5005-d, CT encoder input stubbed to
     zero volumes (the RNA-seq heads do the work), batch 4, fold 1 of 3 -- one epoch of the HIP train_epoch + validate against the oracle
     loops (dropout off).  lr = 0: train mean and validation loss at 1e-4, the C-index from IDENTICAL pair counts.  lr = 1e-4 (the
-    script's value): within 8x the fp32 oracle's own distance from its fp64 run + 1e-4 (see the module docstring)."""
+    script's value): within ENV_FACTOR x the fp32 oracle's own distance from its fp64 run + 1e-4 (see the module docstring)."""
     import copy
     from oracle import loops as OLP
     from multimodal_survival_prediction_amd import data, training
@@ -433,12 +494,14 @@ def test_config1_simple_fusion_ct_stubbed(lr):
         assert got == pytest.approx(want, rel=1e-4)
         assert vg[0] == pytest.approx(vw[0], rel=1e-4) and abs(vg[1] - vw[1]) <= 1e-6          # identical concordant / discordant pair counts
         return
-    leg = _fp64_leg("config1-%g" % lr, _fingerprint(ref64, [cohort["rnaseq"], cohort["label"], torch.as_tensor(tr)]),
+    leg = _fp64_leg("config1-%g" % lr, _fingerprint(ref64, [cohort["rnaseq"], cohort["label"], torch.as_tensor(tr)], _hyper("simple", lr, extra="config1")),
                     lambda: _fp64_config1_leg(lr, ref64, cohort, tr, va))
     want64, vw64 = leg["want64"], tuple(leg["vw64"])
     print("config 1 fp64: train", want64, "validate", vw64)
     for u, w_, v in ((got, want, want64), (vg[0], vw[0], vw64[0])):
         print("  fp64 %.7f | fp32 oracle %+.2e | HIP %+.2e" % (v, w_ - v, u - v))
-        assert abs(u - v) <= 8.0 * abs(w_ - v) + 1e-4 * max(1.0, abs(v)), (u, w_, v)
+        assert abs(u - v) <= ENV_FACTOR * abs(w_ - v) + 1e-4 * max(1.0, abs(v)), (u, w_, v)
+        if abs(w_ - v) > 1e-5:
+            _record_ratio("test_config1_simple_fusion_ct_stubbed", "train mean / validation loss", abs(u - v) / abs(w_ - v))
     n_pairs = len(va) * (len(va) - 1) / 2
     assert abs(vg[1] - vw64[1]) <= 2.0 * abs(vw[1] - vw64[1]) + 4.0 / n_pairs, (vg, vw, vw64)      # <= 4 pairs beyond the oracle's own flips

@@ -8,7 +8,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from gpu_util import DEV, rel_err
+from gpu_util import DEV, GROUP_INDEPENDENT_OPTS as GI, rel_err
 from test_gpu_models import _batch
 
 
@@ -37,11 +37,10 @@ def _kw(cls, ct, rna, clin, t, e, mask, valid):
 
 
 @pytest.mark.parametrize("cls,G", [("MultiModalSurvivalNet", 3), ("PartialModalityNet", 2), ("SimpleFusionModel", 5)])
-def test_group_step_equals_single_steps(cls, G, monkeypatch):
-    # same tap split (27-way) for the single models and the group: identical per-model arithmetic, so the comparison is
-    # tight; with the default, group-size dependent split the fp32 summation order differs and parity becomes statistical
-    # (ReLU-mask flips, see test_gpu_densenet.py) -- covered by test_group_default_split_statistical below
-    monkeypatch.setenv("MMS_SPLIT_WGS", "1000000"); monkeypatch.setenv("MMS_CONV1_KSPLIT", "0"); monkeypatch.setenv("MMS_CONV1_SMALL", "0"); monkeypatch.setenv("MMS_CONV3_MT", "0"); monkeypatch.setenv("MMS_BIG_NG", "0"); monkeypatch.setenv("MMS_MS3_ROWS", "512"); monkeypatch.setenv("MMS_CONV3W_MT", "0"); monkeypatch.setenv("MMS_MS1_DIV", "1")
+def test_group_step_equals_single_steps(cls, G):
+    # group-size independent launch options (gpu_util.GROUP_INDEPENDENT_OPTS) on both sides: identical per-model arithmetic, so the
+    # comparison is tight; with the default, group-size dependent kernel forms the fp32 summation order differs and parity becomes
+    # statistical (ReLU-mask flips, see test_gpu_densenet.py) -- covered by test_group_default_options below
     from multimodal_survival_prediction_amd.engine import SurvivalEngine
     from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
     B, dims, rna_dim = 4, (64, 64, 32), 1024
@@ -50,7 +49,7 @@ def test_group_step_equals_single_steps(cls, G, monkeypatch):
     solo = [copy.deepcopy(m).to(DEV).train() for m in base]
     grp = [copy.deepcopy(m).to(DEV).train() for m in base]
     skip = cls != "PartialModalityNet"
-    kw = dict(lr=1e-4, weight_decay=1e-3 if cls == "SimpleFusionModel" else 1e-4)
+    kw = dict(lr=1e-4, weight_decay=1e-3 if cls == "SimpleFusionModel" else 1e-4, dn_opts=GI)
     se = [SurvivalEngine(m, **kw) for m in solo]
     ge = FoldGroupEngine(grp, **kw)
     valid = torch.tensor([1, 1, 0, 1], dtype=torch.float32)
@@ -93,29 +92,48 @@ def test_group_step_equals_single_steps(cls, G, monkeypatch):
     print(f"{cls} x{G}: group == single steps")
 
 
-def test_group_default_split_statistical():
-    """Default (group-size dependent) tap split: first-step gradients agree with the single-model path statistically."""
+@pytest.mark.parametrize("G", [2, 4])
+def test_group_default_options(G):
+    """DEFAULT launch options (what bench.py and the entry points run; G = 2 is the sub-group size of the K = 5 epoch): a group of G
+    models against the same models stepped alone.  The kernel forms then differ between the two sides (group-size dependent tap
+    split, tile shapes, small-launch kernels), so sums run in another order: everything that does not pass through a ReLU-mask flip
+    agrees at the north_star 1e-4 -- training-mode losses of two steps at lr = 0 (the second a graph replay), BatchNorm running
+    statistics, head gradients -- and the encoder gradients statistically (same bound as the network-level parity tests)."""
     from multimodal_survival_prediction_amd.engine import SurvivalEngine
     from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
-    cls, G, B, dims, rna_dim = "MultiModalSurvivalNet", 4, 4, (64, 64, 32), 512
+    cls, B, dims, rna_dim = "MultiModalSurvivalNet", 4, (64, 64, 32), 512
     base = _models(cls, G, rna_dim)
     solo = [copy.deepcopy(m).to(DEV).train() for m in base]
     grp = [copy.deepcopy(m).to(DEV).train() for m in base]
-    se = [SurvivalEngine(m) for m in solo]
-    ge = FoldGroupEngine(grp)
-    batches = []
+    se = [SurvivalEngine(m, lr=0.0) for m in solo]
+    ge = FoldGroupEngine(grp, lr=0.0)
+    for it in range(2):
+        batches = []
+        for g in range(G):
+            ct, rna, clin, t, e, mask = _batch(B, dims, rna_dim, 90 + 7 * it + g)
+            batches.append(dict(ct=ct, rna=rna, clinical=clin, time=t, event=e))
+            se[g].reset_epoch_stats()
+            se[g].train_step(use_graph=it > 0, **batches[g])
+        ge.reset_epoch_stats()
+        ge.train_step(batches, use_graph=it > 0)
+        torch.cuda.synchronize()
+        for g in range(G):
+            a, b = se[g].gflat.double(), ge.engines[g].gflat.double()
+            l2 = float(((a - b) ** 2).sum().sqrt() / (a ** 2).sum().sqrt())
+            assert l2 <= 1e-2, (it, g, l2)                      # same bound as the network-level gradient parity tests
+            sa, sb = se[g].epoch_stats(), ge.engines[g].epoch_stats()
+            assert abs(sa["sum_loss"] - sb["sum_loss"]) <= 1e-4 * max(1.0, abs(sa["sum_loss"])), (it, g, sa, sb)
+            heads = [(p, q) for (k, p), (_, q) in zip(solo[g].named_parameters(), grp[g].named_parameters()) if not k.startswith("ct_encoder")]
+            gs = dict(zip((id(p) for p in se[g].params), se[g].gviews)); gg = dict(zip((id(p) for p in ge.engines[g].params), ge.engines[g].gviews))
+            for p, q in heads:
+                if float(gs[id(p)].abs().max()) > 0:
+                    assert rel_err(gg[id(q)], gs[id(p)]) <= 2e-4, (it, g)
     for g in range(G):
-        ct, rna, clin, t, e, mask = _batch(B, dims, rna_dim, 90 + g)
-        batches.append(dict(ct=ct, rna=rna, clinical=clin, time=t, event=e))
-        se[g].train_step(use_graph=False, **batches[g])
-    ge.train_step(batches, use_graph=False)
-    torch.cuda.synchronize()
-    for g in range(G):
-        a, b = se[g].gflat.double(), ge.engines[g].gflat.double()
-        l2 = float(((a - b) ** 2).sum().sqrt() / (a ** 2).sum().sqrt())
-        assert l2 <= 1e-2, (g, l2)                      # same bound as the network-level gradient parity tests
-        sa, sb = se[g].epoch_stats(), ge.engines[g].epoch_stats()
-        assert abs(sa["sum_loss"] - sb["sum_loss"]) <= 1e-4 * max(1.0, abs(sa["sum_loss"]))
+        for (k, b), (_, c) in zip(solo[g].named_buffers(), grp[g].named_buffers()):
+            if "num_batches" in k:
+                assert int(b) == int(c) == 2
+            else:
+                assert rel_err(c, b) <= 1e-4, (g, k)
 
 
 def test_group_subset_and_eval():
@@ -158,17 +176,16 @@ def test_group_rejects_mismatched_shapes():
     assert lib.mms_grad_sumsq_group(arr, 11, ops.stream()) == -1      # > MMS_MAX_GROUP
 
 
-def test_indexed_step_equals_batch_step(monkeypatch):
+def test_indexed_step_equals_batch_step():
     """train_step_indexed (one gather launch from the device-resident cohort) == train_step on the same batches."""
-    monkeypatch.setenv("MMS_SPLIT_WGS", "1000000"); monkeypatch.setenv("MMS_CONV1_KSPLIT", "0"); monkeypatch.setenv("MMS_CONV1_SMALL", "0"); monkeypatch.setenv("MMS_CONV3_MT", "0"); monkeypatch.setenv("MMS_BIG_NG", "0"); monkeypatch.setenv("MMS_MS3_ROWS", "512"); monkeypatch.setenv("MMS_CONV3W_MT", "0"); monkeypatch.setenv("MMS_MS1_DIV", "1")
     from multimodal_survival_prediction_amd import data
     from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
     cls, G, B, dims, rna_dim = "PartialModalityNet", 2, 4, (32, 32, 32), 64
     cohort = data.cohort_to(data.make_cohort(n=24, dims=dims, rna_dim=rna_dim, seed=3, complete=False), DEV)
     cohort["valid"] = cohort["has_survival"].float()
     base = _models(cls, G, rna_dim)
-    A = FoldGroupEngine([copy.deepcopy(m).to(DEV).train() for m in base])
-    Bg = FoldGroupEngine([copy.deepcopy(m).to(DEV).train() for m in base])
+    A = FoldGroupEngine([copy.deepcopy(m).to(DEV).train() for m in base], dn_opts=GI)
+    Bg = FoldGroupEngine([copy.deepcopy(m).to(DEV).train() for m in base], dn_opts=GI)
     rng = np.random.default_rng(0)
     for it in range(3):
         idx = np.stack([rng.permutation(24)[:B] for _ in range(G)])
@@ -191,10 +208,12 @@ def test_indexed_step_equals_batch_step(monkeypatch):
 
 
 @pytest.mark.parametrize("style", ["final", "partial", "simple"])
-def test_lockstep_epoch_matches_sequential(style, monkeypatch):
+@pytest.mark.parametrize("lr", [0.0, 1e-4])
+def test_lockstep_epoch_matches_sequential(style, lr):
     """train_epoch_lockstep / validate_lockstep == train_epoch_<style> / validate_<style> fold by fold (ragged fold sizes:
-    the last batch positions run as sub-groups)."""
-    monkeypatch.setenv("MMS_SPLIT_WGS", "1000000"); monkeypatch.setenv("MMS_CONV1_KSPLIT", "0"); monkeypatch.setenv("MMS_CONV1_SMALL", "0"); monkeypatch.setenv("MMS_CONV3_MT", "0"); monkeypatch.setenv("MMS_BIG_NG", "0"); monkeypatch.setenv("MMS_MS3_ROWS", "512"); monkeypatch.setenv("MMS_CONV3W_MT", "0"); monkeypatch.setenv("MMS_MS1_DIV", "1")
+    the last batch positions run as sub-groups).  lr = 0 (frozen weights, dropout on): the order of the folds cannot matter --
+    returned means and validation losses at 1e-4, C-index from identical pair counts.  lr = 1e-4: two correct fp32 runs of a
+    chaotic trajectory (atomic summation order) -- loose, liveness + bookkeeping only."""
     from multimodal_survival_prediction_amd import data, models as HM, training as T
     from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
     dims, rna_dim, K, B = (32, 32, 32), 48, 3, 4
@@ -209,7 +228,7 @@ def test_lockstep_epoch_matches_sequential(style, monkeypatch):
     for f in range(K):
         torch.manual_seed(f)
         base.append(getattr(HM, cls)(rna_dim=rna_dim))
-    kw = dict(lr=1e-4, weight_decay=1e-4, adamw=(style == "simple"))
+    kw = dict(lr=lr, weight_decay=1e-4, adamw=(style == "simple"), dn_opts=GI)
     # sequential: the reference's order
     seq = []
     for f in range(K):
@@ -226,15 +245,18 @@ def test_lockstep_epoch_matches_sequential(style, monkeypatch):
     va = T.validate_lockstep(ge, [l[1] for l in ls], style, DEV)
     for f in range(K):
         a, b = np.atleast_1d(np.asarray(seq[f][0], dtype=float)), np.atleast_1d(np.asarray(tr[f], dtype=float))
+        if lr == 0:
+            assert np.allclose(a, b, rtol=1e-4, atol=1e-6), (f, a, b)
+            assert abs(seq[f][1][0] - va[f][0]) <= 1e-4 * max(1.0, abs(seq[f][1][0])), (f, seq[f][1], va[f])
+            assert abs(seq[f][1][1] - va[f][1]) <= 1e-6, (f, seq[f][1], va[f])          # identical concordant / discordant pair counts
+            continue
         assert np.allclose(a, b, rtol=8e-2, atol=5e-3), (f, a, b)        # one epoch of chaotic fp32 training: loose on the mean loss
         assert abs(seq[f][1][0] - va[f][0]) <= 5e-2 * max(1.0, abs(seq[f][1][0])), (f, seq[f][1], va[f])
-        # C-index over <= 10 patients: one swapped pair = 0.02-0.1; the partial cohort's folds hold only 3-6 permissible pairs
-        assert abs(seq[f][1][1] - va[f][1]) <= (0.34 if style == "partial" else 0.15), (f, seq[f][1], va[f])
 
 
-def test_lockstep_two_streams_matches_one(monkeypatch):
-    """concurrent=2 (two sub-groups on two streams) trains the same folds as concurrent=1."""
-    monkeypatch.setenv("MMS_SPLIT_WGS", "1000000"); monkeypatch.setenv("MMS_CONV1_KSPLIT", "0"); monkeypatch.setenv("MMS_CONV1_SMALL", "0"); monkeypatch.setenv("MMS_CONV3_MT", "0"); monkeypatch.setenv("MMS_BIG_NG", "0"); monkeypatch.setenv("MMS_MS3_ROWS", "512"); monkeypatch.setenv("MMS_CONV3W_MT", "0"); monkeypatch.setenv("MMS_MS1_DIV", "1")
+def test_lockstep_two_streams_matches_one():
+    """concurrent=2 (two sub-groups on two streams) trains the same folds as concurrent=1: at lr = 0 (frozen weights, dropout on) the
+    returned means agree at 1e-4 whatever the stream layout."""
     from multimodal_survival_prediction_amd import data, models as HM, training as T
     from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
     dims, rna_dim, K, B = (32, 32, 32), 48, 5, 4
@@ -247,51 +269,12 @@ def test_lockstep_two_streams_matches_one(monkeypatch):
     res = []
     lazy = lambda f: data.BatchLoader(cohort, folds[f][0], B, shuffle=True, seed=10 + f, lazy=True, with_valid=False)
     for conc, mk in ((1, ld), (2, ld), (2, lazy)):      # lazy: batches named by index, assembled by the group's one gather launch
-        ge = FoldGroupEngine([copy.deepcopy(b).to(DEV) for b in base], lr=1e-4, weight_decay=1e-4)
+        ge = FoldGroupEngine([copy.deepcopy(b).to(DEV) for b in base], lr=0.0, weight_decay=1e-4, dn_opts=GI)
         res.append((T.train_epoch_lockstep(ge, [mk(f) for f in range(K)], "final", concurrent=conc), ge.epoch_stats()))
     for f in range(K):
         assert res[0][1][f]["n_batches"] == res[1][1][f]["n_batches"] == res[2][1][f]["n_batches"] == 9
         for other in (1, 2):
-            assert abs(res[0][0][f] - res[other][0][f]) <= 8e-2 * max(1.0, abs(res[0][0][f])), (f, other, res[0][0][f], res[other][0][f])
-
-
-@pytest.mark.parametrize("part", ["8,2", "4,1", "8,3"])
-def test_cu_partitioned_step_matches_unsplit(part, monkeypatch):
-    """MMS_CU_PARTITION: the step as three graphs (h1 | l | h2) on two CU-masked streams issues the launches of the unsplit step in the
-    same order -- same gradients after one step (atomic ordering aside), same bookkeeping after three."""
-    monkeypatch.setenv("MMS_SPLIT_WGS", "1000000"); monkeypatch.setenv("MMS_CONV1_KSPLIT", "0"); monkeypatch.setenv("MMS_CONV3_MT", "0"); monkeypatch.setenv("MMS_BIG_NG", "0"); monkeypatch.setenv("MMS_MS3_ROWS", "512"); monkeypatch.setenv("MMS_CONV3W_MT", "0"); monkeypatch.setenv("MMS_MS1_DIV", "1")
-    from multimodal_survival_prediction_amd import data, ops
-    from multimodal_survival_prediction_amd.fold_group import FoldGroupEngine
-    cls, G, B, dims, rna_dim = "PartialModalityNet", 2, 4, (64, 64, 32), 64
-    cohort = data.cohort_to(data.make_cohort(n=24, dims=dims, rna_dim=rna_dim, seed=3, complete=False), DEV)
-    cohort["valid"] = cohort["has_survival"].float()
-    base = _models(cls, G, rna_dim)
-    A = FoldGroupEngine([copy.deepcopy(m).to(DEV).train() for m in base])
-    Bg = FoldGroupEngine([copy.deepcopy(m).to(DEV).train() for m in base])
-    monkeypatch.setattr(ops, "_WORKER_STREAMS", {})          # the process-wide worker streams may exist already, unmasked
-    monkeypatch.setattr(ops, "_LIGHT", {})
-    rng = np.random.default_rng(0)
-    for it in range(3):
-        idx = np.stack([rng.permutation(24)[:B] for _ in range(G)])
-        monkeypatch.delenv("MMS_CU_PARTITION", raising=False)
-        A.train_step_indexed(cohort, idx, skip_if_unusable=False)
-        torch.cuda.synchronize()
-        monkeypatch.setenv("MMS_CU_PARTITION", part)
-        heavy = ops.worker_streams(DEV, 1)[0]
-        assert ops.light_partner(heavy) is not None
-        heavy.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(heavy):
-            Bg.train_step_indexed(cohort, idx, skip_if_unusable=False)
-        torch.cuda.synchronize()
-        assert any(k[0] == "train3" for GP in Bg.plans.values() for k in GP.graphs if isinstance(k, tuple)), "the partitioned path did not run"
-        if it == 0:
-            for g in range(G):
-                assert rel_err(Bg.engines[g].gflat, A.engines[g].gflat) <= 2e-5
-    for e in Bg.engines:
-        e.check_b4()
-    for a, b in zip(A.epoch_stats(), Bg.epoch_stats()):
-        assert a["n_batches"] == b["n_batches"] == 3 and a["n_usable"] == b["n_usable"]
-        assert abs(a["sum_loss"] - b["sum_loss"]) <= 5e-2 * max(1.0, abs(a["sum_loss"]))
+            assert abs(res[0][0][f] - res[other][0][f]) <= 1e-4 * max(1.0, abs(res[0][0][f])), (f, other, res[0][0][f], res[other][0][f])
 
 
 def test_training_batch_of_one_raises_like_torch():

@@ -21,7 +21,7 @@ case "$1" in
   stats)       V=("$ALL" "$ALL -DMMS_ABLATE_STATS"); run() { conv3_trace 0; } ;;
   c3m)         V=("-DC3M_TAPS=26" "-DC3M_TAPS=18" "-DC3M_TAPS=8" "-DC3M_TAPS=0"); run() { python3 $R/tools/prof_conv3fwd_group.py 0 10 2>/dev/null; } ;;
   c3w)         V=("" "-DC3W_NO_LOAD" "-DC3W_NO_MFMA" "-DC3W_NO_READ" "-DC3W_NO_LOAD -DC3W_NO_READ" "-DC3W_NO_LOAD -DC3W_NO_READ -DC3W_NO_BARRIER" "-DC3W_NO_LOAD -DC3W_NO_MFMA")
-               run() { echo "b0x10 $(MMS_CONV3W_MT=2 python3 $R/tools/prof_conv3bwdw.py 0 40 10 1024 2>/dev/null | head -1) | b0x5/512 $(MMS_CONV3W_MT=2 python3 $R/tools/prof_conv3bwdw.py 0 40 5 512 2>/dev/null | head -1)"; } ;;
+               run() { echo "b0x10 $(python3 $R/tools/prof_conv3bwdw.py 0 40 10 1024 2 2>/dev/null | head -1) | b0x5/512 $(python3 $R/tools/prof_conv3bwdw.py 0 40 5 512 2 2>/dev/null | head -1)"; } ;;
   conv3bwdw)   V=("" "-DMMS_ABLATE_FLUSH" "-DMMS_ABLATE_FLUSH -DMMS_ABLATE_MMA" "-DMMS_ABLATE_FLUSH -DMMS_ABLATE_GLOAD -DMMS_ABLATE_SSTORE")
                run() { for c in "0 40" "1 100" "2 200"; do echo -n "b${c%% *} $(python3 $R/tools/prof_conv3bwdw.py $c 10 2>/dev/null | head -1) | "; done; echo; } ;;
   conv0bw)     V=("" "-DC0_NO_EPI" "-DC0_NO_MMA" "-DC0_NO_STAGE" "-DC0_NO_MMA -DC0_NO_EPI" "-DC0_NO_STAGE -DC0_NO_EPI")

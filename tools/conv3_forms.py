@@ -1,7 +1,7 @@
 """Block-1 conv2 launches (B=4, 64x64x32 volumes: 8192 rows per model) timed per kernel FORM and sub-group size (GPU box).
 usage: python tools/conv3_forms.py [fwd|bwd_data|bwd_weight] [G ...]
-Forms are switched through the launchers' environment knobs (read at every call): fwd: MMS_CONV3_MT = 0 (per-tap GEMM form),
-3 (multi-tap, 32-row tiles), 2 (multi-tap, 64-row tiles); bwd_weight: MMS_CONV3W_MT = 0 / 2.  Prints microseconds per launch and the fraction
+Forms are selected through the launch-shape options (MmsDnOpts, include/mmsurv.h): fwd: conv3_mt = -1 (per-tap GEMM form),
+3 (multi-tap, 32-row tiles), 2 (multi-tap, 64-row tiles); bwd_weight: conv3w_mt = -1 / 2.  Prints microseconds per launch and the fraction
 of the fp32 MFMA peak (157.3 TFLOP/s)."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -9,7 +9,7 @@ import torch
 from bench import _stat_reps, _bwdw_msplit
 from multimodal_survival_prediction_amd import _lib, ops
 
-FORMS = {"fwd": ("MMS_CONV3_MT", ("0", "3", "2", None)), "bwd_data": ("MMS_CONV3D_MT", ("0", "3", None)), "bwd_weight": ("MMS_CONV3W_MT", ("0", "2", None))}
+FORMS = {"fwd": ("conv3_mt", (-1, 3, 2, 0)), "bwd_data": ("conv3_mt", (0,)), "bwd_weight": ("conv3w_mt", (-1, 2, 0))}
 
 
 def main():
@@ -48,28 +48,18 @@ def main():
             else:
                 ps.append(S["Conv3BwdWP"](y1.data_ptr(), coords.data_ptr(), ops.dims3(gd), M, bn, dz.data_ptr(), dz.stride(0),
                                           dwp.data_ptr(), int(os.environ.get("MSPLIT", _bwdw_msplit(M, G))), 1))
-        if op == "bwd_weight":            # the driver's chunking per form (bench._bwdw_msplit reads the knob), unless MSPLIT overrides it
-            def chunk(form):
-                os.environ[env] = form
-                for q in ps:
-                    q.msplit = int(os.environ.get("MSPLIT", _bwdw_msplit(M, G)))
         name = {"fwd": "Conv3FwdP", "bwd_data": "Conv3BwdDataP", "bwd_weight": "Conv3BwdWP"}[op]
         fn = getattr(lib, "mms_conv3_%s_group" % op)
         arr = (S[name] * G)(*ps)
+        import ctypes
         for form in forms:
-            if form is None:
-                os.environ.pop(env, None)
-            else:
-                os.environ[env] = form
-            if op == "bwd_weight":
-                chunk(form)
-                arr = (S[name] * G)(*ps)
+            o = ops.dn_opts(**{env: form})
             for _ in range(3):
-                _lib.check(fn(arr, G, ops.stream()), op)
+                _lib.check(fn(arr, G, ctypes.byref(o), ops.stream()), op)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(20):
-                _lib.check(fn(arr, G, ops.stream()), op)
+                _lib.check(fn(arr, G, ctypes.byref(o), ops.stream()), op)
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / 20

@@ -24,7 +24,7 @@ for g in range(G):
                                   coords.data_ptr(), M, dw.data_ptr(), 64, dg.data_ptr(), db.data_ptr()))
 arr = (S["Conv0BwdWP"] * G)(*blocks)
 def launch():
-    _lib.check(lib.mms_conv0_bwd_weight_group(arr, G, ops.stream()), "conv0bw")
+    _lib.check(lib.mms_conv0_bwd_weight_group(arr, G, None, ops.stream()), "conv0bw")
 for _ in range(3): launch()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

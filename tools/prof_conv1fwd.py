@@ -25,7 +25,7 @@ for g in range(G):
     blocks.append(p)
 arr = (S["Conv1FwdP"] * G)(*blocks)
 def launch():
-    _lib.check(lib.mms_conv1_fwd_group(arr, G, ops.stream()), "conv1_fwd_group")
+    _lib.check(lib.mms_conv1_fwd_group(arr, G, None, ops.stream()), "conv1_fwd_group")
 for _ in range(5): launch()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

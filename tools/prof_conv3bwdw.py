@@ -1,6 +1,6 @@
 """Microbench of the dominant kernel (conv3 weight gradient) at one DenseNet block shape, launched as the training step
 launches it (one launch = the G models of a fold group), for rocprofv3 --pmc passes.
-usage: prof_conv3bwdw.py <block 0..3> <reps> [G=5]"""
+usage: prof_conv3bwdw.py <block 0..3> <reps> [G=5] [rows per chunk] [mt: -1 = one-tap GEMM form, 2 = multi-tap kernel, 0 = by launch size]"""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multimodal_survival_prediction_amd import ops, _lib
@@ -32,12 +32,14 @@ for _ in range(G):
     keep.append((y1, s, q, dslab, dwp))
     blocks.append(S["Conv3BwdWP"](y1.data_ptr(), coords.data_ptr(), ops.dims3(gd), M, bn, dz.data_ptr(), dz.stride(0), dwp.data_ptr(), ms, 1))
 arr = (S["Conv3BwdWP"] * G)(*blocks)
+import ctypes
+opt = ops.dn_opts(conv3w_mt=int(sys.argv[5]) if len(sys.argv) > 5 else 0)
 for _ in range(3):
-    _lib.check(lib.mms_conv3_bwd_weight_group(arr, G, ops.stream()), "conv3_bwd_weight_group")
+    _lib.check(lib.mms_conv3_bwd_weight_group(arr, G, ctypes.byref(opt), ops.stream()), "conv3_bwd_weight_group")
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(reps):
-    _lib.check(lib.mms_conv3_bwd_weight_group(arr, G, ops.stream()), "conv3_bwd_weight_group")
+    _lib.check(lib.mms_conv3_bwd_weight_group(arr, G, ctypes.byref(opt), ops.stream()), "conv3_bwd_weight_group")
 e1.record()
 torch.cuda.synchronize()
 print("us per launch %.1f" % (e0.elapsed_time(e1) * 1e3 / reps))

@@ -25,7 +25,7 @@ for g in range(G):
                                  os_.data_ptr(), oq.data_ptr(), None, 27))
 arr = (S["Conv3FwdP"] * G)(*blocks)
 def launch():
-    _lib.check(lib.mms_conv3_fwd_group(arr, G, ops.stream()), "conv3_fwd_group")
+    _lib.check(lib.mms_conv3_fwd_group(arr, G, None, ops.stream()), "conv3_fwd_group")
 for _ in range(3): launch()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
