@@ -37,7 +37,7 @@ struct Plan {
     size_t stats_begin, stats_end;
     size_t st_y0, st_slab[NB], st_y1[NLAYER];          // forward (sum | sumsq), each 2*C doubles
     size_t counters;                                   // split-fixup tickets (zeroed at init, re-armed by their users)
-    size_t b4_cnt, b4_err, b4_xa, b4_xb, b4_tab;       // block-4 persistent kernels (dn_b4.hip): counters (inside the per-step zeroed region), sticky error word, hand-off buffers, layer table
+    size_t b4_cnt, b4_ga, b4_gb, b4_err, b4_xa, b4_tab;       // block-4 persistent kernels (dn_b4.hip): counters + granule hand-off buffers (inside the per-step zeroed region), sticky error word, backward hand-off buffer, layer table
     size_t bb_y0, bb_y1[NLAYER], bb_in[NLAYER], bb_tr[3], bb_head;   // backward (s1 | s2)
     size_t total;
 };
@@ -108,11 +108,12 @@ bool make_plan(Plan& P, int B, int D, int H, int W) {
     for (int i = 0; i < 3; ++i) P.bb_tr[i] = take((size_t)P.R[i] * 2 * 1024 * 8);
     P.bb_head = take((size_t)2 * 1024 * 8);
     P.b4_cnt = take(256);
+    P.b4_ga = take((size_t)8 * 256 * 8);         // {tag, value} granules of the forward's two hand-offs: zero before every launch
+    P.b4_gb = take((size_t)8 * 512 * 8);
     P.stats_end = o;
     P.counters = take(4096 * 4);
     P.b4_err = take(1024);
     P.b4_xa = take((size_t)8 * 256 * 4);
-    P.b4_xb = take((size_t)8 * 512 * 4);
     P.b4_tab = take(sizeof(B4Layer) * LAYERS[3]);
     P.total = o;
     return true;
@@ -383,11 +384,11 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
             FOR_G {
                 const Ctx& c = cx[g];
                 q[g] = B4FwdP{at<B4Layer>(c.ws, P.b4_tab), LAYERS[3], C0[3], at<float>(c.ws, P.slab[3]), CTOT[3], at<double>(c.ws, P.st_slab[3]),
-                              at<int>(c.ws, P.coords[3]), P.g[3], P.M[3], train, 1e-5f, at<float>(c.ws, P.b4_xa), at<float>(c.ws, P.b4_xb),
-                              at<unsigned>(c.ws, P.b4_cnt), at<unsigned>(c.ws, P.b4_err)};
+                              at<int>(c.ws, P.coords[3]), P.g[3], P.M[3], train, 1e-5f, at<unsigned long long>(c.ws, P.b4_ga), at<unsigned long long>(c.ws, P.b4_gb),
+                              at<unsigned>(c.ws, P.b4_err)};
                 regs[g] = at<void>(c.ws, P.b4_cnt);
             }
-            if (!train) TRY(mms_zero_regions_group(regs, ng, 256, s));      // (training: the statistics zero-fill above covers the counters)
+            if (!train) TRY(mms_zero_regions_group(regs, ng, P.stats_end - P.b4_cnt, s));      // counters + granules (training: the statistics zero-fill above covers them)
             TRYS(32, mms_b4_fwd_group(q, ng, s));
             l += LAYERS[3];
             continue;

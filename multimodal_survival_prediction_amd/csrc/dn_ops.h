@@ -56,8 +56,8 @@ struct B4FwdP {
     double* st_slab;                           // (sum | sumsq) [2][ld], one replica (train)
     const int* coords; Dims3 g; int M;         // M <= 16 rows
     int train; float eps;
-    float* xa; float* xb;                      // hand-off buffers [8][256], [8][512]
-    unsigned* counter; unsigned* err;          // counter: zero on entry; err: sticky time-out flag
+    unsigned long long* xa; unsigned long long* xb;      // granule hand-off buffers [8][256], [8][512] of {tag, value} words: ZERO on entry
+    unsigned* err;                             // sticky time-out flag
 };
 extern "C" int mms_b4_fwd_group(const B4FwdP* pp, int ng, hipStream_t s);
 struct B4BwdP {                // the data path of block 4's backward (dslab -> norm2/conv2 -> norm1/conv1 -> dslab, layer 15 .. 0) as one launch

@@ -125,8 +125,9 @@ def test_group_default_options(G):
             assert abs(sa["sum_loss"] - sb["sum_loss"]) <= 1e-4 * max(1.0, abs(sa["sum_loss"])), (it, g, sa, sb)
             heads = [(p, q) for (k, p), (_, q) in zip(solo[g].named_parameters(), grp[g].named_parameters()) if not k.startswith("ct_encoder")]
             gs = dict(zip((id(p) for p in se[g].params), se[g].gviews)); gg = dict(zip((id(p) for p in ge.engines[g].params), ge.engines[g].gviews))
+            top = max(float(gs[id(p)].abs().max()) for p, _ in heads)
             for p, q in heads:
-                if float(gs[id(p)].abs().max()) > 0:
+                if float(gs[id(p)].abs().max()) > 1e-5 * top:          # (a bias in front of a BatchNorm has a gradient of rounding noise only)
                     assert rel_err(gg[id(q)], gs[id(p)]) <= 2e-4, (it, g)
     for g in range(G):
         for (k, b), (_, c) in zip(solo[g].named_buffers(), grp[g].named_buffers()):
