@@ -91,17 +91,20 @@ def measure_conv2_family(B, dims, device, G, reps=20):
     launches each per lock-step step, together the largest share of GPU time in profiles/.  Each is timed live with HIP
     events on the launch stream (torch's current stream), launched exactly as the step launches it: one launch carries the G
     models of a sub-group, shape by shape (the four dense blocks) with the driver's own split factors, weighted by the layer
-    counts.  Algorithmic FLOPs per launch of any of the three = G * 2 * M * 27 * 128 * 32.  (Block 4's forward launches do not exist in
-    the step when the block runs as one persistent launch per pass, csrc/dn_b4.hip: they are then left out of the forward / backward-data
-    ops' averages; its weight-gradient launches remain.)
+    counts.  Algorithmic FLOPs per launch of any of the three = G * 2 * M * 27 * 128 * 32.  (The per-layer launches of a dense block that
+    runs as one persistent launch per pass, csrc/dn_cl.hip / dn_b4.hip, do not exist in the step: they are left out of the forward /
+    backward-data ops' averages; the weight-gradient launches remain.)
     -> {op: (avg seconds per launch, avg FLOPs per launch, launches per step)}"""
     from multimodal_survival_prediction_amd import _lib, ops
     lib, S = _lib.load_library(), _lib.structs()
     D, H, W = dims
     gam, bet = torch.ones(128, device=device), torch.zeros(128, device=device)
     tot = {k: [0.0, 0.0, 0] for k in ("fwd", "bwd_data", "bwd_weight")}
-    b4_one = B * (D // 32) * (H // 32) * (W // 32) <= 16 and ops.persistent_b4_fits(device, G)       # (fold_group.FoldGroupEngine._opts_arg)
-    b4_bwd = b4_one                                                                     # block 4's backward data path is one launch too
+    # dense blocks that run as ONE persistent launch per pass have no per-layer conv2 launches (dn_net.hip cluster_block; the residency
+    # rule of fold_group.FoldGroupEngine._opts_arg)
+    po, cw = ops.persistent_opts(ops.dn_opts(), device, G, B, dims), ops.cluster_workgroups(B, dims)
+    cl_fwd = {2: cw[0] > 0 and po.persist_b3 > 0, 3: cw[1] > 0 and po.persist_b4 >= 0}
+    cl_bwd = {2: False, 3: cw[1] == 8 and po.persist_b4 == 0}
     w = torch.randn(32, 128, 3, 3, 3, device=device) * 0.03
     wpf, wpb = ops.pack_conv3(w)
     wff, wfb = ops.pack_conv3_frag(w)
@@ -110,7 +113,7 @@ def measure_conv2_family(B, dims, device, G, reps=20):
         M = B * gd[0] * gd[1] * gd[2]
         R = _stat_reps(M)
         ns = _conv3_nsplit(M, G, gd)
-        frag = i < 3 and 16 + 2 * (gd[1] * gd[2] + gd[2] + 1) <= 120      # dn_net.hip conv3_frag_block
+        frag = i < 3 and 16 + 2 * (gd[1] * gd[2] + gd[2] + 1) <= 120 and not cl_fwd.get(i, False)      # dn_net.hip conv3_frag_block
         coords = ops.init_coords(B, gd, device)
         keep, fw, bd, bw = [], [], [], []
         for _ in range(G):
@@ -137,7 +140,7 @@ def measure_conv2_family(B, dims, device, G, reps=20):
                 "bwd_data": ((S["Conv3BwdDataP"] * G)(*bd), lib.mms_conv3_bwd_data_group),
                 "bwd_weight": ((S["Conv3BwdWP"] * G)(*bw), lib.mms_conv3_bwd_weight_group)}
         for op, (arr, fn) in arrs.items():
-            if i == 3 and ((op == "fwd" and b4_one) or (op == "bwd_data" and b4_bwd)):
+            if (op == "fwd" and cl_fwd.get(i, False)) or (op == "bwd_data" and cl_bwd.get(i, False)):
                 continue
             for _ in range(3):
                 _lib.check(fn(arr, G, None, ops.stream()), op)          # (launch-shape options: NULL = the defaults the step runs with)

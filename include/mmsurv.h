@@ -50,6 +50,9 @@ typedef struct MmsDnOpts {
     int persist_b4;        /* dense block 4 with <= 16 rows as ONE launch per pass (csrc/dn_b4.hip): 0 = both passes, 1 = forward only,
                               -1 = per-layer launches.  The persistent launches need their 8 workgroups per model co-resident: a caller
                               that may have more of them in flight than the chip has CUs passes -1 */
+    int persist_b3;        /* dense block 3's forward as one persistent launch when a sample has <= 32 voxels there (csrc/dn_cl.hip: clusters
+                              of 8 workgroups per sample, BatchNorm partial sums exchanged between them): 1 = on; 0 (default) / -1 = per-layer
+                              launches -- measured faster at 32 voxels per sample (profiles/r04_cluster_kernels.txt) */
     int split_wgs;         /* target workgroups of a tap-split conv2 launch, 0 = 256 */
     int conv1_ksplit;      /* -1 = never split the conv1 K loop over workgroups (0 = by launch size) */
     int conv1_small;       /* whole-K 16x16-tile conv1 forward (csrc/dn_c1s.hip): 0 = launches of <= c1s_max_wgs tiles, 1 = whenever the

@@ -48,333 +48,6 @@ __device__ __forceinline__ bool b4_wait(unsigned* counter, unsigned* err, unsign
     return *s_ok != 0;
 }
 
-// Granule form of a hand-off (round 4; cdna_hip_programming.md, Guideline 16, R2 "the data IS the flag"): every handed-off float travels
-// as ONE naturally aligned 8-byte {tag, value} word written by one agent-scope (sc1, write-through) store; a consumer lane re-reads ITS
-// granules with agent-scope loads until every tag equals the phase's tag.  No counter, no vmcnt drain, no barrier on the producer side and
-// one memory round trip on the consumer side -- against store-ack -> barrier -> atomic add -> poll -> payload load of the counter form
-// (measured with -DB4_TIMING, round 3 kernels: 6.0 + 1.8 us of the 14.3 us per layer sat in the two counter hand-offs).
-// STATE: the granule buffers are zeroed before every launch (tags are 1.. within a step, never 0): the forward driver's per-step
-// zero-fill covers them.  A buffer is rewritten with the next phase's tag only after every consumer has finished reading the previous
-// one (a workgroup publishes phase k + 2 into a buffer only after it has consumed phase k + 1 from ALL workgroups, which each of them
-// publishes only after consuming phase k).
-typedef unsigned long long b4_u64;
-__device__ __forceinline__ void g_store(b4_u64* g, unsigned tag, float v) {
-    __hip_atomic_store(g, ((b4_u64)tag << 32) | (b4_u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// Every lane of the calling WAVE sweeps its N granules g[k * S] until all of the wave's tags match.  Bounded: ~0.3 s of wall clock
-// (100 MHz counter) or another workgroup's raised error word end the sweep with `false` (and raise the word), so the grid always drains.
-template <int N>
-__device__ __forceinline__ bool g_sweep(const b4_u64* g, int S, unsigned tag, float (&v)[N], unsigned* err) {
-    const unsigned long long t0 = wall_clock64();
-    for (unsigned spins = 1;; ++spins) {
-        bool ok = true;
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-            const b4_u64 x = __hip_atomic_load(g + (size_t)k * S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            v[k] = __uint_as_float((unsigned)x);
-            ok = ok && (unsigned)(x >> 32) == tag;
-        }
-        if (__all(ok)) return true;
-        if ((spins & 31u) == 0u) {
-            const bool late = wall_clock64() - t0 > 30000000ull;
-            if (late || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                if (late) atomicExch(err, 1u);
-                return false;
-            }
-        }
-        __builtin_amdgcn_s_sleep(1);
-    }
-}
-
-__global__ __launch_bounds__(256) void b4_fwd_kernel(const Grp<B4FwdP> grp) {
-    const B4FwdP& p = grp.p[blockIdx.z];
-    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, k4 = lane >> 4;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    B4Layer* tabs = (B4Layer*)smem;            // [16] the block's layer table (pointer reads from LDS, not through a dependent global load)
-    float* xs = smem + 512;                    // [16][B4P] raw slab (rows >= M stay zero)
-    float* mu = xs + B4R * B4P;                // [1024] batch mean of every slab channel (train)
-    float* rs = mu + 1024;                     // [1024] batch rstd
-    float* mn1 = rs + 1024;                    // [1024] norm1 of the current layer: mean | gamma * rstd | beta
-    float* sc1 = mn1 + 1024;
-    float* be1 = sc1 + 1024;
-    float* a2s = be1 + 1024;                   // [16][B4A2P] gathered relu(bn2(y1))
-    float* red = a2s + B4R * B4A2P;            // [4][256] cross-wave sums, then scratch
-    double* dred = (double*)(red + 1024);      // [512] column-statistic partials of the four waves
-    int* nbt = (int*)(dred + 512);             // [27][16] neighbour row of (tap, row), -1 = zero padding
-    int* live = nbt + 27 * 16;                 // [0] = number of live taps, [1..27] = their indices, [31] = "a sweep timed out"
-    int& s_fail = live[31];
-    const int M = p.M, C0 = p.C0, ld = p.ld;
-    const float inv_m = 1.0f / (float)M;
-    const int row = tid >> 4, col = tid & 15;
-    const int n0 = 16 * w;                      // this workgroup's conv1 output channels
-
-    // ---- set-up: layer table, slab columns [0, C0) and their statistics, neighbour table, live taps ------------------------
-    static_assert(sizeof(B4Layer) == 120, "layer table entry");
-    for (int i = tid; i < p.nlayers * 30; i += 256) ((unsigned*)tabs)[i] = ((const unsigned*)p.tab)[i];
-    if (tid == 0) s_fail = 0;
-    {   // every load of a batch of 8 float4 per thread is issued before the first LDS store (one memory round trip per batch)
-        const int n4 = C0 >> 2, tot4 = B4R * n4;
-        for (int base = 0; base < tot4; base += 2048) {
-            float4 r[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int i4 = base + tid + 256 * j, m = i4 / n4, k = (i4 - m * n4) << 2;
-                r[j] = (i4 < tot4 && m < M) ? *(const float4*)(p.slab + (size_t)m * ld + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int i4 = base + tid + 256 * j, m = i4 / n4, k = (i4 - m * n4) << 2;
-                if (i4 < tot4) *(float4*)(xs + m * B4P + k) = r[j];
-            }
-        }
-    }
-    if (p.train) {
-        double sv[4], qv[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const int k = tid + 256 * j, kk = k < C0 ? k : 0; sv[j] = p.st_slab[kk]; qv[j] = p.st_slab[ld + kk]; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = tid + 256 * j;
-            const double m_ = sv[j] * (double)inv_m;
-            double v = qv[j] * (double)inv_m - m_ * m_;
-            v = v > 0.0 ? v : 0.0;
-            if (k < C0) { mu[k] = (float)m_; rs[k] = 1.0f / sqrtf((float)v + p.eps); }
-        }
-    }
-    for (int idx = tid; idx < 27 * B4R; idx += 256) {
-        const int tap = idx >> 4, m = idx & 15;
-        int nb = -1;
-        if (m < M) {
-            int d, h, x;
-            unpack_dhw(p.coords[m], d, h, x);
-            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-            const int nd = d + kd - 1, nh = h + kh - 1, nw = x + kw - 1;
-            if ((unsigned)nd < (unsigned)p.g.D && (unsigned)nh < (unsigned)p.g.H && (unsigned)nw < (unsigned)p.g.W)
-                nb = m + ((kd - 1) * p.g.H + (kh - 1)) * p.g.W + (kw - 1);
-        }
-        nbt[idx] = nb;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int n = 0;
-        for (int tap = 0; tap < 27; ++tap) {
-            bool any = false;
-            for (int m = 0; m < M; ++m) any = any || nbt[tap * 16 + m] >= 0;
-            if (any) live[1 + n++] = tap;
-        }
-        live[0] = n;
-    }
-    __syncthreads();
-    const int nlive = live[0];
-
-    // Weights never depend on activations: a layer's conv1 slice (<= 16 float4 per lane), its conv2 tap slices (16 float4 per lane) and
-    // its BatchNorm parameters are requested right after the PREVIOUS layer's second hand-off -- their latency hides under that layer's
-    // statistics and this layer's norm1 set-up, and no load of theirs is in flight while a wave sweeps granules (a wave's loads return
-    // in order: a sweep issued behind 64 KB of weight loads would wait for all of them).
-    const int nt = wave & 1, half = wave >> 1;
-    float4 wreg[16];
-    float4 treg[4][4];
-    int mytap[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { const int li = w + B4W * i; mytap[i] = li < nlive ? live[1 + li] : -1; }
-    auto load_w1 = [&](int l) __attribute__((always_inline)) {
-        const int C = C0 + 32 * l, nT = C >> 4;
-        const float* w1 = tabs[l].w1;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int t = wave + 4 * i;
-            wreg[i] = t < nT ? *(const float4*)(w1 + (size_t)(n0 + r16) * C + 16 * t + 4 * k4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto load_taps = [&](int l) __attribute__((always_inline)) {
-        const float* wpf = tabs[l].wpf;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                treg[i][t] = mytap[i] >= 0 ? *(const float4*)(wpf + ((size_t)(16 * nt + r16) * 27 + mytap[i]) * 128 + 64 * half + 16 * t + 4 * k4)
-                                            : make_float4(0.f, 0.f, 0.f, 0.f);
-    };
-    // norm1 parameters of the layer's C channels (<= 4 per thread): gamma | beta [| running mean | running var]; norm2's of this
-    // workgroup's 16 channels (thread's column): gamma | beta [| running mean | running var]
-    float cg[4], cb[4], cm[4], cv[4], g2v, b2v, m2v, v2v;
-    auto load_c1 = [&](int l) __attribute__((always_inline)) {
-        const int C = C0 + 32 * l;
-        const B4Layer& T = tabs[l];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = tid + 256 * j, kk = k < C ? k : C - 1;
-            cg[j] = T.g1[kk]; cb[j] = T.b1[kk];
-            if (!p.train) { cm[j] = T.rm1[kk]; cv[j] = T.rv1[kk]; } else { cm[j] = 0.f; cv[j] = 1.f; }
-        }
-        g2v = T.g2[n0 + col]; b2v = T.b2[n0 + col];
-        if (!p.train) { m2v = T.rm2[n0 + col]; v2v = T.rv2[n0 + col]; } else { m2v = 0.f; v2v = 1.f; }
-    };
-    load_w1(0);
-    load_c1(0);
-    load_taps(0);
-
-#ifdef B4_TIMING
-    unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tl = wall_clock64();
-#define B4_T(i) do { if (tid == 0) { const unsigned long long n_ = wall_clock64(); tacc[i] += n_ - tl; tl = n_; } } while (0)
-#else
-#define B4_T(i)
-#endif
-    for (int l = 0; l < p.nlayers; ++l) {
-        const int C = C0 + 32 * l, nT = C >> 4;                 // K super-steps of 16 channels
-        const B4Layer& L = tabs[l];
-        B4_T(0);
-        // a. norm1 constants of this layer for the C input channels (train: the channels' batch statistics, cached since they were
-        //    produced; eval: this layer's running statistics); the transform itself rides in the MFMA loop's operand reads
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = tid + 256 * j;
-            if (k < C) {
-                float m_, r_;
-                if (p.train) { m_ = mu[k]; r_ = rs[k]; } else { m_ = cm[j]; r_ = 1.0f / sqrtf(cv[j] + p.eps); }
-                mn1[k] = m_; sc1[k] = cg[j] * r_; be1[k] = cb[j];
-            }
-        }
-        __syncthreads();
-        B4_T(1);
-        // b. conv1: 16 rows x 16 channels, K split over the waves; A = relu(bn1(x)) built from the LDS slab on the fly
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const float rowz = r16 < M ? 1.f : 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int t = wave + 4 * i;
-            if (t < nT) {
-                const int k = 16 * t + 4 * k4;
-                const float4 x = *(const float4*)(xs + r16 * B4P + k), m4 = *(const float4*)(mn1 + k), s4 = *(const float4*)(sc1 + k),
-                             b4 = *(const float4*)(be1 + k);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rowz * fmaxf(bn_apply(x.x, m4.x, s4.x, b4.x), 0.f), wreg[i].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rowz * fmaxf(bn_apply(x.y, m4.y, s4.y, b4.y), 0.f), wreg[i].y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rowz * fmaxf(bn_apply(x.z, m4.z, s4.z, b4.z), 0.f), wreg[i].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rowz * fmaxf(bn_apply(x.w, m4.w, s4.w, b4.w), 0.f), wreg[i].w, acc, 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave * 256 + (4 * k4 + r) * 16 + r16] = acc[r];
-        __syncthreads();
-        const float y = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid];       // y1[row][n0 + col]
-        // c. BatchNorm2 statistics of the 16 channels (all rows are here): rows 4 wave .. 4 wave + 3 by lane shuffles, the four waves
-        //    through LDS; every thread then holds its column's complete sums.  y1 + statistics saved for the backward
-        float m_, r_;
-        if (p.train) {
-            double s = row < M ? (double)y : 0.0, q = s * s;
-            s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);
-            s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
-            if (lane < 16) { dred[wave * 32 + lane] = s; dred[128 + wave * 32 + lane] = q; }
-            __syncthreads();
-            s = ((dred[col] + dred[32 + col]) + dred[64 + col]) + dred[96 + col];
-            q = ((dred[128 + col] + dred[160 + col]) + dred[192 + col]) + dred[224 + col];
-            const double mm = s * (double)inv_m;
-            double v = q * (double)inv_m - mm * mm;
-            v = v > 0.0 ? v : 0.0;
-            m_ = (float)mm; r_ = 1.0f / sqrtf((float)v + p.eps);
-            if (tid < 16) { L.st_y1[n0 + tid] = s; L.st_y1[128 + n0 + tid] = q; }
-            if (row < M) L.y1[(size_t)row * 128 + n0 + col] = y;
-        } else {
-            m_ = m2v; r_ = 1.0f / sqrtf(v2v + p.eps);
-        }
-        const unsigned tagA = 2u * (unsigned)l + 1u, tagB = tagA + 1u;
-        g_store(p.xa + w * 256 + tid, tagA, row < M ? fmaxf(bn_apply(y, m_, g2v * r_, b2v), 0.f) : 0.f);
-        // ---- hand-off A: gather the 16 x 128 relu(bn2(y1)) ------------------------------------------------------------------
-        B4_T(2);
-        {
-            float v[8];
-            const bool ok = g_sweep<8>(p.xa + tid, 256, tagA, v, p.err);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a2s[row * B4A2P + 16 * j + col] = v[j];
-            if (!ok) s_fail = 1;
-        }
-        B4_T(3);
-        __syncthreads();
-        if (s_fail) return;
-        // e. conv2: this workgroup's live taps; wave = (output-channel tile nt, input-channel half)
-        f32x4 zc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (mytap[i] >= 0) {
-                const int nb = nbt[mytap[i] * 16 + r16];
-                const float* ar = a2s + (nb >= 0 ? nb : 0) * B4A2P + 64 * half + 4 * k4;
-                const float z = nb >= 0 ? 1.f : 0.f;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float4 av = *(const float4*)(ar + 16 * t);
-                    zc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x * z, treg[i][t].x, zc, 0, 0, 0);
-                    zc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y * z, treg[i][t].y, zc, 0, 0, 0);
-                    zc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z * z, treg[i][t].z, zc, 0, 0, 0);
-                    zc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w * z, treg[i][t].w, zc, 0, 0, 0);
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave * 256 + (4 * k4 + r) * 16 + r16] = zc[r];      // [wave][row][co within the tile]
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 2; ++j)              // partial z[row][co]: co tile nt = j, halves summed (waves j and j + 2)
-            g_store(p.xb + w * 512 + row * 32 + 16 * j + col, tagB, red[j * 256 + tid] + red[(j + 2) * 256 + tid]);
-        // ---- hand-off B: gather the 8 partial 16 x 32 outputs -----------------------------------------------------------------
-        B4_T(4);
-        float zv[2][8];
-        {
-            float v[16];
-            const bool ok = g_sweep<16>(p.xb + tid, 256, tagB, v, p.err);      // granule (q, e = tid + 256 j) at q * 512 + e: k = 2 q + j
-#pragma unroll
-            for (int k = 0; k < 16; ++k) zv[k & 1][k >> 1] = v[k];
-            if (!ok) s_fail = 1;
-        }
-        B4_T(5);
-        if (l + 1 < p.nlayers) { load_w1(l + 1); load_c1(l + 1); load_taps(l + 1); }      // next layer's weights: ~2 us / ~6 us ahead of their use
-        {
-            double sq[2][2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int e = tid + 256 * j, zr = e >> 5, co = e & 31;
-                const float (&v)[8] = zv[j];
-                float z = v[0];
-#pragma unroll
-                for (int q = 1; q < 8; ++q) z += v[q];                    // fixed order: deterministic, identical in every workgroup
-                if (zr >= M) z = 0.f;
-                xs[zr * B4P + C + co] = z;
-                if (w == 0 && zr < M) p.slab[(size_t)zr * ld + C + co] = z;
-                // column statistics of the 32 new channels: thread e covers (row e >> 5, channel e & 31); a wave = 2 rows x 32 channels
-                double s = (double)z, q2 = s * s;
-                s += __shfl_xor(s, 32, 64); q2 += __shfl_xor(q2, 32, 64);
-                sq[j][0] = s; sq[j][1] = q2;
-            }
-            if (p.train) {
-                // rows {2 wave, 2 wave + 1} (j = 0) and {8 + 2 wave, 9 + 2 wave} (j = 1): 8 partials per channel
-                if (lane < 32) {
-                    dred[wave * 32 + lane] = sq[0][0]; dred[128 + wave * 32 + lane] = sq[0][1];
-                    dred[256 + wave * 32 + lane] = sq[1][0]; dred[384 + wave * 32 + lane] = sq[1][1];
-                }
-            }
-        }
-        __syncthreads();
-        if (s_fail) return;
-        if (tid < 32 && p.train) {
-            double s = 0, q = 0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { s += dred[u * 32 + tid]; q += dred[128 + u * 32 + tid]; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { s += dred[256 + u * 32 + tid]; q += dred[384 + u * 32 + tid]; }
-            const double mm = s * (double)inv_m;
-            double v = q * (double)inv_m - mm * mm;
-            v = v > 0.0 ? v : 0.0;
-            mu[C + tid] = (float)mm; rs[C + tid] = 1.0f / sqrtf((float)v + p.eps);
-            if (w == 0) { p.st_slab[C + tid] = s; p.st_slab[ld + C + tid] = q; }
-        }
-        __syncthreads();          // mu / rs of the new channels feed the next layer's norm1 constants
-        B4_T(6);
-    }
-#ifdef B4_TIMING
-    if (tid == 0) for (int i = 0; i < 7; ++i) p.err[8 + 8 * w + i] = (unsigned)tacc[i];      // 100 MHz ticks summed over the layers, per workgroup
-#endif
-}
-
-
 // ---------------------------------------------------------------------------------------------------------------------------
 // Backward data path of the block (the chain dslab -> relu2/norm2/conv2 -> relu1/norm1/conv1 -> dslab of layers 15 .. 0) as one launch;
 // the weight gradients stay with the batched launches the network driver issues at the end of the block (they read what this kernel
@@ -615,22 +288,6 @@ __global__ __launch_bounds__(256) void b4_bwd_kernel(const Grp<B4BwdP> grp) {
 }
 
 }  // namespace
-
-extern "C" int mms_b4_fwd_group(const B4FwdP* pp, int ng, hipStream_t s) {
-    Grp<B4FwdP> a;
-    if (!grp_fill(a, pp, ng, 1)) return MMS_ERR_ARG;
-    for (int g = 0; g < ng; ++g) {
-        const B4FwdP& p = pp[g];
-        if (p.M < 1 || p.M > 16 || p.ld != 1024 || p.C0 % 32 != 0 || p.C0 + 32 * p.nlayers > p.ld || !p.tab || !p.slab || !p.xa || !p.xb ||
-            !p.err || !p.coords || (p.train && !p.st_slab) || p.M != pp->M || p.nlayers != pp->nlayers || p.nlayers < 1 || p.nlayers > 16 ||
-            (((uintptr_t)p.slab | (uintptr_t)p.xa | (uintptr_t)p.xb) & 15)) return MMS_ERR_ARG;
-    }
-    constexpr int smem = 2048 + (B4R * B4P + 5 * 1024 + B4R * B4A2P + 1024) * 4 + 512 * 8 + (27 * 16 + 32) * 4;
-    static std::once_flag attr_once;
-    std::call_once(attr_once, [&] { hipFuncSetAttribute((const void*)b4_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem); });
-    MMS_LAUNCH(b4_fwd_kernel, dim3(B4W, 1, ng), dim3(256), smem, s, a);
-    return mms_check_launch();
-}
 
 extern "C" int mms_b4_bwd_group(const B4BwdP* pp, int ng, hipStream_t s) {
     Grp<B4BwdP> a;

@@ -37,7 +37,12 @@ struct Plan {
     size_t stats_begin, stats_end;
     size_t st_y0, st_slab[NB], st_y1[NLAYER];          // forward (sum | sumsq), each 2*C doubles
     size_t counters;                                   // split-fixup tickets (zeroed at init, re-armed by their users)
-    size_t b4_cnt, b4_ga, b4_gb, b4_err, b4_xa, b4_tab;       // block-4 persistent kernels (dn_b4.hip): counters + granule hand-off buffers (inside the per-step zeroed region), sticky error word, backward hand-off buffer, layer table
+    // persistent per-block ("cluster") kernels of dense blocks 3 / 4 (dn_cl.hip, dn_b4.hip): geometry (row tiles per cluster: 0 = the block
+    // does not qualify; rows per cluster; clusters), granule hand-off buffers (inside the per-step zeroed region), layer tables; block 4's
+    // backward: counters (zeroed region), hand-off buffer; sticky error word
+    int cl_rt[NB], cl_rpc[NB], cl_ncl[NB];
+    size_t cl_xa[NB], cl_xb[NB], cl_gst[NB], cl_tab[NB], cl_zero_begin;
+    size_t b4_cnt, b4_err, b4_xa;
     size_t bb_y0, bb_y1[NLAYER], bb_in[NLAYER], bb_tr[3], bb_head;   // backward (s1 | s2)
     size_t total;
 };
@@ -107,14 +112,29 @@ bool make_plan(Plan& P, int B, int D, int H, int W) {
     for (int i = 0; i < NLAYER; ++i) P.bb_in[i] = take((size_t)P.R[blk_of[i]] * 2 * 1024 * 8);
     for (int i = 0; i < 3; ++i) P.bb_tr[i] = take((size_t)P.R[i] * 2 * 1024 * 8);
     P.bb_head = take((size_t)2 * 1024 * 8);
+    P.cl_zero_begin = o;
     P.b4_cnt = take(256);
-    P.b4_ga = take((size_t)8 * 256 * 8);         // {tag, value} granules of the forward's two hand-offs: zero before every launch
-    P.b4_gb = take((size_t)8 * 512 * 8);
+    for (int b = 0; b < NB; ++b) {
+        // a block qualifies for the cluster kernels when a sample has <= 32 voxels: clusters of whole samples with <= 16 * RT rows
+        const int vox = P.g[b].D * P.g[b].H * P.g[b].W;
+        int rt = b >= 2 ? (vox <= 16 ? 1 : (vox <= 32 ? 2 : 0)) : 0;
+        int spc = rt ? (16 * rt) / vox : 0;
+        if (spc > B) spc = B;
+        int ncl = rt ? (B + spc - 1) / spc : 0;
+        if (ncl > 8 || P.R[b] != 1) rt = 0;
+        P.cl_rt[b] = rt; P.cl_rpc[b] = rt ? spc * vox : 0; P.cl_ncl[b] = rt ? ncl : 0;
+        P.cl_xa[b] = P.cl_xb[b] = P.cl_gst[b] = 0;
+        if (rt) {      // {tag, value} granules of the hand-offs: zero before every launch
+            P.cl_xa[b] = take((size_t)ncl * 8 * rt * 256 * 8);
+            P.cl_xb[b] = take((size_t)ncl * 8 * rt * 512 * 8);
+            P.cl_gst[b] = take((size_t)ncl * 8 * 192 * 8);
+        }
+    }
     P.stats_end = o;
     P.counters = take(4096 * 4);
     P.b4_err = take(1024);
     P.b4_xa = take((size_t)8 * 256 * 4);
-    P.b4_tab = take(sizeof(B4Layer) * LAYERS[3]);
+    for (int b = 0; b < NB; ++b) P.cl_tab[b] = take(sizeof(B4Layer) * LAYERS[b]);
     P.total = o;
     return true;
 }
@@ -257,18 +277,23 @@ static int dn121_init_impl(void* ws, int B, int D, int H, int W, const void* con
     }
     if (hipMemsetAsync(at<void>(ws, P.counters), 0, 4096 * 4, s) != hipSuccess) return MMS_ERR_LAUNCH;
     if (hipMemsetAsync(at<void>(ws, P.b4_err), 0, 1024, s) != hipSuccess) return MMS_ERR_LAUNCH;
-    B4Layer b4[LAYERS[3]];
+    B4Layer clt[NLAYER];            // layer tables of the cluster kernels (every block: the table is tiny)
+    for (int li = 0; li < NLAYER; ++li) {
+        const int ip = IDX.layer[li], o1 = IDX.bn_layer1[li], o2 = IDX.bn_layer2[li];
+        clt[li] = B4Layer{(const float*)params[ip], (const float*)params[ip + 1], (const float*)params[ip + 2],
+                          (const float*)params[ip + 3], (const float*)params[ip + 4], at<float>(ws, P.wpf[li]), at<float>(ws, P.wpb[li]),
+                          (const float*)buffers[3 * o1], (const float*)buffers[3 * o1 + 1], (const float*)buffers[3 * o2], (const float*)buffers[3 * o2 + 1],
+                          at<float>(ws, P.y1[li]), at<double>(ws, P.st_y1[li]), at<float>(ws, P.dbn_mid_l[li]), at<double>(ws, P.bb_y1[li])};
+    }
+    hipError_t e0 = hipSuccess;
     {
-        const int l0 = NLAYER - LAYERS[3];
-        for (int i = 0; i < LAYERS[3]; ++i) {
-            const int li = l0 + i, ip = IDX.layer[li], o1 = IDX.bn_layer1[li], o2 = IDX.bn_layer2[li];
-            b4[i] = B4Layer{(const float*)params[ip], (const float*)params[ip + 1], (const float*)params[ip + 2],
-                            (const float*)params[ip + 3], (const float*)params[ip + 4], at<float>(ws, P.wpf[li]), at<float>(ws, P.wpb[li]),
-                            (const float*)buffers[3 * o1], (const float*)buffers[3 * o1 + 1], (const float*)buffers[3 * o2], (const float*)buffers[3 * o2 + 1],
-                            at<float>(ws, P.y1[li]), at<double>(ws, P.st_y1[li]), at<float>(ws, P.dbn_mid_l[li]), at<double>(ws, P.bb_y1[li])};
+        int l0 = 0;
+        for (int b = 0; b < NB; ++b) {
+            const hipError_t e = hipMemcpyAsync(at<void>(ws, P.cl_tab[b]), clt + l0, sizeof(B4Layer) * LAYERS[b], hipMemcpyHostToDevice, s);
+            if (e != hipSuccess) e0 = e;
+            l0 += LAYERS[b];
         }
     }
-    hipError_t e0 = hipMemcpyAsync(at<void>(ws, P.b4_tab), b4, sizeof(b4), hipMemcpyHostToDevice, s);
     if (e0 != hipSuccess) return MMS_ERR_LAUNCH;
     hipError_t e1 = hipMemcpyAsync(at<void>(ws, P.tab_pack), pk, sizeof(pk), hipMemcpyHostToDevice, s);
     hipError_t e2 = hipMemcpyAsync(at<void>(ws, P.tab_bn), bn, sizeof(bn), hipMemcpyHostToDevice, s);
@@ -311,7 +336,19 @@ static int conv3_nsplit(int M, int ng, long cap_rows, const Dims3& g, const MmsD
 // Which dense layers get their conv2 weights packed in MFMA-fragment order (Conv3FwdP.wfrag): those of blocks 1-3 whose launches go to the
 // small-grid kernels of dn_c3s.hip.  Block 4 keeps the classic packs (its persistent kernels, dn_b4.hip, read those; its per-layer fallback
 // path runs the small-grid kernels on them).  A function of the plan and MmsDnOpts.conv3_small only, so forward and backward agree.
-static bool conv3_frag_block(const Plan& P, int b, int ng, const MmsDnOpts& o) { return b < NB - 1 && mms_conv3_small_jn(P.M[b], ng, P.g[b], o) != 0; }
+// Whether dense block b runs as ONE launch per pass on the cluster kernels (dn_cl.hip / dn_b4.hip): pass 0 = forward, 1 = backward.
+// Block 4 -- MmsDnOpts.persist_b4: 0 = both passes, 1 = forward only, -1 = per-layer launches.  Block 3 -- persist_b3: 1 = forward
+// (opt-in: measured SLOWER than its per-layer launches at 32 voxels per sample, 522 vs 446 us per model, profiles/r04_cluster_kernels.txt),
+// 0 / -1 = per-layer launches.  (The caller decides: the clusters' workgroups must be co-resident.)
+static bool cluster_block(const Plan& P, int b, const MmsDnOpts& o, int pass) {
+    if (b < 2 || !P.cl_rt[b]) return false;
+    if (b == 2) return pass == 0 && o.persist_b3 > 0;
+    if (pass == 1 && P.M[3] > 16) return false;          // (backward: a single 16-row cluster only)
+    return pass == 0 ? o.persist_b4 >= 0 : o.persist_b4 == 0;
+}
+static bool conv3_frag_block(const Plan& P, int b, int ng, const MmsDnOpts& o) {
+    return b < NB - 1 && mms_conv3_small_jn(P.M[b], ng, P.g[b], o) != 0 && !cluster_block(P, b, o, 0);      // (the cluster kernels read the classic packs)
+}
 static uint64_t conv3_fragmask(const Plan& P, int ng, const MmsDnOpts& o) {
     uint64_t m = 0;
     int l = 0;
@@ -373,26 +410,29 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
         TRYS(28, mms_pool_fwd_group(pf, ng, s));
         SYNC(at<double>(cx[0].ws, P.st_slab[0]), P.R[0], 2 * CTOT[0], 64, CTOT[0]);
     }
-    // block 4 as ONE launch (dn_b4.hip) when its rows fit a single 16-row MFMA tile (batch 4 on 64x64x32 volumes); MmsDnOpts.persist_b4 = -1: off
-    const bool b4_one = P.M[3] <= 16 && P.R[3] == 1 && !dp.hook && dp.bn_world == 1 && o.persist_b4 >= 0;
+    // dense blocks with <= 32 voxels per sample as ONE launch (dn_cl.hip): block 4 (and block 3) of 64x64x32 volumes
+    const bool cl_ok = !dp.hook && dp.bn_world == 1;
+    if (!train && cl_ok && (cluster_block(P, 2, o, 0) || cluster_block(P, 3, o, 0))) {      // granules + counters (training: the statistics zero-fill above covers them)
+        void* regs[MMS_MAX_GROUP];
+        FOR_G regs[g] = at<void>(cx[g].ws, P.cl_zero_begin);
+        TRY(mms_zero_regions_group(regs, ng, P.stats_end - P.cl_zero_begin, s));
+    }
     int l = 0;
     for (int b = 0; b < NB; ++b) {
         int C = C0[b];
-        if (b == 3 && b4_one) {
-            B4FwdP q[MMS_MAX_GROUP];
-            void* regs[MMS_MAX_GROUP];
+        if (cl_ok && cluster_block(P, b, o, 0)) {
+            ClFwdP q[MMS_MAX_GROUP];
             FOR_G {
                 const Ctx& c = cx[g];
-                q[g] = B4FwdP{at<B4Layer>(c.ws, P.b4_tab), LAYERS[3], C0[3], at<float>(c.ws, P.slab[3]), CTOT[3], at<double>(c.ws, P.st_slab[3]),
-                              at<int>(c.ws, P.coords[3]), P.g[3], P.M[3], train, 1e-5f, at<unsigned long long>(c.ws, P.b4_ga), at<unsigned long long>(c.ws, P.b4_gb),
+                q[g] = ClFwdP{at<B4Layer>(c.ws, P.cl_tab[b]), LAYERS[b], C0[b], at<float>(c.ws, P.slab[b]), CTOT[b], at<double>(c.ws, P.st_slab[b]),
+                              at<int>(c.ws, P.coords[b]), P.g[b], P.M[b], P.cl_rpc[b], P.cl_ncl[b], train, 1e-5f,
+                              at<unsigned long long>(c.ws, P.cl_xa[b]), at<unsigned long long>(c.ws, P.cl_xb[b]), at<unsigned long long>(c.ws, P.cl_gst[b]),
                               at<unsigned>(c.ws, P.b4_err)};
-                regs[g] = at<void>(c.ws, P.b4_cnt);
             }
-            if (!train) TRY(mms_zero_regions_group(regs, ng, P.stats_end - P.b4_cnt, s));      // counters + granules (training: the statistics zero-fill above covers them)
-            TRYS(32, mms_b4_fwd_group(q, ng, s));
-            l += LAYERS[3];
-            continue;
-        }
+            TRYS(32, mms_cl_fwd_group(q, ng, s));
+            l += LAYERS[b];
+            C += 32 * LAYERS[b];
+        } else
         for (int i = 0; i < LAYERS[b]; ++i, ++l, C += 32) {
             const int ip = IDX.layer[l];
             Conv1FwdP c1[MMS_MAX_GROUP];
@@ -523,7 +563,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
             B4BwdP q[MMS_MAX_GROUP];
             FOR_G {
                 const Ctx& c = cx[g];
-                q[g] = B4BwdP{at<B4Layer>(c.ws, P.b4_tab), LAYERS[3], C0[3], at<float>(c.ws, P.slab[3]), at<float>(c.ws, P.dslab[3]), CTOT[3],
+                q[g] = B4BwdP{at<B4Layer>(c.ws, P.cl_tab[3]), LAYERS[3], C0[3], at<float>(c.ws, P.slab[3]), at<float>(c.ws, P.dslab[3]), CTOT[3],
                               at<double>(c.ws, P.st_slab[3]), at<int>(c.ws, P.coords[3]), P.g[3], M, 1e-5f, at<float>(c.ws, P.b4_xa),
                               at<unsigned>(c.ws, P.b4_cnt) + 32, at<unsigned>(c.ws, P.b4_err), {}, {}};
                 for (int i = 0; i < LAYERS[3]; ++i) {

@@ -42,24 +42,27 @@ int mms_c1s_bwd(const Conv1BwdP* pp, int ng, hipStream_t s);
 int mms_c3s_fwd(const Conv3FwdP* pp, int ng, const MmsDnOpts& o, hipStream_t s);
 int mms_c3s_bwd_data(const Conv3BwdDataP* pp, int ng, const MmsDnOpts& o, hipStream_t s);
 
-// ---- dense block 4 as one launch per pass (dn_b4.hip); internal to the network drivers ------------------------------------------
-struct B4Layer {               // device table entry, one per dense layer of block 4 (built by mms_dn121_init)
+// ---- dense blocks 3 / 4 as one launch per pass (dn_cl.hip, dn_b4.hip); internal to the network drivers ---------------------------
+struct B4Layer {               // device table entry, one per dense layer (built by mms_dn121_init)
     const float *g1, *b1, *w1;                 // norm1 gamma / beta [C], conv1 weight [128][C]
     const float *g2, *b2, *wpf, *wpb;          // norm2 gamma / beta [128], packed conv2 weights [32][27][128] / [128][27][32]
     const float *rm1, *rv1, *rm2, *rv2;        // running statistics (eval-mode forward)
     float* y1; double* st_y1;                  // pre-BatchNorm2 activations [M][128] and their (sum | sumsq) [2][128], saved for the backward
     float* dmid; double* bb_y1;                // backward: masked gradient at norm2's output [M][128] and its BatchNorm-backward sums (s1 | s2) [2][128]
 };
-struct B4FwdP {
-    const B4Layer* tab; int nlayers; int C0;   // 16 layers, 512 input channels
+// Forward of a dense block with <= 32 voxels per sample as one launch (dn_cl.hip): clusters of 8 workgroups, each owning whole samples.
+struct ClFwdP {
+    const B4Layer* tab; int nlayers; int C0;   // the block's layers, its first layer's input channels
     float* slab; int ld;                       // [M][ld = 1024]: columns [0, C0) in, the rest out
     double* st_slab;                           // (sum | sumsq) [2][ld], one replica (train)
-    const int* coords; Dims3 g; int M;         // M <= 16 rows
+    const int* coords; Dims3 g; int M;         // M = rows of the whole batch (the BatchNorm statistics span them)
+    int rpc; int ncl;                          // rows per cluster (whole samples; <= 16: one MFMA row tile, <= 32: two), clusters (<= 8)
     int train; float eps;
-    unsigned long long* xa; unsigned long long* xb;      // granule hand-off buffers [8][256], [8][512] of {tag, value} words: ZERO on entry
+    unsigned long long* xa; unsigned long long* xb; unsigned long long* gst;     // {tag, value} granule buffers, ZERO on entry:
+                                               // [ncl][8][rt * 256], [ncl][8][rt * 512], [8][ncl][64] + [8][ncl][128] (rt = row tiles)
     unsigned* err;                             // sticky time-out flag
 };
-extern "C" int mms_b4_fwd_group(const B4FwdP* pp, int ng, hipStream_t s);
+extern "C" int mms_cl_fwd_group(const ClFwdP* pp, int ng, hipStream_t s);
 struct B4BwdP {                // the data path of block 4's backward (dslab -> norm2/conv2 -> norm1/conv1 -> dslab, layer 15 .. 0) as one launch
     const B4Layer* tab; int nlayers; int C0;
     const float* slab; float* dslab; int ld;   // saved activations / their gradient [M][ld = 1024]; on entry dslab holds d(loss)/d(slab) from norm5,

@@ -373,13 +373,10 @@ class SurvivalEngine:
         return ops.inprolog(L.pro_bn, train=train, drop_p=p, drop_mask=mask, rng=self.rng, stream_id=idx + 1)
 
     # ---- launches (all on torch's current stream; capturable) ---------------------------------------
-    def _opts_arg(self):
-        """`const MmsDnOpts*` of this engine's driver calls.  The block-4 persistent kernels (csrc/dn_b4.hip) hand data between 8
-        co-resident workgroups per model and one such launch per worker stream may be in flight: if those workgroups could outnumber
-        the CUs, the per-layer path is taken instead (decided here, at launch = graph-capture time, and passed as an ARGUMENT)."""
-        o = self.dn_opts
-        if o.persist_b4 == 0 and not ops.persistent_b4_fits(self.device, 1):
-            o = ops.dn_opts(o, persist_b4=-1)
+    def _opts_arg(self, P):
+        """`const MmsDnOpts*` of this engine's driver calls on plan P (ops.persistent_opts: the persistent per-block launches are taken
+        only where their workgroups can all be co-resident; decided here, at launch = graph-capture time, and passed as an ARGUMENT)."""
+        o = ops.persistent_opts(self.dn_opts, self.device, 1, P.B, P.dims)
         self._opts_live = o          # (keeps the block alive for the duration of the call)
         return ctypes.byref(o)
 
@@ -395,7 +392,7 @@ class SurvivalEngine:
                                               feats.stride(0), 1 if train else 0, st), "mms_fb_forward")
             else:
                 _lib.check(lib.mms_dn121_forward(P.ws.data_ptr(), B, D, H, W, P.ct.data_ptr(), P.ptab, P.btab, out.data_ptr(),
-                                                 feats.stride(0), 1 if train else 0, self._opts_arg(), st), "mms_dn121_forward")
+                                                 feats.stride(0), 1 if train else 0, self._opts_arg(P), st), "mms_dn121_forward")
         if P.big:
             if train:
                 P.big_stats.zero_()
@@ -456,20 +453,20 @@ class SurvivalEngine:
         if stage is not None or hook is not None or P.bn_world > 1:
             hi, lo = stage if stage is not None else (3, 0)
             _lib.check(lib.mms_dn121_backward_stage(P.ws.data_ptr(), B, D, H, W, P.ct.data_ptr(), P.ptab, dct.data_ptr(), dfe.stride(0),
-                                                    P.gtab, hi, lo, P.bn_world, hook, None, self._opts_arg(), st), "mms_dn121_backward_stage")
+                                                    P.gtab, hi, lo, P.bn_world, hook, None, self._opts_arg(P), st), "mms_dn121_backward_stage")
             return
         # The weight-gradient fork (mms_dn121_backward_mt) is off by default: measured, it neither helps a single chain
         # (graph branches run mostly serially) nor concurrent fold models (it takes hardware queues away from them).
         if os.environ.get("MMS_SIDE_STREAM") != "1" and not P.fallback:
             _lib.check(lib.mms_dn121_backward(P.ws.data_ptr(), B, D, H, W, P.ct.data_ptr(), P.ptab, dct.data_ptr(),
-                                              dfe.stride(0), P.gtab, self._opts_arg(), st), "mms_dn121_backward")
+                                              dfe.stride(0), P.gtab, self._opts_arg(P), st), "mms_dn121_backward")
             return
         if P.fallback:
             _lib.check(lib.mms_fb_backward(P.ws.data_ptr(), B, D, H, W, P.ct.data_ptr(), P.ptab, dct.data_ptr(),
                                            dfe.stride(0), P.gtab, st), "mms_fb_backward")
             return
         _lib.check(lib.mms_dn121_backward_mt(P.ws.data_ptr(), B, D, H, W, P.ct.data_ptr(), P.ptab, dct.data_ptr(),
-                                             dfe.stride(0), P.gtab, self._opts_arg(), st, ctypes.c_void_p(self.side_stream.cuda_stream),
+                                             dfe.stride(0), P.gtab, self._opts_arg(P), st, ctypes.c_void_p(self.side_stream.cuda_stream),
                                              ctypes.c_void_p(self.ev_fork.cuda_event), ctypes.c_void_p(self.ev_join.cuda_event)),
                    "mms_dn121_backward_mt")
 
@@ -769,7 +766,7 @@ class SurvivalEngine:
         self.gflat.zero_(); self.sumsq.zero_()
         feats = P.buf["feats"]
         _lib.check(lib.mms_dn121_forward_sync(P.ws.data_ptr(), B, Dd, H, W, P.ct.data_ptr(), P.ptab, P.btab, feats[:, cc:].data_ptr(),
-                                              feats.stride(0), world, hook, None, self._opts_arg(), st), "mms_dn121_forward_sync")
+                                              feats.stride(0), world, hook, None, self._opts_arg(P), st), "mms_dn121_forward_sync")
 
         def gather(dst, src):
             tmp = torch.empty(world * src.shape[0], *src.shape[1:], device=self.device)

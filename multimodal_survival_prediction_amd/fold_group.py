@@ -184,13 +184,12 @@ class FoldGroupEngine:
                     b.copy_(b0)
 
     def _opts_arg(self, GP):
-        """`const MmsDnOpts*` of the group's driver calls (the members share one block: same class, same options).  The block-4
-        persistent kernels (csrc/dn_b4.hip) hand data between 8 co-resident workgroups per model and one such launch per worker stream
-        may be in flight: if those workgroups could outnumber the CUs, the per-layer path is taken -- decided at launch (= graph-capture)
-        time from the number of worker streams the process has created, and passed to the drivers as an ARGUMENT."""
-        o = GP.eng[0].dn_opts
-        if o.persist_b4 == 0 and not ops.persistent_b4_fits(self.device, GP.ng):
-            o = ops.dn_opts(o, persist_b4=-1)
+        """`const MmsDnOpts*` of the group's driver calls (the members share one block: same class, same options).  The persistent
+        per-block kernels (csrc/dn_cl.hip, dn_b4.hip) hand data between co-resident workgroups and one such launch per worker stream
+        may be in flight: where those workgroups could outnumber the CUs, the per-layer path is taken (ops.persistent_opts) -- decided
+        at launch (= graph-capture) time from the number of worker streams the process has created, and passed to the drivers as an
+        ARGUMENT."""
+        o = ops.persistent_opts(GP.eng[0].dn_opts, self.device, GP.ng, GP.B, GP.dims)
         GP.opts_live = o
         return ctypes.byref(o)
 

@@ -273,12 +273,44 @@ def worker_streams(device, n):
     return lst[:n]
 
 
-def persistent_b4_fits(device, ng):
-    """Whether the block-4 persistent launches of ng lock-step models per worker stream can all be co-resident: 8 workgroups per model
-    and one launch per worker stream in flight, against the device's CU count (the kernels' bounded spin + time-out word stay as the
-    backstop).  The rule shared by SurvivalEngine and FoldGroupEngine."""
+def cluster_workgroups(B, dims):
+    """Workgroups per model of the persistent per-block ("cluster") launches of dense blocks 3 and 4 (csrc/dn_cl.hip; the rule of
+    csrc/dn_net.hip make_plan): clusters of 8 workgroups, each owning whole samples with <= 16 or <= 32 rows; 0 = the block has too many
+    voxels per sample (or too many clusters) and runs per layer."""
+    out = []
+    for shift in (4, 5):
+        vox = max(1, (dims[0] >> shift) * (dims[1] >> shift) * (dims[2] >> shift))
+        rt = 1 if vox <= 16 else (2 if vox <= 32 else 0)
+        if not rt:
+            out.append(0)
+            continue
+        spc = min(B, (16 * rt) // vox)
+        ncl = -(-B // spc)
+        out.append(8 * ncl if ncl <= 8 else 0)
+    return tuple(out)
+
+
+def persistent_opts(base, device, ng, B, dims):
+    """MmsDnOpts for a driver call of ng lock-step models: `base` with persist_b3 / persist_b4 switched to the per-layer path (-1) where
+    the persistent launches of all worker streams could not be co-resident -- their workgroups hand data to each other inside the
+    launch, one such launch per worker stream may be in flight, and the chip has a fixed number of CUs (the kernels' bounded sweeps +
+    time-out word stay as the backstop).  The rule shared by SurvivalEngine, FoldGroupEngine and bench.py; decided at launch (=
+    graph-capture) time and passed to the drivers as an argument."""
+    if dims is None or len(dims) != 3:
+        return base
     cus = torch.cuda.get_device_properties(device).multi_processor_count
-    return 8 * ng * max_worker_streams() <= cus
+    w3, w4 = cluster_workgroups(B, dims)
+    kw = {}
+    if base.persist_b3 > 0 and w3 * ng * max_worker_streams() > cus:
+        kw["persist_b3"] = -1
+    if base.persist_b4 >= 0 and w4 * ng * max_worker_streams() > cus:
+        kw["persist_b4"] = -1
+    return dn_opts(base, **kw) if kw else base
+
+
+def persistent_b4_fits(device, ng, B=4, dims=(64, 64, 32)):
+    """Whether dense block 4 runs as one persistent launch per pass for ng lock-step models per worker stream (bench.py's mirror of the drivers)."""
+    return persistent_opts(dn_opts(), device, ng, B, dims).persist_b4 >= 0
 
 
 def max_worker_streams():

@@ -153,30 +153,34 @@ def test_densenet_backward_flip_free(B, dims, signs):
 
 
 @pytest.mark.parametrize("B,dims,train", [(4, (64, 64, 32), True), (3, (64, 64, 32), True), (2, (64, 64, 32), False), (8, (32, 32, 32), True),
-                                          (1, (64, 64, 64), True)])
-def test_block4_persistent_kernel_equals_per_layer_path(B, dims, train):
-    """Dense block 4 as ONE launch (csrc/dn_b4.hip: cluster of 8 workgroups, LDS-resident slab, two in-launch hand-offs per layer) against
-    the per-layer launch sequence it replaces (MmsDnOpts.persist_b4 = -1), same weights and input: features, every saved activation the
-    backward reads (block-4 slab, y1 of its 16 layers), the BatchNorm statistics (through the running statistics) -- ragged row
-    counts (12, 8 rows), a 1x1x1 grid (one live tap) and the eval-mode forward included."""
+                                          (1, (64, 64, 64), True), (8, (64, 64, 32), True), (5, (64, 64, 32), False)])
+def test_persistent_block_kernels_equal_per_layer_path(B, dims, train):
+    """Dense blocks 3 and 4 as ONE launch each (csrc/dn_cl.hip: clusters of 8 workgroups per few samples, on-chip slab, granule hand-offs,
+    BatchNorm partial sums exchanged between clusters) against the per-layer launch sequences they replace (MmsDnOpts.persist_b3 /
+    persist_b4 = -1), same weights and input: features, every saved activation the backward reads (the slabs of blocks 3 / 4, y1 of
+    their 24 + 16 layers), the BatchNorm statistics (through the running statistics).  Cases: block 3 as 4 / 3 / 8 clusters of one
+    32-voxel sample (two MFMA row tiles), as clusters of two 8-voxel samples (32^3 volumes), or per layer (64 voxels per sample);
+    block 4 as one cluster of 16 / 12 / 8 rows, as two clusters (batch 8: statistics exchanged), a 1x1x1 grid (one live tap); ragged
+    last clusters; the eval-mode forward."""
     ref, net = _make(4)
     x = structured_volumes(B, dims, 21).to(DEV)
     net.train(train)
     outs = {}
     for flag in ("0", "1"):
-        net.dn_opts = dict(persist_b4=-1 if flag == "0" else 1)
+        net.dn_opts = dict(persist_b3=-1, persist_b4=-1) if flag == "0" else dict(persist_b3=1, persist_b4=1)
         net.load_state_dict(ref.state_dict())            # same running statistics before each run
         with torch.no_grad():
             y = net(x)
         torch.cuda.synchronize()
-        outs[flag] = dict(y=y.clone(), slab=net.workspace_region("slab", 3).clone(),
-                          y1=[net.workspace_region("y1", 42 + i).clone() for i in range(16)] if train else [],
+        outs[flag] = dict(y=y.clone(), slab3=net.workspace_region("slab", 2).clone(), slab=net.workspace_region("slab", 3).clone(),
+                          y1=[net.workspace_region("y1", 18 + i).clone() for i in range(40)] if train else [],
                           bufs=[b.clone() for b in net.buffers()])
     a, b = outs["0"], outs["1"]
     assert_close(b["y"], a["y"], 1e-5, "features")
+    assert_close(b["slab3"], a["slab3"], 1e-5, "block-3 slab")
     assert_close(b["slab"], a["slab"], 1e-5, "block-4 slab")
     for i, (u, v) in enumerate(zip(a["y1"], b["y1"])):
-        assert_close(v, u, 1e-5, "y1 of block-4 layer %d" % i)
+        assert_close(v, u, 1e-5, "y1 of layer %d" % (18 + i))
     for u, v in zip(a["bufs"], b["bufs"]):
         if u.dtype == torch.float32:
             assert_close(v, u, 1e-5, "running statistics")
