@@ -73,6 +73,13 @@ typedef struct MmsDnOpts {
     int ms1_div;           /* divisor of the conv1 weight-gradient row chunks, 0 = by launch size */
     int c0_nwg;            /* workgroups of the pooled conv0 weight-gradient kernel, 0 = default */
     int c0f_nwg;           /* workgroups of the pooled conv0 forward kernel, 0 = default */
+    int w2_packed;         /* 1: the 58 conv2 weight tensors (and their gradients) are stored [cout][tap][cin] -- "packed primary" -- instead
+                              of torch's [cout][cin][taps]: the forward reads them as they are, the weight-gradient kernels write the
+                              gradient in place (no pack launch, no gradient scratch, no unpack launch in the step), and the parameter
+                              table carries 116 more pointers: params[364 + 2 l] = layer l's backward-data pack, params[364 + 2 l + 1] =
+                              its forward MFMA-fragment pack (layers of mms_dn121_w2_fragmask; else unused) -- kept current by the caller:
+                              mms_clip_adam writes them with the update (AdamP.w2_*), mms_w2_pack after any other change of the weights.
+                              0: torch layout, packs and unpack inside the drivers (rounds 1-3) */
 } MmsDnOpts;
 
 /* BatchNorm parameter source. train=1: batch statistics from the fp64 accumulators; train=0: running stats.
@@ -192,10 +199,13 @@ typedef struct Conv3BwdWP {
     const float* y1; const int* coords; Dims3 g; int M;
     BnSrc bn;
     const float* dz; int lddz;
-    float* dw;                      // canonical torch layout [32][128][27], accumulated with atomics (dw_tapmajor = 0)
+    float* dw;                      // gradient, accumulated with atomics; layout by dw_layout
     int msplit;                     // grid.z = 27 * msplit
-    int dw_tapmajor;                // 1: dw is a zeroed scratch in [27][32][128] (tap, cout, cin) layout: contiguous
-                                    // atomics at full rate; mms_unpack_conv3_grads adds it into the canonical gradient
+    int dw_layout;                  // 0: canonical torch layout [32 cout][128 cin][27 taps] (every atomic on its own cache line);
+                                    // 1: a zeroed scratch in [27][32][128] (tap, cout, cin) order: 512-byte contiguous runs = full atomic
+                                    //    rate; mms_unpack_conv3_grads adds it into the canonical gradient;
+                                    // 2: [32][27][128] (cout, tap, cin) -- the PACKED PRIMARY layout of MmsDnOpts.w2_packed: the same
+                                    //    512-byte runs, and the buffer IS the parameter's gradient (no scratch, no unpack)
 } Conv3BwdWP;
 
 // 1x1 conv backward (dense conv1 and transition conv).
@@ -377,6 +387,12 @@ typedef struct AdamP {
     /* optional per-step bookkeeping done by mms_grad_sumsq (all nullable): acc[4] += {loss*usable, usable, entropy, 1} */
     float* acc; const float* cox_out; const float* entropy;
     int* rng;                       // [2] dropout (seed, step counter): counter += 1 after the step's kernels have used it
+    /* conv2 weights in packed primary storage (MmsDnOpts.w2_packed; n_w2 = 0: none).  The n_w2 tensors of 32 x 27 x 128 floats at
+       offsets w2_off[i] (ascending) of p / g / m / v are stored [cout][tap][cin]; mms_clip_adam updates them with a kernel of their own
+       that also writes the derived packs the convolution kernels read: w2_pack_b[i] = backward-data pack ([cin][tap][cout], or the
+       backward MFMA-fragment order when bit i of w2_fragmask is set), w2_pack_f[i] = forward MFMA-fragment order (bit i set; else unused:
+       the primary storage is the forward pack).  All three tables live in device memory. */
+    const long long* w2_off; float* const* w2_pack_b; float* const* w2_pack_f; int n_w2; uint64_t w2_fragmask;
 } AdamP;
 
 /* Large-batch Linear (rows M > 32: BASELINE config 5, RNA-seq-only B = 2048; R/scripts/training/train_rnaseq_only.py:126-151).
@@ -487,7 +503,8 @@ int mms_missing_mix_bwd(const MixP* p, hipStream_t s);
 int mms_cox_fwd_bwd(const CoxP* p, hipStream_t s);
 int mms_cindex_counts(const CindexP* p, hipStream_t s);
 int mms_grad_sumsq(const AdamP* p, hipStream_t s);             /* sum of squares of the flat gradient (fp64 atomics) */
-int mms_clip_adam(const AdamP* p, hipStream_t s);              /* clip by global norm + Adam/AdamW update */
+int mms_clip_adam(const AdamP* p, hipStream_t s);              /* clip by global norm + Adam/AdamW update (+ the derived conv2 packs, AdamP.w2_*) */
+int mms_w2_pack(const AdamP* p, hipStream_t s);                /* the derived conv2 packs alone, from the current weights (after load_state_dict / any external update) */
 
 /* ---- whole-encoder driver: replaces `self.ct_encoder(ct)` / `self.image_encoder(image)` and its autograd
  *      (R/scripts/training/final_multimodal.py:124, partial_modality_training.py:245, simple_fusion.py:226).
@@ -498,7 +515,10 @@ int mms_ablation_build(void);      /* 1: the library was built with a timing-abl
                                       may be left out of the step -- diagnostics only; bench.py refuses to report a value from such a build */
 int mms_dn121_workspace_bytes(int B, int D, int H, int W, size_t* bytes);
 int mms_dn121_region(int B, int D, int H, int W, const char* name, int index, size_t* off, size_t* bytes);
-int mms_dn121_init(void* ws, int B, int D, int H, int W, const void* const* params, const void* const* buffers, hipStream_t s);
+int mms_dn121_init(void* ws, int B, int D, int H, int W, const void* const* params, const void* const* buffers, const MmsDnOpts* opts, hipStream_t s);
+/* which dense layers (bit l, l < 58) get their conv2 packs in MFMA-fragment order for this problem and these options (the layers whose
+   launches take the small-grid kernels of csrc/dn_c3s.hip) */
+int mms_dn121_w2_fragmask(int B, int D, int H, int W, const MmsDnOpts* opts, uint64_t* mask);
 /* opts: launch-shape options incl. the width of class_layers.out (MmsDnOpts above; NULL = defaults). */
 int mms_dn121_forward(void* ws, int B, int D, int H, int W, const float* x, const void* const* params,
                       const void* const* buffers, float* out, int ldo, int train, const MmsDnOpts* opts, hipStream_t s);
@@ -515,7 +535,8 @@ int mms_dn121_backward(void* ws, int B, int D, int H, int W, const float* x, con
  * on stream s and returns 0.  bn_world = ranks the statistics span (counts become bn_world * rows); hook may be null (bn_world 1).
  * mms_dn121_init_sync: as mms_dn121_init, running-statistics table built for bn_world * rows. */
 typedef int (*mms_sync_fn)(void* user, double* base, int nrep, long rep_stride, int ncols, long pair_stride, hipStream_t s);
-int mms_dn121_init_sync(void* ws, int B, int D, int H, int W, const void* const* params, const void* const* buffers, int bn_world, hipStream_t s);
+int mms_dn121_init_sync(void* ws, int B, int D, int H, int W, const void* const* params, const void* const* buffers, int bn_world,
+                        const MmsDnOpts* opts, hipStream_t s);
 int mms_dn121_forward_sync(void* ws, int B, int D, int H, int W, const float* x, const void* const* params,
                            const void* const* buffers, float* out, int ldo, int bn_world, mms_sync_fn hook, void* user,
                            const MmsDnOpts* opts, hipStream_t s);
@@ -574,6 +595,7 @@ int mms_gate_bwd_group(const GateP* p, int ng, hipStream_t s);
 int mms_cox_fwd_bwd_group(const CoxP* p, int ng, hipStream_t s);
 int mms_grad_sumsq_group(const AdamP* p, int ng, hipStream_t s);
 int mms_clip_adam_group(const AdamP* p, int ng, hipStream_t s);
+int mms_w2_pack_group(const AdamP* p, int ng, hipStream_t s);
 /* whole-encoder drivers: entry g of every array describes model g (arguments as mms_dn121_forward / _backward) */
 int mms_dn121_forward_group(int ng, void* const* ws, int B, int D, int H, int W, const float* const* x,
                             const void* const* const* params, const void* const* const* buffers, float* const* out,

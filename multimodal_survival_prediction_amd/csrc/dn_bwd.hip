@@ -295,7 +295,7 @@ struct Conv3BwdWOp {
 #endif
         for (int idx = tid; idx < TM * TN; idx += 256) {
             const int cin = idx & 127, co = idx >> 7;
-            const size_t dst = p.dw_tapmajor ? ((size_t)tap * 32 + co) * 128 + cin : ((size_t)co * 128 + cin) * 27 + tap;
+            const size_t dst = p.dw_layout == 2 ? ((size_t)co * 27 + tap) * 128 + cin : (p.dw_layout == 1 ? ((size_t)tap * 32 + co) * 128 + cin : ((size_t)co * 128 + cin) * 27 + tap);
             atomicAdd(&p.dw[dst], Cs[cin * (TN + 1) + co]);
         }
     }
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         const int tap = kdh * 3 + kw;
         for (int idx = tid; idx < 128 * 32; idx += 256) {
             const int cin = idx & 127, co = idx >> 7;
-            const size_t dst = p.dw_tapmajor ? ((size_t)tap * 32 + co) * 128 + cin : ((size_t)co * 128 + cin) * 27 + tap;
+            const size_t dst = p.dw_layout == 2 ? ((size_t)co * 27 + tap) * 128 + cin : (p.dw_layout == 1 ? ((size_t)tap * 32 + co) * 128 + cin : ((size_t)co * 128 + cin) * 27 + tap);
             atomicAdd(&p.dw[dst], Cs[cin * 33 + co]);
         }
         __syncthreads();
@@ -523,13 +523,13 @@ extern "C" int mms_conv3_bwd_weight_group(const Conv3BwdWP* pp, int ng, const Mm
     if (!pp || ng < 1 || ng > MMS_MAX_GROUP) return MMS_ERR_ARG;
     const MmsDnOpts o = mms_opts(opts);
     const Conv3BwdWP& p = *pp;
-    if (p.M <= 0 || p.msplit <= 0 || p.lddz % 4 != 0) return MMS_ERR_ARG;
+    if (p.M <= 0 || p.msplit <= 0 || p.lddz % 4 != 0 || p.dw_layout < 0 || p.dw_layout > 2) return MMS_ERR_ARG;
     if ((((p.M + p.msplit - 1) / p.msplit + 31) & ~31) > 1024) return MMS_ERR_ARG;    // row chunk must fit the LDS mask table
     for (int g = 0; g < ng; ++g) if (!mms_bn_aligned16(pp[g].bn)) return MMS_ERR_ARG;   // BatchNorm blocks are read with 16-byte vector loads
     for (int g = 1; g < ng; ++g) {
         const Conv3BwdWP& q = pp[g];
         if (q.M != p.M || q.msplit != p.msplit || q.lddz % 4 != 0 || q.g.D != p.g.D || q.g.H != p.g.H || q.g.W != p.g.W ||
-            q.dw_tapmajor != p.dw_tapmajor) return MMS_ERR_ARG;
+            q.dw_layout != p.dw_layout) return MMS_ERR_ARG;
     }
     if (conv3w_mt_ok(((p.M + p.msplit - 1) / p.msplit + 31) & ~31, p.msplit, ng, o)) {
         constexpr int smem = (2 * C3W_STAGE + 2 * 1024) * (int)sizeof(float);        // 53.3 KB: 3 workgroups per CU

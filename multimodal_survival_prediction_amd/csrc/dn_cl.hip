@@ -431,6 +431,253 @@ __global__ __launch_bounds__(256) void cl_fwd_kernel(const Grp<ClFwdP> grp) {
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Backward data path of a single-cluster block (dense block 4 with <= 16 rows): the chain dslab -> relu2/norm2/conv2 -> relu1/norm1/conv1
+// -> dslab of the layers nl-1 .. 0 as one launch; the weight gradients stay with the batched launches the network driver issues at the
+// end of the block (they read what this kernel leaves per layer: the masked gradient at norm2's output `dmid`, its BatchNorm-backward
+// sums, the final dz columns of dslab).  Round 4 form: granule hand-offs and FIXED column ownership --
+//   * workgroup w owns slab columns [128 w, 128 w + 128) for the whole launch: their saved activations, batch statistics and the running
+//     gradient dslab[:, own] stay in REGISTERS (8 rows per thread), so norm1's in-place update never leaves the chip; the gradient slab is
+//     read once at the start and written once at the end (round 3: a per-layer column split of C/8, the slab exchanged through memory
+//     behind a counter barrier every layer);
+//   * per layer: (dz) the layer's 16 x 32 output gradient = the owner's current dslab columns [C, C + 32), broadcast as granules by the
+//     workgroup that owns them (the last layer reads the incoming slab directly); (A) conv2 backward-data + relu2 mask + norm2 backward
+//     for the own 16 mid channels (all rows are here: sums are local), dy1 published, all gather 16 x 128; (B) conv1 backward-data for
+//     the own columns below C (one float4 of W1 = 4 consecutive columns feeds 4 MFMAs with interleaved output columns), relu1 mask,
+//     norm1 backward applied to the register gradient.
+// Hand-off A's buffer is double-buffered by layer parity (the dz broadcast has ONE producer, so it does not order the other workgroups'
+// reads of the previous A); tags: A = l + 1, dz of layer l = l + 1, in separate buffers, zeroed with the step's statistics.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int CLDZP = 36, CLDYP = 132;
+
+__global__ __launch_bounds__(256) void cl_bwd_kernel(const Grp<ClBwdP> grp) {
+    const ClBwdP& p = grp.p[blockIdx.z];
+    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, k4 = lane >> 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    B4Layer* tabs = (B4Layer*)smem;            // [<= 24] the block's layer table
+    float* dzs = smem + 768;                   // [16][CLDZP] dz of the layer (rows >= M zero)
+    float* dys = dzs + 16 * CLDZP;             // [16][CLDYP] gathered dy1
+    float* da = dys + 16 * CLDYP;              // [2][16][CLDYP] d(a1) partials of the two halves of the reduction
+    float* red = da + 2 * 16 * CLDYP;          // [4][256] cross-wave sums
+    double* dred = (double*)(red + 1024);      // [1024] column-sum partials
+    float* c2 = (float*)(dred + 1024);         // [64]: norm2 mean | rstd | s1/M | s2/M of this workgroup's 16 channels
+    int* nbm = (int*)(c2 + 64);                // [27][16] row whose output tap `tap` reads this row (row - off(tap)), -1 = outside the grid
+    int* live = nbm + 27 * 16;                 // [0] = number of live taps, [1..27] = their indices, [31] = "a sweep timed out"
+    int& s_fail = live[31];
+    const int M = p.M, C0 = p.C0, ld = p.ld;
+    const float inv_m = 1.0f / (float)M;
+    const double inv_md = (double)inv_m;
+
+    for (int i = tid; i < p.nlayers * 30; i += 256) ((unsigned*)tabs)[i] = ((const unsigned*)p.tab)[i];
+    if (tid == 0) s_fail = 0;
+    const int row = tid >> 4, col = tid & 15;                 // phase A: element (row, mid channel 16 w + col)
+    const int bcol = tid & 127, brg = tid >> 7;                // phase B: column 128 w + bcol, rows 8 brg .. 8 brg + 7
+    const int c = 128 * w + bcol;
+    const int T = wave & 1, kh2 = wave >> 1;                   // phase B MFMA: 64-column half, half of the 128-long reduction
+    // the own columns: saved activations, incoming gradient, batch statistics -- loaded once, resident for the launch
+    float xv[8], dv[8], mu1, r1;
+    {
+        const double s_ = p.st_slab[c], q_ = p.st_slab[ld + c];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = 8 * brg + i;
+            xv[i] = m < M ? p.slab[(size_t)m * ld + c] : 0.f;
+            dv[i] = m < M ? p.dslab[(size_t)m * ld + c] : 0.f;
+        }
+        const double mm = s_ * inv_md;
+        double v = q_ * inv_md - mm * mm;
+        v = v > 0.0 ? v : 0.0;
+        mu1 = (float)mm; r1 = 1.0f / sqrtf((float)v + p.eps);
+    }
+    for (int idx = tid; idx < 27 * 16; idx += 256) {
+        const int tap = idx >> 4, m = idx & 15;
+        int nb = -1;
+        if (m < M) {
+            int d, h, x;
+            unpack_dhw(p.coords[m], d, h, x);
+            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+            const int nd = d - (kd - 1), nh = h - (kh - 1), nw = x - (kw - 1);
+            if ((unsigned)nd < (unsigned)p.g.D && (unsigned)nh < (unsigned)p.g.H && (unsigned)nw < (unsigned)p.g.W)
+                nb = m - (((kd - 1) * p.g.H + (kh - 1)) * p.g.W + (kw - 1));
+        }
+        nbm[idx] = nb;
+    }
+    {   // dz of the last layer: straight from the incoming gradient slab (nothing in this launch has written it)
+        const int Cl = C0 + 32 * (p.nlayers - 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const int e = tid + 256 * j, m = e >> 5; dzs[m * CLDZP + (e & 31)] = m < M ? p.dslab[(size_t)m * ld + Cl + (e & 31)] : 0.f; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int n = 0;
+        for (int tap = 0; tap < 27; ++tap) {
+            bool any = false;
+            for (int m = 0; m < M; ++m) any = any || nbm[tap * 16 + m] >= 0;
+            if (any) live[1 + n++] = tap;
+        }
+        live[0] = n;
+    }
+    __syncthreads();
+    const int nlive = live[0];
+    int mytap[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) { const int ti = wave + 4 * j; mytap[j] = ti < nlive ? live[1 + ti] : -1; }
+
+    // registers loaded one phase ahead of their use (weights and saved activations never depend on the chain)
+    float4 treg[7][2];
+    float yv, g2v, b2v; double sy, qy;
+    auto load_A = [&](int l) __attribute__((always_inline)) {
+        const B4Layer& L = tabs[l];
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                treg[j][t] = mytap[j] >= 0 ? *(const float4*)(L.wpb + ((size_t)(16 * w + r16) * 27 + mytap[j]) * 32 + 16 * t + 4 * k4)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+        yv = row < M ? L.y1[(size_t)row * 128 + 16 * w + col] : 0.f;
+        g2v = L.g2[16 * w + col]; b2v = L.b2[16 * w + col];
+        sy = L.st_y1[16 * w + col]; qy = L.st_y1[128 + 16 * w + col];
+    };
+    float4 wreg[16];
+    float g1v, b1v;
+    auto load_B = [&](int l) __attribute__((always_inline)) {
+        const B4Layer& L = tabs[l];
+        const int C = C0 + 32 * l;
+        const bool okw = 128 * w + 64 * T + 4 * r16 < C;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int n = 4 * (16 * kh2 + i) + k4;
+            wreg[i] = okw ? *(const float4*)(L.w1 + (size_t)n * C + 128 * w + 64 * T + 4 * r16) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        g1v = c < C ? L.g1[c] : 0.f; b1v = c < C ? L.b1[c] : 0.f;
+    };
+    load_A(p.nlayers - 1);
+
+    for (int l = p.nlayers - 1; l >= 0; --l) {
+        const int C = C0 + 32 * l;
+        const B4Layer& L = tabs[l];
+        const unsigned tag = (unsigned)l + 1u;
+        cl_u64* ga = p.ga + (size_t)(l & 1) * (CLW * 256);
+        // ---- dz of this layer: broadcast by the owner of columns [C, C + 32) after the previous layer's phase B -------------------
+        if (l != p.nlayers - 1) {
+            unsigned v[2];
+            const bool ok = g_sweep<2>(p.gz + tid, 256, tag, v, p.err);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { const int e = tid + 256 * j; dzs[(e >> 5) * CLDZP + (e & 31)] = __uint_as_float(v[j]); }
+            if (!ok) s_fail = 1;
+        }
+        load_B(l);                                // conv1 weights / norm1 parameters of this layer: used after hand-off A
+        __syncthreads();
+        if (s_fail) return;
+        // ---- A1. conv2 backward-data for the 16 own mid channels, this wave's taps --------------------------------------------------
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            if (mytap[j] >= 0) {
+                const int nb = nbm[mytap[j] * 16 + r16];
+                const float* ar = dzs + (nb >= 0 ? nb : 0) * CLDZP + 4 * k4;
+                const float z = nb >= 0 ? 1.f : 0.f;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const float4 av = *(const float4*)(ar + 16 * t);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x * z, treg[j][t].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y * z, treg[j][t].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z * z, treg[j][t].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w * z, treg[j][t].w, acc, 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave * 256 + (4 * k4 + r) * 16 + r16] = acc[r];
+        if (tid < 16) {                               // norm2 batch statistics of the own channels
+            const double mm = sy * inv_md;
+            double v = qy * inv_md - mm * mm;
+            v = v > 0.0 ? v : 0.0;
+            c2[tid] = (float)mm; c2[16 + tid] = 1.0f / sqrtf((float)v + p.eps);
+        }
+        __syncthreads();
+        // ---- A2. relu2 mask, norm2 backward sums, dy1 ----------------------------------------------------------------------------------
+        const float dval = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid];
+        const float mu2 = c2[col], r2 = c2[16 + col];
+        const float xh2 = (yv - mu2) * r2;
+        const float g = (row < M && fmaf(g2v, xh2, b2v) > 0.f) ? dval : 0.f;
+        if (row < M) L.dmid[(size_t)row * 128 + 16 * w + col] = g;
+        {
+            double a = (double)g, b = (double)g * xh2;          // rows 4 wave .. 4 wave + 3 by shuffles, the waves through LDS
+            a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+            a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+            if (lane < 16) { dred[wave * 32 + lane] = a; dred[128 + wave * 32 + lane] = b; }
+        }
+        __syncthreads();
+        const double s1 = ((dred[col] + dred[32 + col]) + dred[64 + col]) + dred[96 + col];
+        const double s2 = ((dred[128 + col] + dred[160 + col]) + dred[192 + col]) + dred[224 + col];
+        if (tid < 16) { L.bb_y1[16 * w + tid] = s1; L.bb_y1[128 + 16 * w + tid] = s2; }
+        g_store(ga + w * 256 + tid, tag, row < M ? (g2v * r2) * (g - (float)(s1 * inv_md) - (yv - mu2) * r2 * (float)(s2 * inv_md)) : 0.f);
+        // ---- hand-off A: gather dy1 (16 x 128) ------------------------------------------------------------------------------------------
+        {
+            unsigned v[8];
+            const bool ok = g_sweep<8>(ga + tid, 256, tag, v, p.err);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dys[row * CLDYP + 16 * j + col] = __uint_as_float(v[j]);
+            if (!ok) s_fail = 1;
+        }
+        if (l > 0) load_A(l - 1);                     // next layer's conv2 weights / y1 / norm2 parameters: used after the dz broadcast
+        __syncthreads();
+        if (s_fail) return;
+        if (128 * w < C) {          // (workgroup-uniform: the barriers below are taken by all of its threads or by none)
+            // ---- B1. conv1 backward-data: d(a1)[16][own columns], 4 interleaved 16-column sets per wave, half the reduction per wave ------
+            f32x4 ac4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ac4[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float a = dys[r16 * CLDYP + 4 * (16 * kh2 + i) + k4];
+                ac4[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wreg[i].x, ac4[0], 0, 0, 0);
+                ac4[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wreg[i].y, ac4[1], 0, 0, 0);
+                ac4[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wreg[i].z, ac4[2], 0, 0, 0);
+                ac4[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wreg[i].w, ac4[3], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                *(float4*)(da + kh2 * (16 * CLDYP) + (4 * k4 + r) * CLDYP + 64 * T + 4 * r16) = make_float4(ac4[0][r], ac4[1][r], ac4[2][r], ac4[3][r]);
+            __syncthreads();
+            // ---- B2. relu1 mask, column sums, norm1 backward applied to the register gradient ---------------------------------------------
+            const bool okc = c < C;
+            float gv[8];
+            double t1 = 0, t2 = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = 8 * brg + i;
+                const float xh = (xv[i] - mu1) * r1;
+                const float gg = (okc && m < M && fmaf(g1v, xh, b1v) > 0.f) ? da[m * CLDYP + bcol] + da[16 * CLDYP + m * CLDYP + bcol] : 0.f;
+                gv[i] = gg;
+                t1 += gg; t2 += (double)gg * xh;
+            }
+            dred[256 + (brg * 2) * 128 + bcol] = t1; dred[256 + (brg * 2 + 1) * 128 + bcol] = t2;
+            __syncthreads();
+            if (okc) {
+                const double a = dred[256 + bcol] + dred[256 + 256 + bcol], b = dred[256 + 128 + bcol] + dred[256 + 384 + bcol];
+                const float gr = g1v * r1, m1 = (float)(a * inv_md), m2 = r1 * (float)(b * inv_md);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) dv[i] += gr * (gv[i] - m1 - (xv[i] - mu1) * m2);
+                if (brg == 0) { p.dg1[l][c] += (float)b; p.db1[l][c] += (float)a; }
+            }
+        }
+        // ---- the next layer's dz = the (now final) gradient of columns [C - 32, C), broadcast by their owner ------------------------------
+        if (l > 0) {
+            const int Cn = C - 32, j = c - Cn;
+            if (j >= 0 && j < 32) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const int m = 8 * brg + i; g_store(p.gz + m * 32 + j, tag - 1u, m < M ? dv[i] : 0.f); }
+            }
+        }
+    }
+    // the block's gradient slab: columns [0, C0) = the block input's gradient, [C_l, C_l + 32) = layer l's final dz
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const int m = 8 * brg + i; if (m < M) p.dslab[(size_t)m * ld + c] = dv[i]; }
+}
+
 }  // namespace
 
 extern "C" int mms_cl_fwd_group(const ClFwdP* pp, int ng, hipStream_t s) {
@@ -455,5 +702,21 @@ extern "C" int mms_cl_fwd_group(const ClFwdP* pp, int ng, hipStream_t s) {
     });
     if (rt == 1) MMS_LAUNCH(cl_fwd_kernel<1>, dim3(CLW, pp->ncl, ng), dim3(256), smem, s, a);
     else MMS_LAUNCH(cl_fwd_kernel<2>, dim3(CLW, pp->ncl, ng), dim3(256), smem, s, a);
+    return mms_check_launch();
+}
+
+extern "C" int mms_cl_bwd_group(const ClBwdP* pp, int ng, hipStream_t s) {
+    Grp<ClBwdP> a;
+    static_assert(sizeof(Grp<ClBwdP>) <= 4096, "kernel argument block");
+    if (!grp_fill(a, pp, ng, 1)) return MMS_ERR_ARG;
+    for (int g = 0; g < ng; ++g) {
+        const ClBwdP& p = pp[g];
+        if (p.M < 1 || p.M > 16 || p.ld != 1024 || p.C0 % 32 != 0 || p.nlayers < 1 || p.nlayers > 16 || p.C0 + 32 * p.nlayers > p.ld || !p.tab || !p.slab ||
+            !p.dslab || !p.st_slab || !p.ga || !p.gz || !p.err || !p.coords || p.M != pp->M || p.nlayers != pp->nlayers || p.C0 != pp->C0 ||
+            (((uintptr_t)p.ga | (uintptr_t)p.gz) & 15)) return MMS_ERR_ARG;
+        for (int l = 0; l < p.nlayers; ++l) if (!p.dg1[l] || !p.db1[l]) return MMS_ERR_ARG;
+    }
+    constexpr int smem = (768 + 16 * CLDZP + 3 * 16 * CLDYP + 1024) * 4 + 1024 * 8 + 64 * 4 + (27 * 16 + 32) * 4;
+    MMS_LAUNCH(cl_bwd_kernel, dim3(CLW, 1, ng), dim3(256), smem, s, a);
     return mms_check_launch();
 }

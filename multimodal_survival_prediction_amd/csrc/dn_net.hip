@@ -34,15 +34,15 @@ struct Plan {
     size_t coords0, coords[NB], y0, argmax, slab[NB], dslab[NB], y1[NLAYER], wpf[NLAYER], wpb[NLAYER];
     size_t dbn_mid, dbn_mid_l[NLAYER], dbn_in, dbn0, pooled, tab_pack, tab_bn, partial, dwp[NLAYER];
     // fp64 statistic accumulators (one contiguous region, zeroed once per step)
-    size_t stats_begin, stats_end;
+    size_t stats_begin, stats_begin_packed, stats_end;      // (packed primary conv2 storage: the gradient scratch dwp at the head of the region is unused)
     size_t st_y0, st_slab[NB], st_y1[NLAYER];          // forward (sum | sumsq), each 2*C doubles
     size_t counters;                                   // split-fixup tickets (zeroed at init, re-armed by their users)
-    // persistent per-block ("cluster") kernels of dense blocks 3 / 4 (dn_cl.hip, dn_b4.hip): geometry (row tiles per cluster: 0 = the block
-    // does not qualify; rows per cluster; clusters), granule hand-off buffers (inside the per-step zeroed region), layer tables; block 4's
-    // backward: counters (zeroed region), hand-off buffer; sticky error word
+    // persistent per-block ("cluster") kernels of dense blocks 3 / 4 (dn_cl.hip): geometry (row tiles per cluster: 0 = the block does not
+    // qualify; rows per cluster; clusters), granule hand-off buffers of the forward and of block 4's backward (inside the per-step zeroed
+    // region), layer tables; sticky error word
     int cl_rt[NB], cl_rpc[NB], cl_ncl[NB];
-    size_t cl_xa[NB], cl_xb[NB], cl_gst[NB], cl_tab[NB], cl_zero_begin;
-    size_t b4_cnt, b4_err, b4_xa;
+    size_t cl_xa[NB], cl_xb[NB], cl_gst[NB], cl_tab[NB], cl_zero_begin, cl_ga, cl_gz;
+    size_t b4_err;
     size_t bb_y0, bb_y1[NLAYER], bb_in[NLAYER], bb_tr[3], bb_head;   // backward (s1 | s2)
     size_t total;
 };
@@ -102,6 +102,7 @@ bool make_plan(Plan& P, int B, int D, int H, int W) {
     P.tab_bn = take(sizeof(BnRunEntry) * NBN);
     P.stats_begin = o;
     for (int i = 0; i < NLAYER; ++i) P.dwp[i] = take((size_t)27 * 32 * 128 * 4);    // tap-major conv2 gradient scratch (zeroed with the stats)
+    P.stats_begin_packed = o;
     int blk_of[NLAYER];
     { int l2 = 0; for (int b = 0; b < NB; ++b) for (int i = 0; i < LAYERS[b]; ++i) blk_of[l2++] = b; }
     P.st_y0 = take((size_t)P.R0 * 2 * 64 * 8);
@@ -113,7 +114,8 @@ bool make_plan(Plan& P, int B, int D, int H, int W) {
     for (int i = 0; i < 3; ++i) P.bb_tr[i] = take((size_t)P.R[i] * 2 * 1024 * 8);
     P.bb_head = take((size_t)2 * 1024 * 8);
     P.cl_zero_begin = o;
-    P.b4_cnt = take(256);
+    P.cl_ga = take((size_t)2 * 8 * 256 * 8);          // backward of a single-cluster block 4: hand-off A by layer parity, the dz broadcast
+    P.cl_gz = take((size_t)512 * 8);
     for (int b = 0; b < NB; ++b) {
         // a block qualifies for the cluster kernels when a sample has <= 32 voxels: clusters of whole samples with <= 16 * RT rows
         const int vox = P.g[b].D * P.g[b].H * P.g[b].W;
@@ -133,7 +135,6 @@ bool make_plan(Plan& P, int B, int D, int H, int W) {
     P.stats_end = o;
     P.counters = take(4096 * 4);
     P.b4_err = take(1024);
-    P.b4_xa = take((size_t)8 * 256 * 4);
     for (int b = 0; b < NB; ++b) P.cl_tab[b] = take(sizeof(B4Layer) * LAYERS[b]);
     P.total = o;
     return true;
@@ -248,9 +249,11 @@ extern "C" int mms_dn121_region(int B, int D, int H, int W, const char* name, in
 
 // One-time (per workspace / per parameter-pointer set) initialisation: coordinate tables + device tables.
 static int dn121_init_impl(void* ws, int B, int D, int H, int W, const void* const* params,
-                           const void* const* buffers, int bn_world, hipStream_t s) {
+                           const void* const* buffers, int bn_world, const MmsDnOpts* opts, hipStream_t s) {
     Plan P;
+    const bool packed = opts && opts->w2_packed;      // conv2 weights in packed primary storage: params[364 + 2 l (+ 1)] = the derived packs
     if (!make_plan(P, B, D, H, W) || !ws || !params || !buffers || bn_world < 1) return MMS_ERR_ARG;
+    if (packed) for (int l2 = 0; l2 < NLAYER; ++l2) if (!params[NPARAM + 2 * l2]) return MMS_ERR_ARG;
     TRY(mms_init_coords(at<int>(ws, P.coords0), B, P.g0.D, P.g0.H, P.g0.W, s));
     for (int b = 0; b < NB; ++b) TRY(mms_init_coords(at<int>(ws, P.coords[b]), B, P.g[b].D, P.g[b].H, P.g[b].W, s));
     (void)hipGetLastError();
@@ -281,7 +284,9 @@ static int dn121_init_impl(void* ws, int B, int D, int H, int W, const void* con
     for (int li = 0; li < NLAYER; ++li) {
         const int ip = IDX.layer[li], o1 = IDX.bn_layer1[li], o2 = IDX.bn_layer2[li];
         clt[li] = B4Layer{(const float*)params[ip], (const float*)params[ip + 1], (const float*)params[ip + 2],
-                          (const float*)params[ip + 3], (const float*)params[ip + 4], at<float>(ws, P.wpf[li]), at<float>(ws, P.wpb[li]),
+                          (const float*)params[ip + 3], (const float*)params[ip + 4],
+                          packed ? (const float*)params[ip + 5] : at<float>(ws, P.wpf[li]),              // (the cluster kernels read the classic packs:
+                          packed ? (const float*)params[NPARAM + 2 * li] : at<float>(ws, P.wpb[li]),     //  [co][tap][cin] = the packed primary storage itself)
                           (const float*)buffers[3 * o1], (const float*)buffers[3 * o1 + 1], (const float*)buffers[3 * o2], (const float*)buffers[3 * o2 + 1],
                           at<float>(ws, P.y1[li]), at<double>(ws, P.st_y1[li]), at<float>(ws, P.dbn_mid_l[li]), at<double>(ws, P.bb_y1[li])};
     }
@@ -306,12 +311,12 @@ static int dn121_init_impl(void* ws, int B, int D, int H, int W, const void* con
 }
 
 extern "C" int mms_dn121_init(void* ws, int B, int D, int H, int W, const void* const* params,
-                              const void* const* buffers, hipStream_t s) {
-    return dn121_init_impl(ws, B, D, H, W, params, buffers, 1, s);
+                              const void* const* buffers, const MmsDnOpts* opts, hipStream_t s) {
+    return dn121_init_impl(ws, B, D, H, W, params, buffers, 1, opts, s);
 }
 extern "C" int mms_dn121_init_sync(void* ws, int B, int D, int H, int W, const void* const* params,
-                                   const void* const* buffers, int bn_world, hipStream_t s) {
-    return dn121_init_impl(ws, B, D, H, W, params, buffers, bn_world, s);
+                                   const void* const* buffers, int bn_world, const MmsDnOpts* opts, hipStream_t s) {
+    return dn121_init_impl(ws, B, D, H, W, params, buffers, bn_world, opts, s);
 }
 
 // Tap split of the 3x3x3 convolutions (forward and backward-data): a launch should put about `target` workgroups on the
@@ -334,9 +339,9 @@ static int conv3_nsplit(int M, int ng, long cap_rows, const Dims3& g, const MmsD
 }
 
 // Which dense layers get their conv2 weights packed in MFMA-fragment order (Conv3FwdP.wfrag): those of blocks 1-3 whose launches go to the
-// small-grid kernels of dn_c3s.hip.  Block 4 keeps the classic packs (its persistent kernels, dn_b4.hip, read those; its per-layer fallback
+// small-grid kernels of dn_c3s.hip.  Block 4 keeps the classic packs (its persistent kernels, dn_cl.hip, read those; its per-layer fallback
 // path runs the small-grid kernels on them).  A function of the plan and MmsDnOpts.conv3_small only, so forward and backward agree.
-// Whether dense block b runs as ONE launch per pass on the cluster kernels (dn_cl.hip / dn_b4.hip): pass 0 = forward, 1 = backward.
+// Whether dense block b runs as ONE launch per pass on the cluster kernels (dn_cl.hip): pass 0 = forward, 1 = backward.
 // Block 4 -- MmsDnOpts.persist_b4: 0 = both passes, 1 = forward only, -1 = per-layer launches.  Block 3 -- persist_b3: 1 = forward
 // (opt-in: measured SLOWER than its per-layer launches at 32 voxels per sample, 522 vs 446 us per model, profiles/r04_cluster_kernels.txt),
 // 0 / -1 = per-layer launches.  (The caller decides: the clusters' workgroups must be co-resident.)
@@ -347,7 +352,8 @@ static bool cluster_block(const Plan& P, int b, const MmsDnOpts& o, int pass) {
     return pass == 0 ? o.persist_b4 >= 0 : o.persist_b4 == 0;
 }
 static bool conv3_frag_block(const Plan& P, int b, int ng, const MmsDnOpts& o) {
-    return b < NB - 1 && mms_conv3_small_jn(P.M[b], ng, P.g[b], o) != 0 && !cluster_block(P, b, o, 0);      // (the cluster kernels read the classic packs)
+    // (the cluster kernels read the classic forward pack: with packed primary storage that is the parameter itself, always there)
+    return b < NB - 1 && mms_conv3_small_jn(P.M[b], ng, P.g[b], o) != 0 && (o.w2_packed || !cluster_block(P, b, o, 0));
 }
 static uint64_t conv3_fragmask(const Plan& P, int ng, const MmsDnOpts& o) {
     uint64_t m = 0;
@@ -355,6 +361,13 @@ static uint64_t conv3_fragmask(const Plan& P, int ng, const MmsDnOpts& o) {
     for (int b = 0; b < NB; ++b)
         for (int i = 0; i < LAYERS[b]; ++i, ++l) if (conv3_frag_block(P, b, ng, o)) m |= 1ull << l;
     return m;
+}
+
+extern "C" int mms_dn121_w2_fragmask(int B, int D, int H, int W, const MmsDnOpts* opts, uint64_t* mask) {
+    Plan P;
+    if (!make_plan(P, B, D, H, W) || !mask) return MMS_ERR_ARG;
+    *mask = conv3_fragmask(P, 1, mms_opts(opts));
+    return MMS_OK;
 }
 
 // One model of a fold group as the drivers see it.
@@ -382,13 +395,17 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
     const int bw = dp.bn_world;        // BatchNorm statistics are taken over bw * M rows (SyncBN: the hook has summed them over the ranks)
     FOR_G if (!cx[g].ws || !cx[g].x || !cx[g].prm || !cx[g].out) return MMS_ERR_ARG;
     const void* tabs[MMS_MAX_GROUP];
+    const bool packed = o.w2_packed != 0;
     if (train) {
         void* regs[MMS_MAX_GROUP];
-        FOR_G regs[g] = at<void>(cx[g].ws, P.stats_begin);
-        TRY(mms_zero_regions_group(regs, ng, P.stats_end - P.stats_begin, s));
+        const size_t zb = packed ? P.stats_begin_packed : P.stats_begin;
+        FOR_G regs[g] = at<void>(cx[g].ws, zb);
+        TRY(mms_zero_regions_group(regs, ng, P.stats_end - zb, s));
     }
-    FOR_G tabs[g] = at<void>(cx[g].ws, P.tab_pack);
-    TRY(mms_pack_conv3_table_group_ex(tabs, ng, NLAYER, conv3_fragmask(P, ng, o), s));
+    if (!packed) {        // torch-layout weights: both packs are rebuilt from them every forward
+        FOR_G tabs[g] = at<void>(cx[g].ws, P.tab_pack);
+        TRY(mms_pack_conv3_table_group_ex(tabs, ng, NLAYER, conv3_fragmask(P, ng, o), s));
+    }
     auto st = [&](void* ws, size_t off, int Ctot_, int coff, bool sq) -> double* {
         return train ? at<double>(ws, off) + (sq ? Ctot_ : 0) + coff : nullptr;
     };
@@ -450,7 +467,9 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
                                   st(c.ws, P.st_y1[l], 128, 0, false), st(c.ws, P.st_y1[l], 128, 0, true), 0, Dims3{0, 0, 0}};
                 c1[g].srep = P.R[b]; c1[g].sstride = 2 * 128;
                 if (ks1 > 1) { c1[g].partial = at<float>(c.ws, P.partial); c1[g].ksplit = ks1; c1[g].counters = at<unsigned>(c.ws, P.counters); }
-                c3[g] = Conv3FwdP{at<float>(c.ws, P.y1[l]), at<int>(c.ws, P.coords[b]), P.g[b], P.M[b], at<float>(c.ws, P.wpf[l]),
+                const bool frag3 = conv3_frag_block(P, b, ng, o);
+                const float* wp3 = !packed ? at<float>(c.ws, P.wpf[l]) : (frag3 ? c.prm[NPARAM + 2 * l + 1] : c.prm[ip + 5]);
+                c3[g] = Conv3FwdP{at<float>(c.ws, P.y1[l]), at<int>(c.ws, P.coords[b]), P.g[b], P.M[b], wp3,
                                   slab + C, CTOT[b], mk_bn(c.ws, P.st_y1[l], 128, c.prm, ip + 3, c.buf, IDX.bn_layer2[l], P.M[b] * bw, train, P.R[b]),
                                   st(c.ws, P.st_slab[b], CTOT[b], C, false), st(c.ws, P.st_slab[b], CTOT[b], C, true),
                                   ns3 > 1 ? at<float>(c.ws, P.partial) : nullptr, ns3};
@@ -508,6 +527,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
     if (dp.b_hi < dp.b_lo || dp.b_hi >= NB || dp.b_lo < 0) return MMS_ERR_ARG;
     const int bnw = dp.bn_world;
     const bool sync = dp.hook != nullptr || bnw > 1;
+    const bool packed = o.w2_packed != 0;
     auto bbsrc = [&](void* ws, size_t off, int stride, int nrep) { return BnBwd{at<double>(ws, off), at<double>(ws, off) + stride, nrep, 2 * stride}; };
     if (dp.b_hi == NB - 1) {
         HeadBwdP hb[MMS_MAX_GROUP];
@@ -556,22 +576,22 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
         // one launch instead of conv1_bwd_data + bn_bwd_apply, no statistic atomics; MmsDnOpts.conv1_small_bwd = -1 restores the rule above.
         const int fuse_rows = o.fuse_apply_rows > 0 ? o.fuse_apply_rows : (o.conv1_small_bwd < 0 ? 32 : 128);
         const bool fuse_apply = M <= fuse_rows && M <= 128 && !sync;      // SyncBN: the sums leave the workgroup (all-reduce) before they are applied
-        // block 4 with <= 16 rows: the whole data path of the block's backward as ONE launch (dn_b4.hip); the loop below then only queues
+        // block 4 with <= 16 rows: the whole data path of the block's backward as ONE launch (dn_cl.hip); the loop below then only queues
         // the layers' weight-gradient members.  MmsDnOpts.persist_b4: -1 = off (both passes), 1 = forward only; default both.
-        const bool b4_bwd = b == 3 && M <= 16 && P.R[3] == 1 && !sync && dp.bn_world == 1 && defer && fuse_apply && o.persist_b4 == 0;
+        const bool b4_bwd = b == 3 && !sync && dp.bn_world == 1 && defer && fuse_apply && cluster_block(P, 3, o, 1);
         if (b4_bwd) {
-            B4BwdP q[MMS_MAX_GROUP];
+            ClBwdP q[MMS_MAX_GROUP];
             FOR_G {
                 const Ctx& c = cx[g];
-                q[g] = B4BwdP{at<B4Layer>(c.ws, P.cl_tab[3]), LAYERS[3], C0[3], at<float>(c.ws, P.slab[3]), at<float>(c.ws, P.dslab[3]), CTOT[3],
-                              at<double>(c.ws, P.st_slab[3]), at<int>(c.ws, P.coords[3]), P.g[3], M, 1e-5f, at<float>(c.ws, P.b4_xa),
-                              at<unsigned>(c.ws, P.b4_cnt) + 32, at<unsigned>(c.ws, P.b4_err), {}, {}};
+                q[g] = ClBwdP{at<B4Layer>(c.ws, P.cl_tab[3]), LAYERS[3], C0[3], at<float>(c.ws, P.slab[3]), at<float>(c.ws, P.dslab[3]), CTOT[3],
+                              at<double>(c.ws, P.st_slab[3]), at<int>(c.ws, P.coords[3]), P.g[3], M, 1e-5f,
+                              at<unsigned long long>(c.ws, P.cl_ga), at<unsigned long long>(c.ws, P.cl_gz), at<unsigned>(c.ws, P.b4_err), {}, {}};
                 for (int i = 0; i < LAYERS[3]; ++i) {
                     const int ip = IDX.layer[NLAYER - LAYERS[3] + i];
                     q[g].dg1[i] = (float*)c.grd[ip]; q[g].db1[i] = (float*)c.grd[ip + 1];
                 }
             }
-            TRYS(33, mms_b4_bwd_group(q, ng, s));
+            TRYS(33, mms_cl_bwd_group(q, ng, s));
         }
         for (int i = LAYERS[b] - 1; i >= 0; --i) {
             --l; C -= 32;
@@ -599,13 +619,13 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
                 float* dmid = at<float>(c.ws, P.dbn_mid_l[l]);
                 const BnSrc bn1 = mk_bn(c.ws, P.st_slab[b], CTOT[b], c.prm, ip, nullptr, 0, M * bnw, 1, P.R[b]);
                 const BnSrc bn2 = mk_bn(c.ws, P.st_y1[l], 128, c.prm, ip + 3, nullptr, 0, M * bnw, 1, P.R[b]);
-                bd[g] = Conv3BwdDataP{dslab + C, CTOT[b], at<int>(c.ws, P.coords[b]), P.g[b], M, at<float>(c.ws, P.wpb[l]),
+                bd[g] = Conv3BwdDataP{dslab + C, CTOT[b], at<int>(c.ws, P.coords[b]), P.g[b], M, packed ? c.prm[NPARAM + 2 * l] : at<float>(c.ws, P.wpb[l]),
                                       at<float>(c.ws, P.y1[l]), bn2, dmid,
                                       at<double>(c.ws, P.bb_y1[l]), at<double>(c.ws, P.bb_y1[l]) + 128,
                                       ns3 > 1 ? at<float>(c.ws, P.partial) : nullptr, ns3};
                 bd[g].srep = P.R[b]; bd[g].sstride = 2 * 128; bd[g].wfrag = conv3_frag_block(P, b, ng, o) ? 1 : 0;
                 bw[g] = Conv3BwdWP{at<float>(c.ws, P.y1[l]), at<int>(c.ws, P.coords[b]), P.g[b], M, bn2, dslab + C, CTOT[b],
-                                   at<float>(c.ws, P.dwp[l]), ms3, 1};
+                                   packed ? c.grd[ip + 5] : at<float>(c.ws, P.dwp[l]), ms3, packed ? 2 : 1};
                 Conv1BwdP& q = c1[g];
                 q = Conv1BwdP{};
                 q.dyraw = dmid; q.lddy = 128;
@@ -708,7 +728,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
         static_assert(NLAYER == 58, "UnpackGroup is sized for DenseNet121");
         int l0 = 0, nl = 0;
         for (int b = 0; b < NB; ++b) { if (b < dp.b_lo) l0 += LAYERS[b]; else if (b <= dp.b_hi) nl += LAYERS[b]; }
-        if (nl == 0) return MMS_OK;
+        if (nl == 0 || packed) return MMS_OK;        // (packed primary storage: the weight-gradient kernels wrote the gradient in place)
         const float* scr[MMS_MAX_GROUP];
         float* dwt[MMS_MAX_GROUP][NLAYER];
         float* const* dwp_[MMS_MAX_GROUP];

@@ -63,15 +63,15 @@ struct ClFwdP {
     unsigned* err;                             // sticky time-out flag
 };
 extern "C" int mms_cl_fwd_group(const ClFwdP* pp, int ng, hipStream_t s);
-struct B4BwdP {                // the data path of block 4's backward (dslab -> norm2/conv2 -> norm1/conv1 -> dslab, layer 15 .. 0) as one launch
+struct ClBwdP {                // the data path of a single-cluster block's backward (dslab -> norm2/conv2 -> norm1/conv1 -> dslab, last layer .. first) as one launch
     const B4Layer* tab; int nlayers; int C0;
     const float* slab; float* dslab; int ld;   // saved activations / their gradient [M][ld = 1024]; on entry dslab holds d(loss)/d(slab) from norm5,
                                                // on exit columns [0, C0) are the block input's gradient and [C_l, C_l + 32) layer l's final dz
     const double* st_slab;                     // (sum | sumsq) [2][ld] of the slab channels, one replica
     const int* coords; Dims3 g; int M;         // M <= 16 rows
     float eps;
-    float* xa;                                 // hand-off buffer [8][256]
-    unsigned* counter; unsigned* err;          // counter: zero on entry (its own word); err: sticky time-out flag
+    unsigned long long* ga; unsigned long long* gz;      // {tag, value} granule buffers, ZERO on entry: [2][8][256] (hand-off A, by layer parity), [512] (dz broadcast)
+    unsigned* err;                             // sticky time-out flag
     float* dg1[16]; float* db1[16];            // norm1 gamma / beta gradients of the layers (accumulated into)
 };
-extern "C" int mms_b4_bwd_group(const B4BwdP* pp, int ng, hipStream_t s);
+extern "C" int mms_cl_bwd_group(const ClBwdP* pp, int ng, hipStream_t s);

@@ -539,6 +539,7 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(const Grp<AdamP> grp) {
         }
     }
 }
+constexpr int W2N = 32 * 27 * 128;       // floats per conv2 tensor
 __global__ __launch_bounds__(256) void clip_adam_kernel(const Grp<AdamP> grp) {
     const AdamP& p = grp.p[blockIdx.z];
     __shared__ float c[6];
@@ -558,7 +559,19 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const Grp<AdamP> grp) {
     const float coef = c[0], step_size = c[1], inv_sqrt_bc2 = c[2], decay = c[3], wd = c[4];
     const float b1 = p.hyper[1], b2 = p.hyper[2], eps = p.hyper[3];
     const long long stride = (long long)gridDim.x * 256;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.n; i += stride) {
+    // The flat buffer minus the packed-primary conv2 tensors (w2_adam_pack_kernel updates those).  The kernel walks a VIRTUAL index over
+    // the remaining elements; tensor k sits at virtual position vp[k] = w2_off[k] - k * W2N, so element j of the walk is the real element
+    // j + W2N * #{k : vp[k] <= j} (binary search in LDS -- a loop over the 59 gaps with their offsets read from memory cost 59 serial
+    // round trips per workgroup: 108 us instead of 40).
+    __shared__ long long vp[64];
+    const int nw = p.n_w2;
+    if ((int)threadIdx.x < nw) vp[threadIdx.x] = p.w2_off[threadIdx.x] - (long long)threadIdx.x * W2N;
+    if (nw) __syncthreads();
+    const long long nv = p.n - (long long)nw * W2N;
+    for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < nv; j += stride) {
+        int lo = 0, hi = nw;               // #{k : vp[k] <= j}
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (vp[mid] <= j) lo = mid + 1; else hi = mid; }
+        const long long i = j + (long long)lo * W2N;
         float w = p.p[i], g = p.g[i] * coef;
         if (p.adamw) w *= decay; else g = fmaf(wd, w, g);
         const float m = fmaf(b1, p.m[i], (1.f - b1) * g);
@@ -567,9 +580,117 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const Grp<AdamP> grp) {
         p.p[i] = w - step_size * m / (sqrtf(v) * inv_sqrt_bc2 + eps);
     }
 }
+
+// ---- conv2 (3x3x3, 128 -> 32) weights of the dense layers in PACKED PRIMARY storage (MmsDnOpts.w2_packed, round 4) -------------------
+// MONAI's _DenseLayer.layers.conv2.weight is a torch tensor [32 co][128 cin][3][3][3].  The kernels never read that layout: the forward
+// wants [co][tap][cin] (or an MFMA-fragment order), the backward-data [cin][tap][co] (or its fragment order), and the weight-gradient
+// kernels flush 512-byte runs per (co, tap).  Rounds 1-3 kept the torch layout as primary storage and paid, every step, a pack launch
+// (canonical -> two packs, 51 MB per model) and an unpack launch (tap-major gradient scratch -> canonical gradient).  Now the host stores
+// weight, gradient and both Adam moments of such a tensor as [co][tap][cin] inside its flat buffers (the nn.Parameter is a strided VIEW of
+// that storage, so state_dict() / load_state_dict() / .grad keep their torch shapes), and the optimiser step -- which touches every
+// weight anyway -- emits the derived packs:
+//   * forward, layers whose launches take the classic pack: the primary storage IS that pack -- nothing to do;
+//   * backward-data pack [cin][tap][co], or both MFMA-fragment orders for the layers of w2_fragmask: written here through an LDS transpose.
+// One workgroup = (layer, tap): the tap's 32 x 128 tile of w, g, m, v is one 512-byte run per output channel.
+constexpr int W2P = 132;                 // LDS pitch of the 32 x 128 tile (floats): float4-aligned rows, 4 banks of skew per row
+
+template <bool UPDATE>
+__global__ __launch_bounds__(256) void w2_adam_pack_kernel(const Grp<AdamP> grp) {
+    const AdamP& p = grp.p[blockIdx.z];
+    const int tap = blockIdx.x, layer = blockIdx.y, tid = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float t[32 * W2P];
+    __shared__ float c[6];
+    if (UPDATE) {
+        if (p.skip_flag != nullptr && *p.skip_flag == 0.f) return;      // unusable batch: no update, the packs stay valid
+        if (tid == 0) {      // (the constants of clip_adam_kernel, same arithmetic)
+            const double lr = p.hyper[0], b1 = p.hyper[1], b2 = p.hyper[2], wd = p.hyper[4], maxn = p.hyper[5];
+            const double st = p.step[0];
+            const double norm = sqrt(*p.sumsq);
+            double coef = maxn / (norm + 1e-6);
+            if (coef > 1.0) coef = 1.0;
+            if (maxn <= 0.0) coef = 1.0;
+            const double bc1 = 1.0 - pow(b1, st), bc2 = 1.0 - pow(b2, st);
+            c[0] = (float)coef; c[1] = (float)(lr / bc1); c[2] = (float)(1.0 / sqrt(bc2));
+            c[3] = (float)(1.0 - lr * wd); c[4] = (float)wd;
+        }
+        __syncthreads();
+    }
+    const size_t base = (size_t)p.w2_off[layer];
+    // thread -> float4 j of the tile: co = idx4 >> 5, cin = 4 * (idx4 & 31); 32 consecutive threads cover one 512-byte run
+    float4 w4[4];
+    size_t off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx4 = tid + 256 * j, co = idx4 >> 5, c4 = idx4 & 31;
+        off[j] = base + ((size_t)co * 27 + tap) * 128 + 4 * c4;
+        w4[j] = *(const float4*)(p.p + off[j]);
+    }
+    if (UPDATE) {
+        float4 g4[4], m4[4], v4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { g4[j] = *(const float4*)(p.g + off[j]); m4[j] = *(const float4*)(p.m + off[j]); v4[j] = *(const float4*)(p.v + off[j]); }
+        const float coef = c[0], step_size = c[1], inv_sqrt_bc2 = c[2], decay = c[3], wd = c[4];
+        const float b1 = p.hyper[1], b2 = p.hyper[2], eps = p.hyper[3];
+        auto upd = [&](float& w, float g, float& m, float& v) {
+            g *= coef;
+            if (p.adamw) w *= decay; else g = fmaf(wd, w, g);
+            m = fmaf(b1, m, (1.f - b1) * g);
+            v = fmaf(b2, v, (1.f - b2) * g * g);
+            w = w - step_size * m / (sqrtf(v) * inv_sqrt_bc2 + eps);
+        };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            upd(w4[j].x, g4[j].x, m4[j].x, v4[j].x); upd(w4[j].y, g4[j].y, m4[j].y, v4[j].y);
+            upd(w4[j].z, g4[j].z, m4[j].z, v4[j].z); upd(w4[j].w, g4[j].w, m4[j].w, v4[j].w);
+            *(float4*)(p.p + off[j]) = w4[j]; *(float4*)(p.m + off[j]) = m4[j]; *(float4*)(p.v + off[j]) = v4[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx4 = tid + 256 * j, co = idx4 >> 5, c4 = idx4 & 31;
+        *(float4*)(t + co * W2P + 4 * c4) = w4[j];
+    }
+    __syncthreads();
+    const bool frag = (p.w2_fragmask >> layer) & 1ull;
+    float4* pb = (float4*)p.w2_pack_b[layer];
+    if (frag) {
+        // backward fragment order [tap][cin/16][co/16][lane = ((co/4)%4)*16 + cin%16][co%4]: float4 index q * 64 + lane, q = (cin/16)*2 + co/16
+        float4* dst = pb + (size_t)tap * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx4 = tid + 256 * j, q = idx4 >> 6, lane = idx4 & 63;
+            const int cin = ((q >> 1) << 4) | (lane & 15), co0 = ((q & 1) << 4) | ((lane >> 4) << 2);
+            dst[idx4] = make_float4(t[co0 * W2P + cin], t[(co0 + 1) * W2P + cin], t[(co0 + 2) * W2P + cin], t[(co0 + 3) * W2P + cin]);
+        }
+        // forward fragment order [tap][cin/32][(cin/16)%2][co/16][lane = ((cin/4)%4)*16 + co%16][cin%4]: float4 index q * 64 + lane,
+        // q = (cin/16)*2 + co/16 (cin/16 = 2*(cin/32) + (cin/16)%2)
+        float4* df = (float4*)p.w2_pack_f[layer] + (size_t)tap * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx4 = tid + 256 * j, q = idx4 >> 6, lane = idx4 & 63;
+            const int c4 = ((q >> 1) << 2) | (lane >> 4), co = ((q & 1) << 4) | (lane & 15);
+            df[idx4] = *(const float4*)(t + co * W2P + 4 * c4);
+        }
+    } else {
+        // classic backward-data pack [cin][tap][co]: one 128-byte run of 32 output channels per input channel
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx4 = tid + 256 * j, cin = idx4 >> 3, co0 = (idx4 & 7) << 2;
+            pb[((size_t)cin * 27 + tap) * 8 + (idx4 & 7)] =
+                make_float4(t[co0 * W2P + cin], t[(co0 + 1) * W2P + cin], t[(co0 + 2) * W2P + cin], t[(co0 + 3) * W2P + cin]);
+        }
+    }
+}
+
+
+
 static bool adam_group(Grp<AdamP>& a, const AdamP* pp, int ng) {
     if (!grp_fill(a, pp, ng, 1) || pp->n <= 0) return false;
-    for (int g = 1; g < ng; ++g) if (pp[g].n != pp->n) return false;
+    for (int g = 0; g < ng; ++g) {
+        const AdamP& p = pp[g];
+        if (p.n != pp->n || p.n_w2 != pp->n_w2 || p.w2_fragmask != pp->w2_fragmask || p.n_w2 < 0 || p.n_w2 > 64) return false;
+        if (p.n_w2 && (!p.w2_off || !p.w2_pack_b || (p.w2_fragmask && !p.w2_pack_f) || (((uintptr_t)p.p | (uintptr_t)p.g | (uintptr_t)p.m | (uintptr_t)p.v) & 15))) return false;
+    }
     return true;
 }
 extern "C" int mms_grad_sumsq_group(const AdamP* pp, int ng, hipStream_t s) {
@@ -587,10 +708,18 @@ extern "C" int mms_clip_adam_group(const AdamP* pp, int ng, hipStream_t s) {
     long long blocks = (pp->n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     MMS_LAUNCH(clip_adam_kernel, dim3((unsigned)blocks, 1, ng), dim3(256), 0, s, a);
+    if (pp->n_w2 > 0) MMS_LAUNCH(w2_adam_pack_kernel<true>, dim3(27, pp->n_w2, ng), dim3(256), 0, s, a);
+    return mms_check_launch();
+}
+extern "C" int mms_w2_pack_group(const AdamP* pp, int ng, hipStream_t s) {
+    Grp<AdamP> a;
+    if (!adam_group(a, pp, ng)) return MMS_ERR_ARG;
+    if (pp->n_w2 > 0) MMS_LAUNCH(w2_adam_pack_kernel<false>, dim3(27, pp->n_w2, ng), dim3(256), 0, s, a);
     return mms_check_launch();
 }
 MMS_SINGLE(mms_grad_sumsq, AdamP)
 MMS_SINGLE(mms_clip_adam, AdamP)
+MMS_SINGLE(mms_w2_pack, AdamP)
 
 // ------------------------------------------------------------------------------------------------------
 // batch assembly: gather cohort rows into the step's static input buffers (all sources, all models, one launch)

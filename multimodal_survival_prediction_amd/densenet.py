@@ -116,7 +116,7 @@ class DenseNet121(nn.Module):
         ptab = (ctypes.c_void_p * 364)(*[p.data_ptr() for p in params])
         btab = (ctypes.c_void_p * 363)(*[b.data_ptr() for b in bufs])
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        _lib.check(lib.mms_dn121_init(ws.data_ptr(), B, D, H, W, ptab, btab, st), "mms_dn121_init")
+        _lib.check(lib.mms_dn121_init(ws.data_ptr(), B, D, H, W, ptab, btab, None, st), "mms_dn121_init")      # (torch-layout conv2 weights)
         self._eng = dict(key=key, ws=ws, ptab=ptab, btab=btab, dims=(B, D, H, W), lib=lib)
         return self._eng
 

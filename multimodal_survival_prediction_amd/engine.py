@@ -126,7 +126,9 @@ class SurvivalEngine:
         self.model = model
         self.prog = head_program(model)
         # MmsDnOpts of every encoder driver call of this engine (the width of class_layers.out rides in it)
-        self.dn_opts = ops.dn_opts(dict(dn_opts or {}), out_features=self.prog.get("enc_width", 128))
+        from .densenet import DenseNet121
+        self.packed = isinstance(self.prog["encoder"], DenseNet121)      # conv2 weights in packed primary storage (MmsDnOpts.w2_packed)
+        self.dn_opts = ops.dn_opts(dict(dn_opts or {}), out_features=self.prog.get("enc_width", 128), w2_packed=1 if self.packed else 0)
         p0 = next(model.parameters())
         if not p0.is_cuda:
             raise RuntimeError("SurvivalEngine: move the model to the GPU first (model.to('cuda')); no CPU fallback")
@@ -166,20 +168,55 @@ class SurvivalEngine:
         assert self.gflat.numel() == n + pad and self.gflat.is_contiguous()
         o = 0
         self.gviews = []
+        # DenseNet121's 58 conv2 weights (_DenseLayer.layers.conv2, [32, 128, 3, 3, 3]) are stored [cout][tap][cin] -- the layout the
+        # forward kernels read and the weight-gradient kernels flush -- as strided VIEWS with the torch shape: state_dict(),
+        # load_state_dict(), .grad and torch optimisers see ordinary tensors (MmsDnOpts.w2_packed; csrc/heads.hip w2_adam_pack_kernel)
+        w2ids = set()
+        if self.packed:
+            w2ids = {id(p) for k, p in self.prog["encoder"].named_parameters() if k.endswith("layers.conv2.weight")}
+            assert len(w2ids) == 58
+        self.w2_offsets = []
+
+        def view(buf, o, p):
+            if id(p) in w2ids:
+                return buf.as_strided((32, 128, 3, 3, 3), (27 * 128, 1, 9 * 128, 3 * 128, 128), buf.storage_offset() + o)      # (the offset is absolute in the storage)
+            return buf[o:o + p.numel()].view_as(p)
         with torch.no_grad():
             for p in self.params:
-                v = self.flat[o:o + p.numel()].view_as(p)
+                if id(p) in w2ids:
+                    assert tuple(p.shape) == (32, 128, 3, 3, 3) and o % 4 == 0
+                    self.w2_offsets.append(o)
+                v = view(self.flat, o, p)
                 v.copy_(p.data)
                 p.data = v
-                g = self.gflat[o:o + p.numel()].view_as(p)
-                self.gviews.append(g)
+                self.gviews.append(view(self.gflat, o, p))
                 o += p.numel()
         self._key = (self.params[0].data_ptr(), self.params[-1].data_ptr())
+        self.w2 = None
+        if self.w2_offsets:
+            # the derived packs (backward-data pack; forward MFMA-fragment pack of the small-grid layers) and the device tables of AdamP.w2_*
+            self.w2_packs = torch.zeros(len(self.w2_offsets), 2, 32 * 27 * 128, device=self.device)
+            base, step = self.w2_packs.data_ptr(), 32 * 27 * 128 * 4
+            self.w2 = dict(off=torch.tensor(self.w2_offsets, dtype=torch.int64, device=self.device),
+                           pack_b=torch.tensor([base + 2 * i * step for i in range(len(self.w2_offsets))], dtype=torch.int64, device=self.device),
+                           pack_f=torch.tensor([base + (2 * i + 1) * step for i in range(len(self.w2_offsets))], dtype=torch.int64, device=self.device),
+                           fragmask=None)
+            self._packs_version = None
 
     def _check_params(self):
         if (self.params[0].data_ptr(), self.params[-1].data_ptr()) != self._key:
             raise RuntimeError("model parameters were re-allocated (e.g. .to()/.load on another device) after the "
                                "engine was built; create a new SurvivalEngine")
+
+    def sync_packs(self, force=False):
+        """Packed primary conv2 storage: the derived packs are written by the fused optimiser step (mms_clip_adam); after ANY other
+        change of the weights -- load_state_dict, a torch optimiser, the roll-back around graph capture -- they are rebuilt here
+        (mms_w2_pack).  Detected through the version counter torch keeps for the flat buffer (its views share it); cheap to call."""
+        if self.w2 is None or self.w2["fragmask"] is None:
+            return
+        if force or self._packs_version != self.flat._version:
+            _lib.check(self.lib.mms_w2_pack(ctypes.byref(self._w2_adam), ops.stream()), "mms_w2_pack")
+            self._packs_version = self.flat._version
 
     def set_lr(self, lr):
         self.hyper[0] = lr
@@ -233,11 +270,24 @@ class SurvivalEngine:
             ebufs = list(enc.buffers())
             npar, nbuf = (12, 9) if P.fallback else (364, 363)
             assert len(eparams) == npar and len(ebufs) == nbuf
+            if self.w2 is not None:
+                mask = ctypes.c_uint64(0)
+                _lib.check(self.lib.mms_dn121_w2_fragmask(B, D, H, W, ctypes.byref(self.dn_opts), ctypes.byref(mask)), "mms_dn121_w2_fragmask")
+                if self.w2["fragmask"] is None:
+                    self.w2["fragmask"] = mask.value
+                    self._w2_adam = ops.adam_params(self.flat, self.gflat, self.m, self.v, self.hyper, self.sumsq, self.step_count, w2=self.w2)
+                elif self.w2["fragmask"] != mask.value:
+                    raise RuntimeError("this engine's conv2 packs were laid out for another volume size (fragment-order layers differ); "
+                                       "use one volume size per model")
             nbytes = ctypes.c_size_t(0)
             wsfn = self.lib.mms_fb_workspace_bytes if P.fallback else self.lib.mms_dn121_workspace_bytes
             _lib.check(wsfn(B, D, H, W, ctypes.byref(nbytes)), "workspace_bytes")
             P.ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
-            P.ptab = (ctypes.c_void_p * npar)(*[p.data_ptr() for p in eparams])
+            ptrs = [p.data_ptr() for p in eparams]
+            if self.w2 is not None:       # packed primary conv2 storage: + 116 pointers (layer l: backward-data pack, forward fragment pack)
+                base, step = self.w2_packs.data_ptr(), 32 * 27 * 128 * 4
+                ptrs += [base + j * step for j in range(2 * len(self.w2_offsets))]
+            P.ptab = (ctypes.c_void_p * len(ptrs))(*ptrs)
             P.btab = (ctypes.c_void_p * nbuf)(*[b.data_ptr() for b in ebufs])
             P.gtab = (ctypes.c_void_p * npar)(*[gmap[id(p)].data_ptr() for p in eparams])
             if P.fallback:
@@ -245,8 +295,8 @@ class SurvivalEngine:
                     raise RuntimeError("SyncBN drives the DenseNet121-3D encoder only")
                 _lib.check(self.lib.mms_fb_init(P.ws.data_ptr(), B, D, H, W, P.btab, ops.stream()), "mms_fb_init")
             else:
-                _lib.check(self.lib.mms_dn121_init_sync(P.ws.data_ptr(), B, D, H, W, P.ptab, P.btab, bn_world, ops.stream()),
-                           "mms_dn121_init_sync")
+                _lib.check(self.lib.mms_dn121_init_sync(P.ws.data_ptr(), B, D, H, W, P.ptab, P.btab, bn_world, ctypes.byref(self.dn_opts),
+                                                        ops.stream()), "mms_dn121_init_sync")
         # head launches (train / eval variants)
         P.lin_fwd = {True: [], False: []}
         P.lin_bwd = []
@@ -303,10 +353,13 @@ class SurvivalEngine:
         P.cox_eval = _S()["CoxP"](hz.data_ptr(), 1, P.time.data_ptr(), P.event.data_ptr(), P.valid.data_ptr(), B, 1.0,
                                   P.lse.data_ptr(), None, 1, P.cox_eval_out.data_ptr(), self.tie_mode, P.tie_frac.data_ptr())
         book = dict(acc=self.acc, cox_out=P.cox_out, entropy=self.entropy, rng=self.rng)   # per-step bookkeeping, in-kernel
+        w2 = self.w2 if (self.w2 is not None and self.w2["fragmask"] is not None) else None
+        if self.w2 is not None and w2 is None:        # (an encoder-less plan of an imaging model, e.g. the SyncBN heads plan, made first)
+            raise RuntimeError("create the engine's first plan with the encoder (packed conv2 storage needs the volume size)")
         P.adam = ops.adam_params(self.flat, self.gflat, self.m, self.v, self.hyper, self.sumsq, self.step_count,
-                                 None, self.adamw, **book)
+                                 None, self.adamw, w2=w2, **book)
         P.adam_skip = ops.adam_params(self.flat, self.gflat, self.m, self.v, self.hyper, self.sumsq, self.step_count,
-                                      P.cox_out[1:], self.adamw, **book)
+                                      P.cox_out[1:], self.adamw, w2=w2, **book)
         P.graphs = {}
         self.plans[key] = P
         return P
@@ -381,6 +434,7 @@ class SurvivalEngine:
         return ctypes.byref(o)
 
     def _forward(self, P, train):
+        self.sync_packs()
         st = ops.stream()
         lib, prog = self.lib, self.prog
         B, (D, H, W) = P.B, (P.dims if P.has_enc else (1, 1, 1))
@@ -601,6 +655,7 @@ class SurvivalEngine:
         check_train_batch(B, ddp_world if sync_bn else 1)
         P = self.plan(B, tuple(ct.shape[-3:]) if ct is not None else None, bn_world=ddp_world if (sync_bn and ddp_world > 1) else 1)
         self.load_batch(P, ct, rna, clinical, mask, time, event, valid)
+        self.sync_packs()
         if ddp_world > 1 and sync_bn:
             self._ddp_step_syncbn(P, ddp_world)
             return
@@ -626,6 +681,7 @@ class SurvivalEngine:
                 self.step_count.copy_(state[3]); self.rng.copy_(state[4]); self.acc.copy_(state[5])
                 for b, b0 in zip(self.model.buffers(), state[6]):
                     b.copy_(b0)
+            self.sync_packs()          # (the roll-back changed the weights: rebuild the derived conv2 packs, outside any capture)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._train_body(P, skip_if_unusable)
@@ -635,6 +691,7 @@ class SurvivalEngine:
                 self.step_count.copy_(state[3]); self.rng.copy_(state[4]); self.acc.copy_(state[5])
                 for b, b0 in zip(self.model.buffers(), state[6]):
                     b.copy_(b0)
+            self.sync_packs()          # (the roll-back changed the weights: rebuild the derived conv2 packs, outside any capture)
         P.graphs[key].replay()
 
     # ---- data-parallel step (one process per GPU) --------------------------------------------------------
@@ -704,6 +761,7 @@ class SurvivalEngine:
                 self.step_count.copy_(state[3]); self.rng.copy_(state[4]); self.acc.copy_(state[5])
                 for b, b0 in zip(self.model.buffers(), state[6]):
                     b.copy_(b0)
+            self.sync_packs()          # (the roll-back changed the weights: rebuild the derived conv2 packs, outside any capture)
             graphs = {}
             for part in [it[1] for it in seq if it[0] == "part"] + [upd]:
                 g = torch.cuda.CUDAGraph()
@@ -808,6 +866,7 @@ class SurvivalEngine:
         B = rna.shape[0]
         P = self.plan(B, tuple(ct.shape[-3:]) if ct is not None else None)
         self.load_batch(P, ct, rna, clinical, mask)
+        self.sync_packs()
         if use_graph:
             if "eval" not in P.graphs:
                 s = torch.cuda.Stream()

@@ -138,6 +138,13 @@ class FoldGroupEngine:
         for i in range(n_pre, len(lf)):
             _lib.check(lib.mms_linear_fwd_group(lf[i], ng, st), "mms_linear_fwd_group")
 
+    @staticmethod
+    def _sync_packs(GP):
+        """Derived conv2 packs of every member current (SurvivalEngine.sync_packs: a no-op unless the weights were changed outside the
+        fused step since the last call)."""
+        for e in GP.eng:
+            e.sync_packs()
+
     def _zero(self, GP):
         if GP.full:
             self.gflat_all.zero_(); self.sumsq_all.zero_(); self.entropy_all.zero_()
@@ -182,6 +189,7 @@ class FoldGroupEngine:
                 e.acc.copy_(s[5]); e.acc_eval.copy_(s[7])
                 for b, b0 in zip(e.model.buffers(), s[6]):
                     b.copy_(b0)
+                e.sync_packs()         # (the roll-back changed the weights: rebuild the derived conv2 packs, outside any capture)
 
     def _opts_arg(self, GP):
         """`const MmsDnOpts*` of the group's driver calls (the members share one block: same class, same options).  The persistent
@@ -227,6 +235,7 @@ class FoldGroupEngine:
         GP = self.plan(B, dims, members)
         for e, P, b in zip(GP.eng, GP.Ps, batches):
             e.load_batch(P, **b)
+        self._sync_packs(GP)
         if not use_graph:
             self._train_body(GP, skip_if_unusable)
             return
@@ -274,6 +283,7 @@ class FoldGroupEngine:
         dims = tuple(cohort["image"].shape[-3:]) if self.engines[0].prog["encoder"] is not None else None
         GP = self.plan(B, dims, members)
         self._gather_indexed(GP, cohort, idx)
+        self._sync_packs(GP)
         if not use_graph:
             self._train_body(GP, skip_if_unusable)
             return
@@ -298,6 +308,7 @@ class FoldGroupEngine:
         dims = tuple(cohort["image"].shape[-3:]) if self.engines[0].prog["encoder"] is not None else None
         GP = self.plan(idx.shape[1], dims, members)
         self._gather_indexed(GP, cohort, idx)
+        self._sync_packs(GP)
         self._graph(GP, "evalloss", lambda: self._eval_loss_body(GP)).replay()
         return [(P.buf["hz"][:, 0], P.cox_eval_out) for P in GP.Ps]
 
@@ -309,6 +320,7 @@ class FoldGroupEngine:
         GP = self.plan(B, dims, members)
         for e, P, b in zip(GP.eng, GP.Ps, batches):
             e.load_batch(P, **b)
+        self._sync_packs(GP)
         if use_graph:
             self._graph(GP, "eval", lambda: self._forward(GP, False)).replay()
         else:

@@ -130,9 +130,9 @@ def conv3_bwd_data(dz, coords, dims, wpb, y1, bn, dbn, s1, s2, partial=None, nsp
     call("mms_conv3_bwd_data", p, opts)
 
 
-def conv3_bwd_weight(y1, coords, dims, bn, dz, dw, msplit=1, tapmajor=False, opts=None):
+def conv3_bwd_weight(y1, coords, dims, bn, dz, dw, msplit=1, tapmajor=False, opts=None, layout=None):
     p = _S()["Conv3BwdWP"](ptr(y1), ptr(coords), dims3(dims), y1.shape[0], bn, ptr(dz), dz.stride(0), ptr(dw), msplit,
-                           1 if tapmajor else 0)
+                           layout if layout is not None else (1 if tapmajor else 0))          # Conv3BwdWP.dw_layout
     call("mms_conv3_bwd_weight", p, opts)
 
 
@@ -243,9 +243,15 @@ def cindex_counts(h, time, event):
 
 
 def adam_params(p_, g, m, v, hyper, sumsq, step, skip_flag=None, adamw=False, acc=None, cox_out=None, entropy=None,
-                rng=None):
-    return _S()["AdamP"](ptr(p_), ptr(g), ptr(m), ptr(v), p_.numel(), ptr(hyper), ptr(sumsq), ptr(step), ptr(skip_flag),
-                         1 if adamw else 0, ptr(acc), ptr(cox_out), ptr(entropy), ptr(rng))
+                rng=None, w2=None):
+    """w2: None or dict(off=int64[n] device tensor, pack_b=ptr table (int64[n] device tensor of addresses), pack_f=the same,
+    fragmask=int): the conv2 tensors kept in packed primary storage inside the flat buffers (AdamP.w2_*, include/mmsurv.h)."""
+    a = _S()["AdamP"](ptr(p_), ptr(g), ptr(m), ptr(v), p_.numel(), ptr(hyper), ptr(sumsq), ptr(step), ptr(skip_flag),
+                      1 if adamw else 0, ptr(acc), ptr(cox_out), ptr(entropy), ptr(rng))
+    if w2 is not None:
+        a.w2_off, a.w2_pack_b, a.w2_pack_f = ptr(w2["off"]), ptr(w2["pack_b"]), ptr(w2["pack_f"])
+        a.n_w2, a.w2_fragmask = int(w2["off"].numel()), int(w2["fragmask"])
+    return a
 
 
 _WORKER_STREAMS = {}

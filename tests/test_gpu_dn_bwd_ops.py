@@ -78,6 +78,10 @@ def test_dense_layer_backward(ops, B, dims, C, Ctot, ms, split, small):
     dw2m, dw2t = torch.zeros_like(w2), torch.zeros(27, 32, 128, device=DEV)
     ops.conv3_bwd_weight(y1d, coords, dims, bn2, dslab[:, C:C + 32], dw2m, ms, opts=mt)
     ops.conv3_bwd_weight(y1d, coords, dims, bn2, dslab[:, C:C + 32], dw2t, ms, tapmajor=True, opts=mt)
+    dw2p = torch.zeros(32, 27, 128, device=DEV)            # packed primary layout [cout][tap][cin] (Conv3BwdWP.dw_layout = 2), both kernel forms
+    dw2q = torch.zeros(32, 27, 128, device=DEV)
+    ops.conv3_bwd_weight(y1d, coords, dims, bn2, dslab[:, C:C + 32], dw2p, ms, layout=2, opts=mt)
+    ops.conv3_bwd_weight(y1d, coords, dims, bn2, dslab[:, C:C + 32], dw2q, ms, layout=2, opts=ops.dn_opts(conv3w_mt=-1))
     dw1 = torch.zeros_like(w1)
     dg2, db2, dg1, db1 = (torch.zeros(128, device=DEV), torch.zeros(128, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV))
     dbn_in = torch.empty(M, Ctot, device=DEV)
@@ -105,6 +109,8 @@ def test_dense_layer_backward(ops, B, dims, C, Ctot, ms, split, small):
     assert_close(dw2, c2.weight.grad, 1e-4, "dW conv2")
     assert_close(dw2m, c2.weight.grad, 1e-4, "dW conv2 (multi-tap kernel)")
     assert_close(dw2t.permute(1, 2, 0).reshape(32, 128, 3, 3, 3), c2.weight.grad, 1e-4, "dW conv2 (multi-tap kernel, tap-major scratch)")
+    assert_close(dw2p.permute(0, 2, 1).reshape(32, 128, 3, 3, 3), c2.weight.grad, 1e-4, "dW conv2 (multi-tap kernel, packed primary layout)")
+    assert_close(dw2q.permute(0, 2, 1).reshape(32, 128, 3, 3, 3), c2.weight.grad, 1e-4, "dW conv2 (one-tap kernel, packed primary layout)")
     assert_close(dg2, n2.weight.grad, 1e-4, "dgamma2")
     assert_close(db2, n2.bias.grad, 1e-4, "dbeta2")
     assert_close(dw1, c1.weight.grad.view(128, C), 1e-4, "dW conv1")
