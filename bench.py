@@ -85,13 +85,15 @@ def _bwdw_multitap(M, G):          # dn_bwd.hip conv3w_mt_ok: which of the two w
     return chunk >= 512 and w * 10 >= -(-w // 768) * 768 * 9
 
 
-def measure_conv2_family(B, dims, device, G, reps=20):
+def measure_conv2_family(B, dims, device, G, reps=20, manifest=None):
     """The three kernels of the dense layers' 3x3x3 convolution (norm2/relu2/conv2 of MONAI's _DenseLayer): forward
     (mms_conv3_fwd_group), backward-data (mms_conv3_bwd_data_group) and weight gradient (mms_conv3_bwd_weight_group) -- 58
     launches each per lock-step step, together the largest share of GPU time in profiles/.  Each is timed live with HIP
     events on the launch stream (torch's current stream), launched exactly as the step launches it: one launch carries the G
-    models of a sub-group, shape by shape (the four dense blocks) with the driver's own split factors, weighted by the layer
-    counts.  Algorithmic FLOPs per launch of any of the three = G * 2 * M * 27 * 128 * 32.  (The per-layer launches of a dense block that
+    models of a sub-group, shape by shape (the four dense blocks) with the driver's own split factors, weighted by the launch
+    counts.  Algorithmic FLOPs per launch of any of the three = members * 2 * M * 27 * 128 * 32: members = the G models for the forward,
+    the backward-data and block 1's weight gradient; the weight-gradient launches of blocks 2-4 are DEFERRED to the end of their block
+    and batched over layers by the driver (dn_net.hip flush_w: up to 10 // G * G (model, layer) members per launch) -- timed that way.  (The per-layer launches of a dense block that
     runs as one persistent launch per pass, csrc/dn_cl.hip / dn_b4.hip, do not exist in the step: they are left out of the forward /
     backward-data ops' averages; the weight-gradient launches remain.)
     -> {op: (avg seconds per launch, avg FLOPs per launch, launches per step)}"""
@@ -133,26 +135,42 @@ def measure_conv2_family(B, dims, device, G, reps=20):
                                ost[0, 0, 64:].data_ptr(), ost[0, 1, 64:].data_ptr(), ops.ptr(part), ns, R, 2 * 256, 1 if frag else 0)
             d = S["Conv3BwdDataP"](dz.data_ptr(), dz.stride(0), coords.data_ptr(), ops.dims3(gd), M, (wfb if frag else wpb).data_ptr(), y1.data_ptr(), bn,
                                    dbn.data_ptr(), bst[0, 0].data_ptr(), bst[0, 1].data_ptr(), ops.ptr(part), ns, R, 2 * 128, 1 if frag else 0)
-            g_ = S["Conv3BwdWP"](y1.data_ptr(), coords.data_ptr(), ops.dims3(gd), M, bn, dz.data_ptr(), dz.stride(0),
-                                 dwp.data_ptr(), _bwdw_msplit(M, G), 1)
-            fw.append(f); bd.append(d); bw.append(g_)
-        arrs = {"fwd": ((S["Conv3FwdP"] * G)(*fw), lib.mms_conv3_fwd_group),
-                "bwd_data": ((S["Conv3BwdDataP"] * G)(*bd), lib.mms_conv3_bwd_data_group),
-                "bwd_weight": ((S["Conv3BwdWP"] * G)(*bw), lib.mms_conv3_bwd_weight_group)}
-        for op, (arr, fn) in arrs.items():
+            fw.append(f); bd.append(d)
+        # weight gradient: one launch carries `nw` (model, layer) members -- G for block 1, the deferred + batched count for blocks 2-4
+        defer = i > 0 and 2 * G <= 10
+        nw = (10 // G) * G if defer else G
+        for k in range(nw):           # (every member has its own activations and gradients, as the layers of a block have in the step)
+            if k < G:
+                y1, s_, q_, dslab = keep[k][0], keep[k][1], keep[k][2], keep[k][4]
+            else:
+                y1 = torch.randn(M, 128, device=device)
+                s_, q_ = y1.double().sum(0), (y1.double() ** 2).sum(0)
+                dslab = torch.randn(M, 256, device=device)
+            bn = ops.bnsrc(gam, bet, M, True, s_, q_)
+            dz = dslab[:, 64:96]
+            dwk = torch.zeros(27 * 32 * 128, device=device)
+            keep.append((y1, s_, q_, dslab, dwk))
+            bw.append(S["Conv3BwdWP"](y1.data_ptr(), coords.data_ptr(), ops.dims3(gd), M, bn, dz.data_ptr(), dz.stride(0),
+                                      dwk.data_ptr(), _bwdw_msplit(M, nw), 2))
+        arrs = {"fwd": ((S["Conv3FwdP"] * G)(*fw), lib.mms_conv3_fwd_group, G, layers),
+                "bwd_data": ((S["Conv3BwdDataP"] * G)(*bd), lib.mms_conv3_bwd_data_group, G, layers),
+                "bwd_weight": ((S["Conv3BwdWP"] * nw)(*bw), lib.mms_conv3_bwd_weight_group, nw, layers * G / nw)}      # launches per step: members / members per launch
+        for op, (arr, fn, nm, nlaunch) in arrs.items():
             if (op == "fwd" and cl_fwd.get(i, False)) or (op == "bwd_data" and cl_bwd.get(i, False)):
                 continue
             for _ in range(3):
-                _lib.check(fn(arr, G, None, ops.stream()), op)          # (launch-shape options: NULL = the defaults the step runs with)
+                _lib.check(fn(arr, nm, None, ops.stream()), op)          # (launch-shape options: NULL = the defaults the step runs with)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(reps):
-                _lib.check(fn(arr, G, None, ops.stream()), op)
+                _lib.check(fn(arr, nm, None, ops.stream()), op)
             e1.record()
             torch.cuda.synchronize()
-            tot[op][0] += e0.elapsed_time(e1) * 1e-3 / reps * layers
-            tot[op][1] += G * 2.0 * M * 27 * 128 * 32 * layers
-            tot[op][2] += layers
+            tot[op][0] += e0.elapsed_time(e1) * 1e-3 / reps * nlaunch
+            tot[op][1] += nm * 2.0 * M * 27 * 128 * 32 * nlaunch
+            tot[op][2] += nlaunch
+            if manifest is not None:      # what this leg launched, in order: 3 warm-up + `reps` timed calls each (tools/pmc_conv2.py reads it)
+                manifest.append(dict(G=G, block=i, op=op, M=M, members=nm, launches_per_step=nlaunch, calls=3 + reps))
     return {op: (t / n, f / n, n) for op, (t, f, n) in tot.items()}
 
 
@@ -171,26 +189,28 @@ def _roof_name(op, B, dims, group_sizes):
     return name
 
 
-def roofline_block(B, dims, dev, group_sizes):
+def roofline_block(B, dims, dev, group_sizes, with_manifest=False):
     """`roofline` object of the JSON line.  group_sizes: models per launch of the sub-groups the timed region ran (e.g. (3, 2));
     per op the launches of all sub-groups are pooled (time and FLOPs summed).  The dominant kernel = the op with the largest
     time per lock-step step; the other two are listed beside it."""
     fam = {}
+    manifest = [] if with_manifest else None
     for G in group_sizes:
-        for op, (t, f, nl) in measure_conv2_family(B, dims, dev, G).items():
+        for op, (t, f, nl) in measure_conv2_family(B, dims, dev, G, manifest=manifest).items():
             a = fam.setdefault(op, [0.0, 0.0, 0, 0])
             a[0] += t; a[1] += f; a[2] += 1; a[3] = nl
     dom = max(fam, key=lambda k: fam[k][0] * fam[k][3])          # largest time per lock-step step = average x launches
     t, f, n, _ = fam[dom]
     traffic = None      # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_pmc_conv2_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r04_pmc_conv2_traffic.json")) as fh:
             j = json.load(fh)
         if tuple(j.get("sub_groups", ())) == tuple(group_sizes):          # the committed passes ran on this launch configuration
             traffic = j[dom]["avg_hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError, TypeError):
         pass
-    return {"bound": "mfma", "kernel": _roof_name(dom, B, dims, group_sizes) + f"; {fam[dom][3]} launches per lock-step step and sub-group, sub-groups of {'+'.join(map(str, group_sizes))} fold models per launch",
+    extra = {"manifest": manifest} if with_manifest else {}
+    return {**extra, "bound": "mfma", "kernel": _roof_name(dom, B, dims, group_sizes) + f"; {fam[dom][3]:.1f} launches per lock-step step and sub-group (the weight-gradient launches of dense blocks 2-4 carry up to 10 (model, layer) members, as the step batches them), sub-groups of {'+'.join(map(str, group_sizes))} fold models",
             "achieved": f / t / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": f / t / 1e12 / PEAK_FP32_MFMA_TFLOPS,
             "traffic": traffic, "avg_launch_us": t / n * 1e6, "avg_flops_per_launch": f / n,
             "family": {op: {"avg_launch_us": v[0] / v[2] * 1e6, "launches_per_step_and_sub_group": v[3], "achieved": v[1] / v[0] / 1e12,
@@ -773,7 +793,7 @@ def main():
         from multimodal_survival_prediction_amd.training import subgroup_sizes
         sub = (subgroup_sizes(args.folds, args.lockstep_streams) if args.workload == "c3"
                else (max(1, min(args.fold_group, 10)),))
-        print(json.dumps(roofline_block(args.batch, tuple(args.volume), dev, sub)), flush=True)
+        print(json.dumps(roofline_block(args.batch, tuple(args.volume), dev, sub, with_manifest=True)), flush=True)
         return
     if args.workload == "c5":
         if world > 1:

@@ -29,6 +29,24 @@ template <class P> static inline bool grp_fill(Grp<P>& a, const P* pp, int ng, i
 static inline MmsDnOpts mms_opts(const MmsDnOpts* o) { return o ? *o : MmsDnOpts{}; }
 
 
+// XCD-aware placement of an M-tiled launch whose grid is (tiles, *, models) (cdna_hip_programming.md T1; placement affects speed only,
+// never results).  Workgroups are dealt round-robin over the 8 XCDs by linear id, so with gridDim.x a multiple of 8 the workgroups
+// with equal blockIdx.x % 8 share an XCD (and its L2) whatever their y / z.  (a) One model: XCD k gets the CONTIGUOUS tile range
+// [k n/8, (k+1) n/8) -- neighbouring tiles share halo rows.  (b) A fold group of 2, 4 or 8 models: model g gets the 8 / ng XCDs
+// g * 8/ng ..: a layer's weights are then fetched by 4 / 2 / 1 L2s instead of by all 8 (round 3, sub-groups of 2: forward 2.96x the
+// algorithmic bytes at the fabric, each of the 8 L2s holding its own copy of both models' 442 KB).  -> model index, tile index.
+__device__ __forceinline__ void xcd_place(int& gi, int& bx) {
+    gi = blockIdx.z; bx = blockIdx.x;
+    if ((gridDim.x & 7) != 0) return;
+    const int k = blockIdx.x & 7, per = gridDim.x >> 3, ng = gridDim.z;
+    if (ng > 1 && ng <= 8 && (8 % ng) == 0) {
+        const int X = 8 / ng, slots = per * ng, slot = (blockIdx.x >> 3) + per * blockIdx.z;
+        gi = k / X; bx = (k % X) * slots + slot;
+    } else {
+        bx = k * per + (blockIdx.x >> 3);
+    }
+}
+
 // Statistic accumulators may be replicated (fp64 atomics on one address serialise: 256 workgroups adding to the same 64
 // words cost ~5 us): a producer workgroup adds to replica blockIdx.x % nrep, readers add the replicas up.
 __device__ __forceinline__ double* stat_rep(double* base, int nrep, int stride) {

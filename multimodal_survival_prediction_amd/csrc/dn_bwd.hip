@@ -939,7 +939,8 @@ __global__ __launch_bounds__(256) void head_bwd_feat_kernel(const Grp<HeadBwdP> 
     if (ok)
         for (int b = bl; b < p.B; b += 4) {
             float dp = 0;
-            for (int n = 0; n < p.N; ++n) dp = fmaf(p.dout[b * p.lddout + n], p.w[(size_t)n * p.C + c], dp);
+#pragma unroll 16
+            for (int n = 0; n < p.N; ++n) dp = fmaf(p.dout[b * p.lddout + n], p.w[(size_t)n * p.C + c], dp);      // (16 weight loads in flight)
             dp *= invV;
             for (int v = 0; v < p.V; ++v) {
                 const size_t m = (size_t)b * p.V + v;

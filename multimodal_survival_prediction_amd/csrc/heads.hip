@@ -71,18 +71,20 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const Grp<LinearFwdP> g
     for (int m = 0; m < MM; ++m) acc[m] = 0.f;
     int kstart = lane;
     const bool plain = !p.pro.bn && !(p.pro.train && (p.pro.drop_mask || p.pro.drop_p > 0.f));
-    if (plain) {     // raw input (first layers: 5005-wide RNA-seq rows): 4 independent (w, x[0..M)) load groups in flight
+    if (plain) {     // raw input (first layers: 5005-wide RNA-seq rows): NU independent (w, x[0..M)) load groups in flight -- the wave's
+                     // 20 KB weight row is a chain of K / (64 NU) memory round trips (NU = 4: 20 trips, 27.6 us per launch; 8: 10)
+        constexpr int NU = MM <= 4 ? 8 : 4;
         const float* wr = p.w + (size_t)n * p.K;
-        for (; kstart + 192 < p.K; kstart += 256) {
-            float w4[4], x4[4][MM];
+        for (; kstart + 64 * (NU - 1) < p.K; kstart += 64 * NU) {
+            float w4[NU], x4[NU][MM];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NU; ++u) {
                 w4[u] = wr[kstart + 64 * u];
 #pragma unroll
                 for (int m = 0; m < MM; ++m) x4[u][m] = m < p.M ? p.x[(size_t)m * p.ldx + kstart + 64 * u] : 0.f;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < NU; ++u)
 #pragma unroll
                 for (int m = 0; m < MM; ++m) acc[m] = fmaf(w4[u], x4[u][m], acc[m]);
         }
@@ -148,7 +150,31 @@ __global__ __launch_bounds__(256) void linear_bwd_w_kernel(const Grp<LinearBwdP>
         dz[m] = g; db += g;
     }
     if (lane == 0 && p.dbias) p.dbias[n] += db;
-    for (int k = lane; k < p.K; k += 64) {
+    // the gradient row is read-modify-written: NU independent (dw, x[0..M)) load groups are requested before the first store (one
+    // group per trip was a chain of K / 64 dependent round trips: 56 us for the 5005-wide first layer)
+    constexpr int NU = MM <= 4 ? 8 : 2;
+    float* __restrict__ dwr = p.dw + (size_t)n * p.K;
+    const float* __restrict__ xr = p.x;
+    int k0 = lane;
+    for (; k0 + 64 * (NU - 1) < p.K; k0 += 64 * NU) {
+        float d0[NU], xx[NU][MM];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            d0[u] = dwr[k0 + 64 * u];
+#pragma unroll
+            for (int m = 0; m < MM; ++m) xx[u][m] = m < p.M ? xr[(size_t)m * p.ldx + k0 + 64 * u] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            ColProlog<MM> cp;
+            cp.template apply<false>(p.pro, xx[u], p.M, k0 + 64 * u, p.K);
+            float a = 0.f;
+#pragma unroll
+            for (int m = 0; m < MM; ++m) a = fmaf(dz[m], xx[u][m], a);
+            dwr[k0 + 64 * u] = d0[u] + a;
+        }
+    }
+    for (int k = k0; k < p.K; k += 64) {
         float x[MM];
 #pragma unroll
         for (int m = 0; m < MM; ++m) x[m] = m < p.M ? p.x[(size_t)m * p.ldx + k] : 0.f;
@@ -184,6 +210,7 @@ __global__ __launch_bounds__(256) void linear_bwd_x_kernel(const Grp<LinearBwdP>
         __syncthreads();
         if (k < p.K) {
             const int ne = p.N - nb < 128 ? p.N - nb : 128;
+#pragma unroll 8
             for (int n = 0; n < ne; ++n) {
                 const float w = p.w[(size_t)(nb + n) * p.K + k];
 #pragma unroll

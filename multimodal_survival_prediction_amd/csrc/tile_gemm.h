@@ -76,8 +76,9 @@ template <class Op> struct has_zremap<Op, decltype((void)&Op::zremap)> { static 
 #endif
 template <class Op>
 __global__ __launch_bounds__(256) MMS_TGK_ATTR void tile_gemm_kernel(const Grp<typename Op::Params> grp) {
-    int gi, z;                                             // model of the fold group, the op's own z index
+    int gi, z, bx = blockIdx.x;                            // model of the fold group, the op's own z index, the M tile
     if constexpr (has_zremap<Op>::value) Op::zremap((int)blockIdx.z, grp.zdim, (int)gridDim.z, gi, z);
+    else if (grp.zdim == 1) { xcd_place(gi, bx); z = 0; }  // M-tiled launch: XCD-contiguous tile ranges, each model of a 2 / 4 / 8 group on its own XCDs
     else { gi = blockIdx.z / grp.zdim; z = blockIdx.z - gi * grp.zdim; }
     const typename Op::Params& p = grp.p[gi];
     constexpr int WM = Op::WM, WN = Op::WN, WK = Op::WK;
@@ -97,9 +98,8 @@ __global__ __launch_bounds__(256) MMS_TGK_ATTR void tile_gemm_kernel(const Grp<t
     // XCD-aware tile order (cdna_hip_programming.md T1): workgroups are dealt round-robin over the 8 XCDs, so give the
     // blocks that share an XCD (equal blockIdx.x % 8) a CONTIGUOUS range of M tiles -- neighbouring tiles share halo rows /
     // operand panels, and each XCD's L2 then holds one compact slice of the activations instead of a scatter of all of them.
-    // Placement only affects speed, never results.
-    int bx = blockIdx.x;
-    if ((gridDim.x & 7) == 0) bx = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    // Placement only affects speed, never results.  (zdim == 1: done by xcd_place above, with the models of a fold group apart.)
+    if ((has_zremap<Op>::value || grp.zdim != 1) && (gridDim.x & 7) == 0) bx = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const int m0 = bx * TM, n0 = blockIdx.y * TN;
 
     Op op;

@@ -239,9 +239,8 @@ def run_mode(MODE):
             gmax = max(float(g.abs().max()) for g in gref)
             num = den = 0.0; hworst = 0.0
             names = [k for k, _ in ref.named_parameters()]
-            o = 0
-            for k, g in zip(names, gref):
-                h = eng.gflat[o:o + g.numel()].view_as(g).cpu().double(); o += g.numel()
+            for k, g, hv in zip(names, gref, eng.gviews):      # (the engine's gradient views: conv2 tensors are strided views of packed storage)
+                h = hv.cpu().double()
                 num += float(((h - g.double()) ** 2).sum()); den += float((g.double() ** 2).sum())
                 if "ct_encoder" not in k and float(g.abs().max()) > 1e-5 * gmax:
                     er = float((h - g.double()).abs().max() / g.abs().max())

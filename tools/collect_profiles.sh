@@ -1,7 +1,6 @@
 #!/bin/bash
 # Collects the round's judged profile artifacts on the GPU box into gpurun_out/prof_final/ (copy what you keep to profiles/).
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/prof_final; rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-SUB=${SUB:-3+2}
 # 1. kernel-trace summary of the default bench (config 3 headline; extra legs off so that the table is the K-fold epoch)
 rm -rf /tmp/pf1; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf1 -- python3 $R/bench.py --no-cpu-baseline --no-h2d --no-many-folds > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
 cp $(ls /tmp/pf1/*/*_kernel_stats.csv | head -1) $O/kernel_stats.csv
@@ -9,13 +8,13 @@ echo "step 1 done"
 # 2. the roofline leg alone: exactly the launches bench.py times live with HIP events
 rm -rf /tmp/pf2; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf2 -- python3 $R/bench.py --roofline-only > $O/roofline_leg.json 2> /dev/null
 cp $(ls /tmp/pf2/*/*_kernel_stats.csv | head -1) $O/roofline_leg_kernel_stats.csv
-python3 $R/tools/pmc_conv2.py trace $(ls /tmp/pf2/*/*_kernel_trace.csv | head -1) $SUB >> $O/roofline_leg.json
+python3 $R/tools/pmc_conv2.py trace $(ls /tmp/pf2/*/*_kernel_trace.csv | head -1) $O/roofline_leg.json >> $O/roofline_leg.json
 echo "step 2 done"
 # 3. PMC passes (kernel-trace only, one counter per pass) over the same command
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pm_$c; rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pm_$c -- python3 $R/bench.py --roofline-only > /dev/null 2>&1
 done
-python3 $R/tools/pmc_conv2.py pmc $(ls /tmp/pm_FETCH_SIZE/*/*_counter_collection.csv | head -1) $(ls /tmp/pm_WRITE_SIZE/*/*_counter_collection.csv | head -1) $SUB > $O/pmc_conv2_traffic.json
+python3 $R/tools/pmc_conv2.py pmc $(ls /tmp/pm_FETCH_SIZE/*/*_counter_collection.csv | head -1) $(ls /tmp/pm_WRITE_SIZE/*/*_counter_collection.csv | head -1) $O/roofline_leg.json > $O/pmc_conv2_traffic.json
 echo "step 3 done"
 # 4. plain default bench line (no profiler)
 cd $R && python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
