@@ -70,12 +70,23 @@ def _conv3_nsplit(M, ng, gd):      # dn_net.hip conv3_nsplit (scratch assumed la
     return (27 + tpw - 1) // tpw
 
 
-def _bwdw_msplit(M, G):            # dn_net.hip dn121_backward_impl: rows per weight-gradient workgroup
-    rows, rows_s = (1024, 256) if G >= 4 else (512, 128)
-    fills = lambda w: w * 10 >= -(-w // 768) * 768 * 9                     # dn_ops.h: mms_conv3w_mt_fills
-    if G >= 4 and M > 1024 and not fills(-(-M // 1024) * G * 9) and fills(-(-M // 512) * G * 9):
-        rows = 512
-    return (M + rows - 1) // rows if M > 1024 else max((M + rows_s - 1) // rows_s, 1)
+def _bwdw_msplit(M, members):      # the driver's own rule (csrc/dn_ops.h mms_conv3w_msplit), asked of the library
+    from multimodal_survival_prediction_amd import _lib
+    ms = _lib.load_library().mms_conv3_bwd_weight_msplit(int(M), int(members), None)
+    assert ms > 0
+    return ms
+
+
+def _bwdw_members(G, block, layers):
+    """(model, layer) members per weight-gradient launch (dn_net.hip: defer / ngw_blk): the launches are deferred to the end of their
+    dense block and batched over layers when 2 G <= 10 -- blocks 2-4 greedily (10 // G * G members), block 1's layers split evenly
+    over the fewest launches."""
+    if 2 * G > 10:
+        return G
+    if block > 0:
+        return (10 // G) * G
+    nl = -(-layers * G // 10)
+    return -(-layers // nl) * G
 
 
 def _bwdw_multitap(M, G):          # dn_bwd.hip conv3w_mt_ok: which of the two weight-gradient kernels a launch runs on
@@ -92,8 +103,9 @@ def measure_conv2_family(B, dims, device, G, reps=20, manifest=None):
     events on the launch stream (torch's current stream), launched exactly as the step launches it: one launch carries the G
     models of a sub-group, shape by shape (the four dense blocks) with the driver's own split factors, weighted by the launch
     counts.  Algorithmic FLOPs per launch of any of the three = members * 2 * M * 27 * 128 * 32: members = the G models for the forward,
-    the backward-data and block 1's weight gradient; the weight-gradient launches of blocks 2-4 are DEFERRED to the end of their block
-    and batched over layers by the driver (dn_net.hip flush_w: up to 10 // G * G (model, layer) members per launch) -- timed that way.  (The per-layer launches of a dense block that
+    and the backward-data; the weight-gradient launches are DEFERRED to the end of their block and batched over layers by the driver
+    (dn_net.hip flush_w: up to 10 // G * G (model, layer) members per launch in blocks 2-4, block 1's six layers split evenly over the
+    fewest launches) -- timed that way.  (The per-layer launches of a dense block that
     runs as one persistent launch per pass, csrc/dn_cl.hip / dn_b4.hip, do not exist in the step: they are left out of the forward /
     backward-data ops' averages; the weight-gradient launches remain.)
     -> {op: (avg seconds per launch, avg FLOPs per launch, launches per step)}"""
@@ -137,8 +149,7 @@ def measure_conv2_family(B, dims, device, G, reps=20, manifest=None):
                                    dbn.data_ptr(), bst[0, 0].data_ptr(), bst[0, 1].data_ptr(), ops.ptr(part), ns, R, 2 * 128, 1 if frag else 0)
             fw.append(f); bd.append(d)
         # weight gradient: one launch carries `nw` (model, layer) members -- G for block 1, the deferred + batched count for blocks 2-4
-        defer = i > 0 and 2 * G <= 10
-        nw = (10 // G) * G if defer else G
+        nw = _bwdw_members(G, i, layers)
         for k in range(nw):           # (every member has its own activations and gradients, as the layers of a block have in the step)
             if k < G:
                 y1, s_, q_, dslab = keep[k][0], keep[k][1], keep[k][2], keep[k][4]
@@ -182,10 +193,10 @@ def _roof_name(op, B, dims, group_sizes):
         return "mms_conv3_bwd_data_group = tile_gemm_kernel<Conv3BwdDataOp> (block 1) / conv3s_bwd_data_kernel (blocks 2-4)"
     D, H, W = dims
     ms = [B * (D // 4 >> i) * (H // 4 >> i) * (W // 4 >> i) for i in range(4)]
-    mt = sorted({G for G in group_sizes for M in ms if _bwdw_multitap(M, G)})
+    mt = sorted({_bwdw_members(G, i, BLOCKS[i][0]) for G in group_sizes for i, M in enumerate(ms) if _bwdw_multitap(M, _bwdw_members(G, i, BLOCKS[i][0]))})
     name = "mms_conv3_bwd_weight_group = tile_gemm_kernel<Conv3BwdWOp>"
     if mt:
-        name += " (conv3_bwdw_mt_kernel for block 1 of the %s-model launches)" % "/".join(map(str, mt))
+        name += " (conv3_bwdw_mt_kernel for the %s-member launches of block 1)" % "/".join(map(str, mt))
     return name
 
 

@@ -68,7 +68,8 @@ typedef struct MmsDnOpts {
     int conv3_mt32_min;    /* fewest 32-row tiles for it, 0 = 256 */
     int conv3w_mt;         /* multi-tap conv2 weight gradient: 0 = by launch size, 2 = force, -1 = never */
     int big_ng;            /* -1 = tile shapes of the 1x1x1 kernels from ONE model's work (arithmetic independent of the group size) */
-    int batch_w;           /* -1 = weight-gradient launches per layer instead of batched over layers at the end of a block */
+    int batch_w;           /* weight-gradient launches deferred to the end of their dense block and batched over layers: 0 = every block,
+                              1 = blocks 2-4 only (rounds 2-3), -1 = one launch pair per layer */
     int ms3_rows;          /* rows per conv2 weight-gradient workgroup, 0 = by launch size */
     int ms1_div;           /* divisor of the conv1 weight-gradient row chunks, 0 = by launch size */
     int c0_nwg;            /* workgroups of the pooled conv0 weight-gradient kernel, 0 = default */
@@ -574,6 +575,9 @@ int mms_conv3_fwd_group(const Conv3FwdP* p, int ng, const MmsDnOpts* opts, hipSt
 int mms_head_fwd_group(const HeadFwdP* p, int ng, hipStream_t s);
 int mms_conv3_bwd_data_group(const Conv3BwdDataP* p, int ng, const MmsDnOpts* opts, hipStream_t s);
 int mms_conv3_bwd_weight_group(const Conv3BwdWP* p, int ng, const MmsDnOpts* opts, hipStream_t s);
+/* Conv3BwdWP.msplit the whole-encoder drivers use for a launch of `members` (model, layer) members of M rows each (0: bad arguments) --
+   so that a caller timing the launch alone (bench.py's roofline leg) shapes it exactly as the step does */
+int mms_conv3_bwd_weight_msplit(int M, int members, const MmsDnOpts* opts);
 int mms_conv1_bwd_data_group(const Conv1BwdP* p, int ng, const MmsDnOpts* opts, hipStream_t s);
 int mms_conv1_bwd_weight_group(const Conv1BwdP* p, int ng, hipStream_t s);
 int mms_bn_bwd_apply_group(const BnBwdApplyP* p, int ng, hipStream_t s);

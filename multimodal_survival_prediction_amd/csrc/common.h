@@ -1,5 +1,6 @@
 // Shared device helpers for the mmsurv gfx950 kernels (CDNA4, wave64, fp32-input MFMA).
 #pragma once
+#include <utility>
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <mutex>
@@ -46,6 +47,13 @@ __device__ __forceinline__ void xcd_place(int& gi, int& bx) {
         bx = k * per + (blockIdx.x >> 3);
     }
 }
+
+// Compile-time loop: f(std::integral_constant<int, 0>{}) ... f(<N - 1>) in order.  (A `#pragma unroll` loop whose body holds rarely taken
+// branches is costed at full size per iteration and left rolled; arrays it indexes by the loop counter then live in scratch.)
+template <class F, int... T>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, T...>) { (f(std::integral_constant<int, T>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // Statistic accumulators may be replicated (fp64 atomics on one address serialise: 256 workgroups adding to the same 64
 // words cost ~5 us): a producer workgroup adds to replica blockIdx.x % nrep, readers add the replicas up.

@@ -541,6 +541,10 @@ extern "C" int mms_conv3_bwd_weight_group(const Conv3BwdWP* pp, int ng, const Mm
     return launch_tile_gemm<Conv3BwdWOp>(pp, ng, dim3(1, 1, 27 * p.msplit), s);
 }
 MMS_SINGLE_O(mms_conv3_bwd_weight, Conv3BwdWP)
+extern "C" int mms_conv3_bwd_weight_msplit(int M, int members, const MmsDnOpts* opts) {
+    if (M <= 0 || members < 1 || members > MMS_MAX_GROUP) return 0;
+    return mms_conv3w_msplit(M, members, mms_opts(opts));
+}
 
 // ------------------------------------------------------------------------------------------------------
 // 1x1 conv backward.  Shared pieces: dy(m, n) with the output-side BN backward folded in, a(m, k) recompute.

@@ -294,39 +294,75 @@ __global__ __launch_bounds__(256) void conv3_fwd_reduce_kernel(const Grp<Conv3Fw
 // channel quarters, window 32 + 2(W+1) rows = 26 KB at W = 8): the block-1 launches of 2-3 fold models (512 / 768 tiles, 2-3 per CU).
 #define C3M_PITCH 132
 #define C3M_MAXHALO 17
-template <int C3M_TM>
+// -DC3M_TIMING (tools/c3m_timing.py): shader-clock stamps of the kernel's phases, one record of 8 words per workgroup
+#ifdef C3M_TIMING
+__device__ unsigned long long* c3m_ts_buf = nullptr;
+extern "C" int mms_c3m_timing_buffer(void* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(c3m_ts_buf), &buf, sizeof(buf)) == hipSuccess ? MMS_OK : MMS_ERR_LAUNCH; }
+#define C3M_TS_DECL unsigned long long ts_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define C3M_STAMP(i) do { asm volatile("" ::: "memory"); ts_[i] = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); } while (0)
+#define C3M_STAMPW(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); ts_[i] = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); } while (0)
+#define C3M_TS_FLUSH() do { if (threadIdx.x == 0 && c3m_ts_buf) { unsigned long long* o_ = c3m_ts_buf + 8 * (size_t)(blockIdx.x + gridDim.x * blockIdx.z); \
+    for (int i_ = 0; i_ < 8; ++i_) o_[i_] = ts_[i_]; } } while (0)
+#else
+#define C3M_TS_DECL
+#define C3M_STAMP(i)
+#define C3M_STAMPW(i)
+#define C3M_TS_FLUSH()
+#endif
+// Program order of the tap loop is the schedule: the empty asm keeps the IR passes, the scheduling barrier the machine scheduler from
+// moving memory operations across (left alone the compiler sinks every LDS read next to its first use: the wave then idles for the LDS
+// latency twice per tap -- with one or two waves per SIMD, launches of 1-2 models, nothing else covers it; measured per tap and workgroup,
+// one model: 1.63 k cycles against 1.02 k of MFMA issue, tools/c3m_timing.py).
+// With three workgroups per CU (launches of >= 4 models) the other waves cover those latencies and the free schedule is the faster one
+// (5 models: 107.5 vs 112.0 us per launch; 1 / 2 / 3 models: 36.2 / 46.5 / 68.4 free vs 29.6 / 44.1 / 65.0 us pinned): PIN is a template flag.
+#define C3M_PIN() do { if constexpr (PIN) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#ifndef C3M_NTAPS
+#define C3M_NTAPS 27          // timing-only ablation: fewer taps (tools/build_variant.sh)
+#endif
+template <int C3M_TM, bool PIN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C3M_TM == 64 ? 1 : 3, C3M_TM == 64 ? 2 : 3))) void conv3_fwd_mt_kernel(const Grp<Conv3FwdP> grp) {
-    constexpr int RT = C3M_TM / 32, KS = 4 / RT, CW = 128 / KS, NQ = CW / 8;      // row tiles, channel splits, channels and float4 K-groups per wave
+    constexpr int RT = C3M_TM / 32, KS = 4 / RT, CW = 128 / KS, NQ = CW / 8, NH = NQ / 2;   // row tiles, channel splits, channels / float4 K-groups per wave, per half tap
     int gi, bx;
+    C3M_TS_DECL;
+    C3M_STAMP(0);
     xcd_place(gi, bx);           // XCD-contiguous row ranges; a fold group of 2 / 4 / 8 models: each model on its own XCDs
     const Conv3FwdP& p = grp.p[gi];
+    // every kernel argument the loops need, read ONCE into registers (left as references into the kernarg segment the compiler re-loads them,
+    // s_load + wait, inside each predicated load)
+    const float* __restrict__ y1 = p.y1;
+    const float* __restrict__ wp = p.wp;
+    const int M = p.M, W = p.g.W, HW = p.g.H * p.g.W;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* img = smem;                                               // [nrows][132]
+    float* img = smem;                                               // [nrows + 1][132]: the window and one row of zeros
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kq = lane >> 5;
     const int rt = wave / KS, kh2 = wave % KS;
     const int m0 = bx * C3M_TM;
-    const int W = p.g.W, HW = p.g.H * p.g.W, halo = W + 1, nrows = C3M_TM + 2 * halo;
+    const int halo = W + 1, nrows = C3M_TM + 2 * halo;
     const int c4 = (tid & 31) * 4;
     float mean[4], sc[4], beta[4];
     bn_consts4(p.bn, c4, mean, sc, beta);
     const int myrow = m0 + rt * 32 + li;
-    const unsigned m9 = myrow < p.M ? tap_mask9(p.coords[myrow], p.g, false) : 0u;
+    const unsigned m9 = myrow < M ? tap_mask9(p.coords[myrow < M ? myrow : 0], p.g, false) : 0u;
     f32x16 acc, acc2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
 
     // B operand: straight from global memory (L1/L2-resident packed weights) into the MFMA register layout, one tap ahead:
-    // lane (kq, co = li) needs W[co][tap][64*kh2 + 8q + 4kq .. +3], q = 0..7 -- 8 x 16 B per lane and tap.  No LDS tile,
-    // hence no per-tap barrier: the window is read-only during a kd phase and the waves drift freely (the two waves that
-    // share a channel half hit the same lines in L1).
-    const float* wlane = p.wp + (size_t)li * (27 * 128) + CW * kh2 + 4 * kq;
-    float4 bA[NQ], bB[NQ];
-    auto bload = [&](float4 (&b)[NQ], int tap) __attribute__((always_inline)) {
+    // lane (kq, co = li) needs W[co][tap][CW*kh2 + 8q + 4kq .. +3], q = 0..NQ-1.  No LDS tile, hence no per-tap barrier: the window is
+    // read-only during a kd phase and the waves drift freely.
+    // (Measured and dropped: a tap-major lane order [tap][cin / 8][kq][cout][4], in which the 64 lanes of a load read one contiguous KB
+    // instead of 32 bytes of 32 lines -- 43.0 vs 44.6 us per 2-model launch, 110.8 vs 113.3 at 5 models, 30.6 vs 30.1 at one: not worth a
+    // third derived weight pack.)
+    const float* wlane = wp + (size_t)li * (27 * 128) + CW * kh2 + 4 * kq;
+    constexpr int wts = 128, wqs = 8;
+    float4 b[2][NQ];
+    auto bload = [&](float4 (&bb)[NQ], int tap) __attribute__((always_inline)) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) b[q] = *(const float4*)(wlane + tap * 128 + 8 * q);
+        for (int q = 0; q < NQ; ++q) bb[q] = *(const float4*)(wlane + tap * wts + q * wqs);
     };
-    // window rows: loaded into registers ahead of the kd phase that needs them (wload), transformed + stored at its start (wstore)
-    constexpr int NI = ((C3M_TM + 2 * C3M_MAXHALO) * 32 + 255) / 256;      // 13
+    // window rows: loaded into registers ahead of the kd phase that needs them (wload: branch-free, invalid rows read row 0 and are zeroed
+    // when staged), transformed + stored at its start (wstore)
+    constexpr int NI = ((C3M_TM + 2 * C3M_MAXHALO) * 32 + 255) / 256;      // 9 / 13
     float4 wv[NI];
     unsigned wok = 0;
     auto wload = [&](int kd) __attribute__((always_inline)) {
@@ -334,17 +370,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C3M_TM == 6
         wok = 0;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int s = (tid >> 5) + 8 * i, src = base + s;
-            const bool ok = s < nrows && src >= 0 && src < p.M;
-            wok |= (ok ? 1u : 0u) << i;
-            wv[i] = ok ? *(const float4*)(p.y1 + (size_t)src * 128 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (8 * i < nrows) {                                       // workgroup-uniform
+                const int s = (tid >> 5) + 8 * i, src = base + s;
+                const bool ok = s < nrows && src >= 0 && src < M;
+                wok |= (ok ? 1u : 0u) << i;
+                wv[i] = *(const float4*)(y1 + (size_t)(ok ? src : 0) * 128 + c4);
+            }
         }
     };
     auto wstore = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int s = (tid >> 5) + 8 * i;
-            if (s < nrows) {
+            if (8 * i < nrows && s < nrows) {
                 const float z = (wok >> i) & 1u ? 1.f : 0.f;
                 *(float4*)&img[s * C3M_PITCH + c4] =
                     make_float4(z * fmaxf(bn_apply(wv[i].x, mean[0], sc[0], beta[0]), 0.f), z * fmaxf(bn_apply(wv[i].y, mean[1], sc[1], beta[1]), 0.f),
@@ -352,73 +390,84 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C3M_TM == 6
             }
         }
     };
-    auto mma = [&](int tap, const float4 (&b)[NQ]) __attribute__((always_inline)) {
+    // A operand of a tap: the window slot shifted by (kh - 1, kw - 1) -- or, for a row the tap's zero padding excludes, the row of zeros
+    // (one address select per tap instead of 4 NQ multiplies by a 0/1 factor)
+    const float* arow = img + (rt * 32 + li + halo) * C3M_PITCH + CW * kh2 + 4 * kq;
+    const float* azero = img + nrows * C3M_PITCH + CW * kh2 + 4 * kq;
+    float4 aL[NH], aH[NH];
+    auto aread = [&](float4 (&a)[NH], int tap, int half) __attribute__((always_inline)) {
         const int kd = tap / 9, t9 = tap - 9 * kd, kh = t9 / 3, kw = t9 - 3 * kh;
         const unsigned sel = (1u << kd) | (8u << kh) | (64u << kw);
-        const float mk = (m9 & sel) == sel ? 1.f : 0.f;
-        const float* ar = img + (rt * 32 + li + halo + (kh - 1) * W + (kw - 1)) * C3M_PITCH + CW * kh2 + 4 * kq;
-        float4 a[NQ];
-#ifdef C3M_NO_AREAD
+        const float* ar = (m9 & sel) == sel ? arow + ((kh - 1) * W + (kw - 1)) * C3M_PITCH : azero;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) a[q] = make_float4(mk, mk + q, mk * 2, 1.f);
-#else
+        for (int q = 0; q < NH; ++q) a[q] = *(const float4*)(ar + 8 * (half * NH + q));
+    };
+    auto mma = [&](const float4 (&a)[NH], const float4 (&bb)[NQ], int half) __attribute__((always_inline)) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) a[q] = *(const float4*)(ar + 8 * q);
-#endif
-#ifdef C3M_NO_MASK
-#define MK_(x) (x)
-#else
-#define MK_(x) ((x) * mk)
-#endif
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {        // two accumulators: consecutive MFMAs never wait for each other's result
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(MK_(a[q].x), b[q].x, acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(MK_(a[q].y), b[q].y, acc2, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(MK_(a[q].z), b[q].z, acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(MK_(a[q].w), b[q].w, acc2, 0, 0, 0);
+        for (int q = 0; q < NH; ++q) {        // two accumulators: consecutive MFMAs never wait for each other's result
+            const float4& bq = bb[half * NH + q];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, bq.x, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, bq.y, acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, bq.z, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, bq.w, acc2, 0, 0, 0);
         }
     };
-    auto step = [&](int tap, const float4 (&cur)[NQ], float4 (&nxt)[NQ]) __attribute__((always_inline)) {
-        const int t9 = tap % 9;
-#ifndef C3M_NO_BLOAD
-        if (tap + 1 < 27) bload(nxt, tap + 1);
-#endif
-        if (t9 == 5 && tap + 4 < 27) wload(tap / 9 + 1);             // next kd's rows: in flight during taps 5..8
-        mma(tap, cur);
-        if (t9 == 8 && tap + 1 < 27) { __syncthreads(); wstore(); __syncthreads(); }   // all waves are done with this window
-    };
-    bload(bA, 0);
+    bload(b[0], 0);
     wload(0);
+    if (tid < C3M_PITCH) img[nrows * C3M_PITCH + tid] = 0.f;
+    C3M_STAMP(1);                 // prologue loads issued (constants, mask, first window, first tap's weights)
     wstore();
     __syncthreads();
-#ifndef C3M_TAPS
-#define C3M_TAPS 26
+    C3M_STAMP(2);                 // first window staged
+    aread(aL, 0, 0);
+    // Half-tap software pipeline over the same 4 NQ A registers: the LDS reads of half h + 1 are issued BEFORE the MFMAs of half h.
+    static_for<C3M_NTAPS>([&](auto T) __attribute__((always_inline)) {
+        constexpr int tap = decltype(T)::value, t9 = tap % 9;
+#ifdef C3M_TIMING
+        if constexpr (tap == 10) C3M_STAMP(3);      // kd = 0 done, second window staged, tap 9 done
+        if constexpr (tap == 18) C3M_STAMP(4);      // kd = 1 done
 #endif
-#pragma unroll 1
-    for (int tap = 0; tap < C3M_TAPS; tap += 2) {
-        step(tap, bA, bB);
-        step(tap + 1, bB, bA);
-    }
-    step(26, bA, bB);
+        if constexpr (tap + 1 < C3M_NTAPS) bload(b[(tap + 1) & 1], tap + 1);     // next tap's weights: in flight during this tap
+        if constexpr (t9 == 5 && tap + 4 < C3M_NTAPS) wload(tap / 9 + 1);        // next kd's rows: in flight during taps 5..8
+        aread(aH, tap, 1);
+        C3M_PIN();
+        mma(aL, b[tap & 1], 0);
+        C3M_PIN();
+        if constexpr (t9 != 8 && tap + 1 < C3M_NTAPS) aread(aL, tap + 1, 0);
+        C3M_PIN();
+        mma(aH, b[tap & 1], 1);
+        C3M_PIN();
+        if constexpr (t9 == 8 && tap + 1 < C3M_NTAPS) {                          // all waves are done with this window
+            __syncthreads();
+            wstore();
+            __syncthreads();
+            aread(aL, tap + 1, 0);
+        }
+    });
+    C3M_STAMP(5);                 // 27 taps
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
     __syncthreads();                                                 // window -> Cs alias
-    // ---- epilogue: add the channel splits, write the 32 slab columns, batch statistics
-    float* Cs = smem;                                                // [64][33], aliases the window
-    const int crow = rt * 32 + 4 * kq;
+    // ---- epilogue: every channel split's partial tile into its own LDS region, summed in split order; 32 slab columns, batch statistics
+    float* Cs = smem;                                                // [KS][C3M_TM][33], aliases the window (<= C3M_TM x 132 floats)
+    {
+        float* mine = Cs + kh2 * (C3M_TM * 33) + (rt * 32 + 4 * kq) * 33 + li;
 #pragma unroll
-    for (int h = 0; h < KS; ++h) {
-        if (kh2 == h) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float* c = &Cs[(crow + (r & 3) + 8 * (r >> 2)) * 33 + li];
-                if (h == 0) *c = acc[r]; else *c += acc[r];
-            }
-        }
-        __syncthreads();
+        for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2)) * 33] = acc[r];
     }
-    store_tile<C3M_TM, 32>(p.out, p.ldo, p.M, 32, m0, 0, Cs, tid);
-    tile_col_stats<C3M_TM, 32>(stat_rep(p.osum, p.srep, p.sstride), stat_rep(p.osumsq, p.srep, p.sstride), p.M, 32, m0, 0, Cs, tid);
+    __syncthreads();
+    for (int idx = tid; idx < C3M_TM * 33; idx += 256) {
+        float v = Cs[idx];
+#pragma unroll
+        for (int h = 1; h < KS; ++h) v += Cs[idx + h * (C3M_TM * 33)];
+        Cs[idx] = v;
+    }
+    __syncthreads();
+    C3M_STAMP(6);                 // channel splits added
+    store_tile<C3M_TM, 32>(p.out, p.ldo, M, 32, m0, 0, Cs, tid);
+    tile_col_stats<C3M_TM, 32>(stat_rep(p.osum, p.srep, p.sstride), stat_rep(p.osumsq, p.srep, p.sstride), M, 32, m0, 0, Cs, tid);
+    C3M_STAMPW(7);                // tile written, statistic atomics acknowledged
+    C3M_TS_FLUSH();
 }
 // Tile height by how well the launch fills whole rounds of the chip: 32-row tiles run 3 workgroups per CU (768 per round), 64-row tiles
 // 2 per CU (512 per round).  Measured on block 1 (8192 rows per model), G models per launch, us per launch, per-tap GEMM form / 32 / 64:
@@ -435,16 +484,18 @@ static inline int conv3_mt_tile(int M, int ng, const Dims3& g, const MmsDnOpts& 
     const double f32 = (double)n32 / (double)((n32 + 767) / 768 * 768), f64 = (double)n64 / (double)((n64 + 511) / 512 * 512);
     return n64 >= 512 && f64 > f32 + 0.1 ? 64 : 32;
 }
-template <int TM>
+template <int TM, bool PIN>
 static int launch_conv3_fwd_mt(const Conv3FwdP* pp, int ng, hipStream_t s) {
     const Conv3FwdP& p = *pp;
-    constexpr int smem_max = (TM + 2 * C3M_MAXHALO) * C3M_PITCH * (int)sizeof(float);
-    const int smem = (TM + 2 * (p.g.W + 1)) * C3M_PITCH * (int)sizeof(float);       // W = 8: 43 KB (64 rows) / 26 KB (32 rows)
+    constexpr int smem_max = (TM + 2 * C3M_MAXHALO + 1) * C3M_PITCH * (int)sizeof(float);
+    constexpr int smem_epi = 4 / (TM / 32) * TM * 33 * (int)sizeof(float);                // the epilogue's partial tiles: 16.9 KB
+    const int smem_win = (TM + 2 * (p.g.W + 1) + 1) * C3M_PITCH * (int)sizeof(float);  // window + the row of zeros; W = 8: 43.8 KB (64 rows) / 26.9 KB (32 rows)
+    const int smem = smem_win > smem_epi ? smem_win : smem_epi;
     static std::once_flag attr_once;
-    std::call_once(attr_once, [&] { hipFuncSetAttribute((const void*)conv3_fwd_mt_kernel<TM>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_max); });
+    std::call_once(attr_once, [&] { hipFuncSetAttribute((const void*)(conv3_fwd_mt_kernel<TM, PIN>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_max); });
     Grp<Conv3FwdP> a;
     grp_fill(a, pp, ng, 1);
-    MMS_LAUNCH(conv3_fwd_mt_kernel<TM>, dim3((p.M + TM - 1) / TM, 1, ng), dim3(256), smem, s, a);
+    MMS_LAUNCH((conv3_fwd_mt_kernel<TM, PIN>), dim3((p.M + TM - 1) / TM, 1, ng), dim3(256), smem, s, a);
     return mms_check_launch();
 }
 
@@ -460,7 +511,11 @@ extern "C" int mms_conv3_fwd_group(const Conv3FwdP* pp, int ng, const MmsDnOpts*
     }
     for (int g = 0; g < ng; ++g) if (!mms_bn_aligned16(pp[g].bn) || pp[g].wfrag != p.wfrag) return MMS_ERR_ARG;   // BatchNorm blocks are read with 16-byte vector loads
     if (p.wfrag) return (!p.partial && mms_conv3_small_jn(p.M, ng, p.g, o)) ? mms_c3s_fwd(pp, ng, o, s) : MMS_ERR_ARG;       // fragment-ordered weights: the small-grid kernel only
-    if (const int tm = p.partial ? 0 : conv3_mt_tile(p.M, ng, p.g, o)) return tm == 64 ? launch_conv3_fwd_mt<64>(pp, ng, s) : launch_conv3_fwd_mt<32>(pp, ng, s);
+    if (const int tm = p.partial ? 0 : conv3_mt_tile(p.M, ng, p.g, o)) {
+        if (tm == 64) return launch_conv3_fwd_mt<64, false>(pp, ng, s);
+        // pinned schedule while the launch is at most one round of three 32-row workgroups per CU
+        return (long)((p.M + 31) / 32) * ng <= 768 ? launch_conv3_fwd_mt<32, true>(pp, ng, s) : launch_conv3_fwd_mt<32, false>(pp, ng, s);
+    }
     if (!p.partial && mms_conv3_small_jn(p.M, ng, p.g, o)) return mms_c3s_fwd(pp, ng, o, s);      // small grids: 16-row tiles, all taps, no reduce launch
     if (p.partial) {
         if (p.nsplit < 1 || p.nsplit > 27) return MMS_ERR_ARG;

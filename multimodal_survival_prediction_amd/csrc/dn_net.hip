@@ -32,7 +32,7 @@ struct Plan {
     int R0, R[NB];     // statistic-accumulator replicas of the stem level / of each block (common.h: stat_rep)
     // byte offsets into the workspace
     size_t coords0, coords[NB], y0, argmax, slab[NB], dslab[NB], y1[NLAYER], wpf[NLAYER], wpb[NLAYER];
-    size_t dbn_mid, dbn_mid_l[NLAYER], dbn_in, dbn0, pooled, tab_pack, tab_bn, partial, dwp[NLAYER];
+    size_t dbn_mid_l[NLAYER], dbn_in, dbn0, pooled, tab_pack, tab_bn, partial, dwp[NLAYER];
     // fp64 statistic accumulators (one contiguous region, zeroed once per step)
     size_t stats_begin, stats_begin_packed, stats_end;      // (packed primary conv2 storage: the gradient scratch dwp at the head of the region is unused)
     size_t st_y0, st_slab[NB], st_y1[NLAYER];          // forward (sum | sumsq), each 2*C doubles
@@ -81,12 +81,11 @@ bool make_plan(Plan& P, int B, int D, int H, int W) {
             P.wpf[l] = take((size_t)32 * 27 * 128 * 4);
             P.wpb[l] = take((size_t)32 * 27 * 128 * 4);
         }
-    P.dbn_mid = take((size_t)P.M[0] * 128 * 4);
-    {   // conv2's input gradient of a layer: block 1 reuses one buffer; blocks 2-4 keep one per layer, so that their conv1
-        // weight-gradient kernels (off the backward's critical chain) can run batched over layers at the end of the block
+    {   // conv2's input gradient of a layer: one buffer per layer, so that the layers' weight-gradient kernels (off the backward's
+        // critical chain) can run batched over layers at the end of their block (round 4: block 1 too -- 6 x 4 MB per model at batch 4)
         int l2 = 0;
         for (int b = 0; b < NB; ++b)
-            for (int i = 0; i < LAYERS[b]; ++i, ++l2) P.dbn_mid_l[l2] = b == 0 ? P.dbn_mid : take((size_t)P.M[b] * 128 * 4);
+            for (int i = 0; i < LAYERS[b]; ++i, ++l2) P.dbn_mid_l[l2] = take((size_t)P.M[b] * 128 * 4);
     }
     size_t mx = 0;
     for (int b = 0; b < NB; ++b) { size_t v = (size_t)P.M[b] * CTOT[b] * 4; if (v > mx) mx = v; }
@@ -551,11 +550,14 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
     // deferred and issued batched over layers -- as many (model, layer) members per launch as the group entry points carry --
     // once the block's chain is through: dz_l = dslab[:, C_l:C_l+32] is final from the moment layer l has been processed (earlier
     // layers only add into columns < C_l), y1 / the statistic accumulators are per layer, and dbn_mid is per layer there.
-    // MmsDnOpts.batch_w = -1 restores one launch pair per layer.
+    // Round 4: block 1 too.  Its launches do fill the chip, but at 1-2 models per launch badly (weight gradient 32 / 37 % of the MFMA
+    // peak at 1 / 2 models, 48-53 % at 5-10): its six layers are issued as launches of 6 (one model), 3 + 3 layers x 2 (two models), ...
+    // members.  MmsDnOpts.batch_w = -1 restores one launch pair per layer, 1 = blocks 2-4 only (rounds 2-3).
     const bool batch_w = o.batch_w >= 0 && !side;      // (fine under SyncBN too: the sums the weight kernels read are all-reduced by then)
     Conv3BwdWP bwq[MMS_MAX_GROUP];
     Conv1BwdP c1q[MMS_MAX_GROUP];
     int nq = 0;
+    int nq_limit = MMS_MAX_GROUP;
     auto flush_w = [&](int b) -> int {
         if (nq == 0) return MMS_OK;
         TRYS(12 + b, mms_conv3_bwd_weight_group(bwq, nq, &o, s));
@@ -568,7 +570,15 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
     for (int b = dp.b_hi; b >= dp.b_lo; --b) {
         int C = CTOT[b];
         const int M = P.M[b];
-        const bool defer = batch_w && b > 0 && 2 * ng <= MMS_MAX_GROUP;
+        const bool defer = batch_w && (b > 0 || o.batch_w == 0) && 2 * ng <= MMS_MAX_GROUP;
+        // (model, layer) members per weight-gradient launch: blocks 2-4 fill the launches greedily; block 1 -- where a launch is large
+        // and its kernel form depends on its size -- splits its layers evenly over the fewest launches
+        int ngw_blk = ng;
+        if (defer) {
+            if (b > 0) ngw_blk = MMS_MAX_GROUP / ng * ng;
+            else { const int nl = (LAYERS[b] * ng + MMS_MAX_GROUP - 1) / MMS_MAX_GROUP; ngw_blk = (LAYERS[b] + nl - 1) / nl * ng; }
+        }
+        nq_limit = ngw_blk;
         // block 4 (<= 32 rows, one MFMA row tile): norm1's backward rides in conv1_bwd_data's epilogue (Conv1BwdP.fuse_dx), no
         // mms_bn_bwd_apply launch.  (Measured at 128 rows -- block 3, 128 x 32 tiles -- the fused form is slower than the two
         // launches it replaces: 25 us against 8.8 + 6.7 us, rocprofv3 kernel stats; MmsDnOpts.fuse_apply_rows = 128 selects it anyway.)
@@ -601,15 +611,8 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
             Conv1BwdP c1[MMS_MAX_GROUP];
             BnBwdApplyP ap[MMS_MAX_GROUP];
             const int ns3 = conv3_nsplit(M, ng, P.partial_rows, P.g[b], o);
-            // rows per weight-gradient workgroup: every chunk flushes 27 x 16 KB of fp32 atomics, so groups (which bring their own
-            // parallelism) take chunks twice as long -- half the fabric writes (PMC WRITE_SIZE) for the same FLOPs
-            const int ngw = defer ? MMS_MAX_GROUP / ng * ng : ng;        // (model, layer) members per weight-gradient launch
-            const bool e3 = o.ms3_rows > 0;
-            int rows3 = e3 ? o.ms3_rows : (ngw >= 4 ? 1024 : 512);
-            const int rows3s = e3 ? 128 : (ngw >= 4 ? 256 : 128);
-            // 512-row chunks when that (and not the default) puts the launch on the multi-tap kernel with a well-filled grid (5-model groups)
-            if (!e3 && ngw >= 4 && M > 1024 && !mms_conv3w_mt_fills((long)((M + 1023) / 1024) * ngw * 9) && mms_conv3w_mt_fills((long)((M + 511) / 512) * ngw * 9)) rows3 = 512;
-            int ms3 = M > 1024 ? (M + rows3 - 1) / rows3 : (M + rows3s - 1) / rows3s; if (ms3 < 1) ms3 = 1;
+            const int ngw = ngw_blk;                                      // (model, layer) members per weight-gradient launch
+            const int ms3 = mms_conv3w_msplit(M, ngw, o);
             int ms1 = M > 1024 ? M / 256 : M / 128; if (ms1 < 1) ms1 = 1; if (ms1 > 32) ms1 = 32;
             { const int dv = o.ms1_div > 0 ? o.ms1_div : (ngw >= 4 ? 2 : 1); if (dv > 1) { ms1 = ms1 / dv; if (ms1 < 1) ms1 = 1; } }   // groups: half the chunks (fewer atomic flushes)
             FOR_G {
@@ -652,7 +655,7 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
                 SYNC(at<double>(cx[0].ws, P.bb_y1[l]), P.R[b], 2 * 128, 128, 128);
             }
             if (defer) {
-                if (nq + ng > MMS_MAX_GROUP) TRY(flush_w(b));
+                if (nq + ng > nq_limit) TRY(flush_w(b));
                 FOR_G { bwq[nq] = bw[g]; c1q[nq] = c1[g]; ++nq; }
             } else {
                 if (side) {

@@ -10,6 +10,29 @@ static inline bool mms_conv3w_mt_fills(long workgroups) {
     return workgroups > 0 && workgroups * 10 >= rounds * slots * 9;
 }
 
+// Row chunks of a conv2 weight-gradient launch with `members` (model, layer) members of M rows each (the msplit the driver passes;
+// MmsDnOpts.ms3_rows > 0 fixes the rows per chunk).  Every chunk flushes 27 x 16 KB of fp32 atomics, so launches with >= 4 members
+// (which bring their own parallelism) take chunks twice as long -- half the fabric writes (PMC WRITE_SIZE) for the same FLOPs.  Large-M
+// launches of >= 4 members look for a chunk count that puts them on the multi-tap kernel with a well-filled grid: among the counts with
+// chunks of 512..1024 rows whose 9-per-chunk grid passes mms_conv3w_mt_fills, the one with the least rounds x rows per chunk (ties: fewest
+// chunks): 10 members x 8192 rows -> 8 chunks (720 workgroups), 5 -> 16 (720), 6 -> 14 (756), 9 -> 9 (729), 8 -> 10 (720).
+static inline int mms_conv3w_msplit(int M, int members, const MmsDnOpts& o) {
+    const bool e3 = o.ms3_rows > 0;
+    const int rows3 = e3 ? o.ms3_rows : (members >= 4 ? 1024 : 512), rows3s = e3 ? 128 : (members >= 4 ? 256 : 128);
+    if (M <= 1024) { const int ms = (M + rows3s - 1) / rows3s; return ms < 1 ? 1 : ms; }
+    int best = 0; long best_cost = 0;
+    if (!e3 && members >= 4 && o.conv3w_mt >= 0) {
+        for (int ms = (M + 1023) / 1024; ms <= M / 512; ++ms) {
+            const int chunk = ((M + ms - 1) / ms + 31) & ~31;
+            const long wgs = (long)ms * members * 9;
+            if (chunk < 512 || chunk > 1024 || !mms_conv3w_mt_fills(wgs)) continue;
+            const long cost = (wgs + 767) / 768 * chunk;
+            if (!best || cost < best_cost) { best = ms; best_cost = cost; }
+        }
+    }
+    return best ? best : (M + rows3 - 1) / rows3;
+}
+
 // Small-grid 3x3x3 convolution kernels (dn_c3s.hip): a workgroup owns 16 voxel rows and all 27 taps, the rows' whole neighbourhood
 // [m0 - halo, m0 + 16 + halo), halo = H*W + W + 1, staged in LDS once -- no tap split, no reduce launch.  Applies when that window fits
 // (dense blocks 2-4 of 64x64x32 volumes, blocks 3-4 of 128x128x64 volumes).  Returns 0 (not applicable / MMS_CONV3_SMALL=0) or the

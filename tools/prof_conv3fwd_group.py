@@ -1,4 +1,6 @@
-"""Microbench of conv3 forward at a DenseNet block shape for a fold group of G models (event-timed)."""
+"""Microbench of conv3 forward at a DenseNet block shape for a fold group of G models (event-timed).
+usage: prof_conv3fwd_group.py <block> <G> [<sets>]   sets > 1: the launches rotate over that many distinct (activations, weights) sets, so that
+every launch meets its operands as cold in L2 as the step's launches do (default 1: every launch re-reads the same, L2-warm operands)."""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multimodal_survival_prediction_amd import ops, _lib
@@ -6,13 +8,16 @@ dev = "cuda:0"
 blk = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 reps = 20
+nsets = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 B, (D, H, W) = 4, (64, 64, 32)
 gd = (D // 4 >> blk, H // 4 >> blk, W // 4 >> blk)
 M = B * gd[0] * gd[1] * gd[2]
 lib, S = _lib.load_library(), _lib.structs()
 coords = ops.init_coords(B, gd, dev)
-keep, blocks = [], []
-for g in range(G):
+keep, arrs = [], []
+for g in range(G * nsets):
+    if g % G == 0:
+        blocks = []
     y1 = torch.randn(M, 128, device=dev)
     wp = torch.randn(32 * 27 * 128, device=dev) * 0.02
     s, q = y1.double().sum(0), (y1.double() ** 2).sum(0)
@@ -23,14 +28,15 @@ for g in range(G):
     keep.append((y1, wp, s, q, slab, os_, oq))
     blocks.append(S["Conv3FwdP"](y1.data_ptr(), coords.data_ptr(), ops.dims3(gd), M, wp.data_ptr(), out.data_ptr(), out.stride(0), bn,
                                  os_.data_ptr(), oq.data_ptr(), None, 27))
-arr = (S["Conv3FwdP"] * G)(*blocks)
-def launch():
-    _lib.check(lib.mms_conv3_fwd_group(arr, G, None, ops.stream()), "conv3_fwd_group")
-for _ in range(3): launch()
+    if g % G == G - 1:
+        arrs.append((S["Conv3FwdP"] * G)(*blocks))
+def launch(i):
+    _lib.check(lib.mms_conv3_fwd_group(arrs[i % nsets], G, None, ops.stream()), "conv3_fwd_group")
+for i in range(3): launch(i)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(reps): launch()
+for i in range(reps): launch(i)
 e1.record(); torch.cuda.synchronize()
 t = e0.elapsed_time(e1) * 1e3 / reps
-print(f"block {blk + 1} M={M} G={G}: conv3 fwd avg {t:.1f} us ({G * 2.0 * M * 27 * 128 * 32 / t / 1e6:.1f} TFLOP/s)")
+print(f"block {blk + 1} M={M} G={G} sets={nsets}: conv3 fwd avg {t:.1f} us ({G * 2.0 * M * 27 * 128 * 32 / t / 1e6:.1f} TFLOP/s)")
