@@ -190,7 +190,7 @@ def _roof_name(op, B, dims, group_sizes):
     if op == "fwd":
         return "mms_conv3_fwd_group = conv3_fwd_mt_kernel (block 1) / conv3s_fwd_kernel (blocks 2-4)"
     if op == "bwd_data":
-        return "mms_conv3_bwd_data_group = tile_gemm_kernel<Conv3BwdDataOp> (block 1) / conv3s_bwd_data_kernel (blocks 2-4)"
+        return "mms_conv3_bwd_data_group = conv3_bwd_data_mt_kernel (block 1) / conv3s_bwd_data_kernel (blocks 2-4)"
     D, H, W = dims
     ms = [B * (D // 4 >> i) * (H // 4 >> i) * (W // 4 >> i) for i in range(4)]
     mt = sorted({_bwdw_members(G, i, BLOCKS[i][0]) for G in group_sizes for i, M in enumerate(ms) if _bwdw_multitap(M, _bwdw_members(G, i, BLOCKS[i][0]))})

@@ -191,6 +191,148 @@ __global__ __launch_bounds__(256) void conv3_bwd_data_reduce16_kernel(const Grp<
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// conv2 backward-data, multi-tap form (block 1: launches with >= 256 tiles of 32 rows; the mirror of conv3_fwd_mt_kernel, dn_fwd.hip).
+// dy1[m][cin] = sum_tap sum_co dz[m - off(tap)][co] * W[co][tap][cin].  A workgroup owns 32 rows x 128 input channels, wave w the channels
+// 32w..32w+31 (no split of the reduction: K = 32 output channels per tap, 16 MFMAs per tap and wave).  dz is only 32 channels wide, so the
+// windows of ALL three kd planes -- rows [m0 - (kd-1) HW - (W+1), .. + 32 + 2(W+1)) x 32 floats, 21.7 KB at W = 8 -- are staged once: no
+// barrier inside the tap loop.  A operand: the window slot shifted by -((kh-1) W + (kw-1)), or a row of zeros where the tap's (mirrored)
+// zero padding excludes the row; B operand: straight from the [cin][tap][cout] pack into the MFMA register layout, two taps ahead (ring of
+// three).  Half-tap software pipeline and pinned schedule as in the forward kernel.  Epilogue from the accumulator registers (a lane holds
+// 16 rows of ONE channel): relu2 mask from y1, dbn2 store, BatchNorm-backward sums -- no LDS staging, no barrier.
+// ------------------------------------------------------------------------------------------------------
+#define C3D_BP 36
+#define C3D_MAXHALO 17
+#define C3D_PIN() do { if constexpr (PIN) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } } while (0)
+template <bool PIN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv3_bwd_data_mt_kernel(const Grp<Conv3BwdDataP> grp) {
+    int gi, bx;
+    xcd_place(gi, bx);
+    const Conv3BwdDataP& p = grp.p[gi];
+    const float* __restrict__ dz = p.dz;
+    const float* __restrict__ wpb = p.wpb;
+    const float* __restrict__ y1 = p.y1;
+    float* __restrict__ dbn = p.dbn;
+    const int M = p.M, lddz = p.lddz, W = p.g.W, HW = p.g.H * p.g.W;
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // [3][nrows][36] + one row of zeros
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kq = lane >> 5;
+    const int m0 = bx * 32, halo = W + 1, nrows = 32 + 2 * halo;
+    const int cin = 32 * wave + li;
+    // ---- prologue: every load issued before the first use (constants of this lane's channel, the row's tap mask, the three windows)
+    float mu, rstd, ga, be;
+    bn_consts1(p.bn, cin, mu, rstd, ga, be);
+    const int myrow = m0 + li;
+    const int mycoord = p.coords[myrow < M ? myrow : 0];
+    constexpr int NR = (32 + 2 * C3D_MAXHALO + 31) / 32;               // row passes per window: 3
+    float4 wv[3][NR];
+    const int wr = tid >> 3, wc = (tid & 7) * 4;
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int r = wr + 32 * i, src = m0 - (kd - 1) * HW - halo + r;
+            const bool ok = r < nrows && src >= 0 && src < M;
+            const float4 v = *(const float4*)(dz + (size_t)(ok ? src : 0) * lddz + wc);
+            wv[kd][i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    const float* wl = wpb + (size_t)cin * 864 + 4 * kq;
+    float4 b[3][4];
+    auto bload = [&](float4 (&bb)[4], int tap) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bb[q] = *(const float4*)(wl + tap * 32 + 8 * q);
+    };
+    bload(b[0], 0);
+    bload(b[1], 1);
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int r = wr + 32 * i;
+            if (r < nrows) *(float4*)&smem[(kd * nrows + r) * C3D_BP + wc] = wv[kd][i];
+        }
+    if (tid < C3D_BP) smem[3 * nrows * C3D_BP + tid] = 0.f;
+    const unsigned m9 = myrow < M ? tap_mask9(mycoord, p.g, true) : 0u;
+    __syncthreads();
+    const float* arow = smem + (li + halo) * C3D_BP + 4 * kq;
+    const float* azero = smem + 3 * nrows * C3D_BP + 4 * kq;
+    f32x16 acc, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+    float4 aL[2], aH[2];
+    auto aread = [&](float4 (&a)[2], int tap, int half) __attribute__((always_inline)) {
+        const int kd = tap / 9, t9 = tap - 9 * kd, kh = t9 / 3, kw = t9 - 3 * kh;
+        const unsigned sel = (1u << kd) | (8u << kh) | (64u << kw);
+        const float* ar = (m9 & sel) == sel ? arow + (kd * nrows - ((kh - 1) * W + (kw - 1))) * C3D_BP : azero;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) a[q] = *(const float4*)(ar + 8 * (half * 2 + q));
+    };
+    auto mma = [&](const float4 (&a)[2], const float4 (&bb)[4], int half) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {          // two accumulators: consecutive MFMAs never wait for each other's result
+            const float4& bq = bb[half * 2 + q];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, bq.x, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, bq.y, acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, bq.z, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, bq.w, acc2, 0, 0, 0);
+        }
+    };
+    aread(aL, 0, 0);
+    static_for<27>([&](auto T) __attribute__((always_inline)) {
+        constexpr int tap = decltype(T)::value;
+        if constexpr (tap + 2 < 27) bload(b[(tap + 2) % 3], tap + 2);
+        aread(aH, tap, 1);
+        C3D_PIN();
+        mma(aL, b[tap % 3], 0);
+        C3D_PIN();
+        if constexpr (tap + 1 < 27) aread(aL, tap + 1, 0);
+        C3D_PIN();
+        mma(aH, b[tap % 3], 1);
+        C3D_PIN();
+    });
+    // ---- epilogue: lane (channel cin, row half kq) holds rows 4 kq + (r & 3) + 8 (r >> 2), r = 0..15
+    float yv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + 4 * kq + (r & 3) + 8 * (r >> 2);
+        yv[r] = y1[(size_t)(m < M ? m : 0) * 128 + cin];
+    }
+    double s1 = 0, s2 = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + 4 * kq + (r & 3) + 8 * (r >> 2);
+        if (m < M) {
+            const float xh = (yv[r] - mu) * rstd;
+            const float pre = fmaf(ga, xh, be);
+            const float g = pre > 0.f ? acc[r] + acc2[r] : 0.f;
+            dbn[(size_t)m * 128 + cin] = g;
+            s1 += g; s2 += (double)g * xh;
+        }
+    }
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 32);
+    if (kq == 0) {
+        atomicAdd(&stat_rep(p.s1, p.srep, p.sstride)[cin], s1);
+        atomicAdd(&stat_rep(p.s2, p.srep, p.sstride)[cin], s2);
+    }
+}
+// Taken where the forward takes its multi-tap form (conv3_mt_tile, dn_fwd.hip): un-split launches of >= MmsDnOpts.conv3_mt32_min (256) tiles of 32
+// rows on levels with >= 1024 rows and W <= 16; MmsDnOpts.conv3_mt: -1 = never, 2 / 3 = whenever it applies (tests).
+static inline bool conv3_bwd_data_mt_ok(int M, int ng, const Dims3& g, const MmsDnOpts& o) {
+    if (g.W + 1 > C3D_MAXHALO || o.conv3_mt < 0) return false;
+    if (o.conv3_mt == 2 || o.conv3_mt == 3) return M >= 64;
+    const int min32 = o.conv3_mt32_min > 0 ? o.conv3_mt32_min : 256;
+    return M >= 1024 && (long)((M + 31) / 32) * ng >= min32;
+}
+template <bool PIN>
+static int launch_conv3_bwd_data_mt(const Conv3BwdDataP* pp, int ng, hipStream_t s) {
+    const Conv3BwdDataP& p = *pp;
+    const int smem = (3 * (32 + 2 * (p.g.W + 1)) + 1) * C3D_BP * (int)sizeof(float);      // W = 8: 21.7 KB, W = 16: 28.7 KB
+    Grp<Conv3BwdDataP> a;
+    grp_fill(a, pp, ng, 1);
+    MMS_LAUNCH((conv3_bwd_data_mt_kernel<PIN>), dim3((p.M + 31) / 32, 1, ng), dim3(256), smem, s, a);
+    return mms_check_launch();
+}
+
 extern "C" int mms_conv3_bwd_data_group(const Conv3BwdDataP* pp, int ng, const MmsDnOpts* opts, hipStream_t s) {
     if (!pp || ng < 1 || ng > MMS_MAX_GROUP) return MMS_ERR_ARG;
     const MmsDnOpts o = mms_opts(opts);
@@ -212,6 +354,11 @@ extern "C" int mms_conv3_bwd_data_group(const Conv3BwdDataP* pp, int ng, const M
         if (p.nsplit <= 4 && p.M >= 512) MMS_LAUNCH(conv3_bwd_data_reduce16_kernel<8>, dim3((p.M + 15) / 16, 1, ng), dim3(256), 0, s, a);
         else MMS_LAUNCH(conv3_bwd_data_reduce_kernel, dim3((p.M + 3) / 4, 1, ng), dim3(256), 0, s, a);
         return mms_check_launch();
+    }
+    if (conv3_bwd_data_mt_ok(p.M, ng, p.g, o)) {
+        for (int g = 0; g < ng; ++g) if (pp[g].lddz % 4 != 0 || ((uintptr_t)pp[g].dz & 15) != 0) return MMS_ERR_ARG;     // dz rows are read with 16-byte loads
+        // pinned schedule while the launch is at most one round of three workgroups per CU
+        return (long)((p.M + 31) / 32) * ng <= 768 ? launch_conv3_bwd_data_mt<true>(pp, ng, s) : launch_conv3_bwd_data_mt<false>(pp, ng, s);
     }
     if (mms_conv3_small_jn(p.M, ng, p.g, o)) return mms_c3s_bwd_data(pp, ng, o, s);      // small grids: 16-row tiles, all taps, no reduce launch
     return launch_tile_gemm<Conv3BwdDataOp<false>>(pp, ng, dim3((p.M + 31) / 32, 1, 1), s);

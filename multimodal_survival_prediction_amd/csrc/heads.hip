@@ -60,60 +60,82 @@ struct ColProlog {
     }
 };
 
-template <int MM>
+// One wave per output feature n (KS4 = false: four features per workgroup), or -- wide layers, K >= 2048: the 5005-wide RNA-seq input
+// layers -- one WORKGROUP per feature whose four waves split the row (KS4: a wave's 20 KB weight row was a chain of K / (64 NU) memory round
+// trips on 128 workgroups; 25.3 us per launch).  Columns are taken NU at a time: every (w, x[0..M)) load of the NU groups is requested
+// before the first prologue / FMA.
+template <int MM, bool KS4>
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const Grp<LinearFwdP> grp) {
     const LinearFwdP& p = grp.p[blockIdx.z];
-    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= p.N) return;
+    __shared__ float red[4][MM];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = KS4 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+    if (n >= p.N) return;                                            // (KS4: workgroup-uniform)
+    constexpr int KSTEP = KS4 ? 256 : 64;
     const bool upd = (n == 0) && p.pro.bn && p.pro.train;
     float acc[MM];
 #pragma unroll
     for (int m = 0; m < MM; ++m) acc[m] = 0.f;
-    int kstart = lane;
+    int kstart = lane + (KS4 ? 64 * wave : 0);
+    const float* __restrict__ wr = p.w + (size_t)n * p.K;
+    const float* __restrict__ xr = p.x;
     const bool plain = !p.pro.bn && !(p.pro.train && (p.pro.drop_mask || p.pro.drop_p > 0.f));
-    if (plain) {     // raw input (first layers: 5005-wide RNA-seq rows): NU independent (w, x[0..M)) load groups in flight -- the wave's
-                     // 20 KB weight row is a chain of K / (64 NU) memory round trips (NU = 4: 20 trips, 27.6 us per launch; 8: 10)
-        constexpr int NU = MM <= 4 ? 8 : 4;
-        const float* wr = p.w + (size_t)n * p.K;
-        for (; kstart + 64 * (NU - 1) < p.K; kstart += 64 * NU) {
-            float w4[NU], x4[NU][MM];
+    constexpr int NU = MM <= 4 ? 8 : (MM <= 8 ? 4 : 2);
+    for (; kstart + KSTEP * (NU - 1) < p.K; kstart += KSTEP * NU) {
+        float w4[NU], x4[NU][MM];
 #pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                w4[u] = wr[kstart + 64 * u];
+        for (int u = 0; u < NU; ++u) {
+            w4[u] = wr[kstart + KSTEP * u];
 #pragma unroll
-                for (int m = 0; m < MM; ++m) x4[u][m] = m < p.M ? p.x[(size_t)m * p.ldx + kstart + 64 * u] : 0.f;
+            for (int m = 0; m < MM; ++m) x4[u][m] = m < p.M ? xr[(size_t)m * p.ldx + kstart + KSTEP * u] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            if (!plain) {
+                ColProlog<MM> cp;
+                if (upd) cp.template apply<true>(p.pro, x4[u], p.M, kstart + KSTEP * u, p.K); else cp.template apply<false>(p.pro, x4[u], p.M, kstart + KSTEP * u, p.K);
             }
 #pragma unroll
-            for (int u = 0; u < NU; ++u)
-#pragma unroll
-                for (int m = 0; m < MM; ++m) acc[m] = fmaf(w4[u], x4[u][m], acc[m]);
+            for (int m = 0; m < MM; ++m) acc[m] = fmaf(w4[u], x4[u][m], acc[m]);
         }
     }
-    for (int k = kstart; k < p.K; k += 64) {
+    for (int k = kstart; k < p.K; k += KSTEP) {
         float x[MM];
 #pragma unroll
-        for (int m = 0; m < MM; ++m) x[m] = m < p.M ? p.x[(size_t)m * p.ldx + k] : 0.f;
+        for (int m = 0; m < MM; ++m) x[m] = m < p.M ? xr[(size_t)m * p.ldx + k] : 0.f;
         ColProlog<MM> cp;
         if (upd) cp.template apply<true>(p.pro, x, p.M, k, p.K); else cp.template apply<false>(p.pro, x, p.M, k, p.K);
-        const float w = p.w[(size_t)n * p.K + k];
+        const float w = wr[k];
 #pragma unroll
         for (int m = 0; m < MM; ++m) acc[m] = fmaf(w, x[m], acc[m]);
     }
-    if (upd && lane == 0 && p.pro.nbt) *p.pro.nbt += 1;
+    if (upd && lane == 0 && (!KS4 || wave == 0) && p.pro.nbt) *p.pro.nbt += 1;
     const float b = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
-    for (int m = 0; m < MM; ++m) {
-        float v = wave_sum(acc[m]);
-        if (lane == 0 && m < p.M) {
-            v += b;
-            p.y[(size_t)m * p.ldy + n] = p.out_relu ? fmaxf(v, 0.f) : v;
+    for (int m = 0; m < MM; ++m) acc[m] = wave_sum(acc[m]);
+    if constexpr (KS4) {
+        if (lane == 0) {
+#pragma unroll
+            for (int m = 0; m < MM; ++m) red[wave][m] = acc[m];
         }
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int m = 0; m < MM; ++m) acc[m] = red[0][m] + red[1][m] + red[2][m] + red[3][m];
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int m = 0; m < MM; ++m)
+            if (m < p.M) {
+                const float v = acc[m] + b;
+                p.y[(size_t)m * p.ldy + n] = p.out_relu ? fmaxf(v, 0.f) : v;
+            }
     }
 }
 
 template <int MM>
 static int launch_linear_fwd(const Grp<LinearFwdP>& a, int ng, hipStream_t s) {
-    MMS_LAUNCH(linear_fwd_kernel<MM>, dim3((a.p[0].N + 3) / 4, 1, ng), dim3(256), 0, s, a);
+    if (a.p[0].K >= 2048) MMS_LAUNCH((linear_fwd_kernel<MM, true>), dim3(a.p[0].N, 1, ng), dim3(256), 0, s, a);
+    else MMS_LAUNCH((linear_fwd_kernel<MM, false>), dim3((a.p[0].N + 3) / 4, 1, ng), dim3(256), 0, s, a);
     return mms_check_launch();
 }
 extern "C" int mms_linear_fwd_group(const LinearFwdP* pp, int ng, hipStream_t s) {
@@ -134,11 +156,12 @@ extern "C" int mms_linear_fwd_group(const LinearFwdP* pp, int ng, hipStream_t s)
 MMS_SINGLE(mms_linear_fwd, LinearFwdP)
 
 // ---- backward: weight/bias (one wave per output feature n) ---------------------------------------------------
-template <int MM>
+template <int MM, bool KS4>
 __global__ __launch_bounds__(256) void linear_bwd_w_kernel(const Grp<LinearBwdP> grp) {
     const LinearBwdP& p = grp.p[blockIdx.z];
-    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = KS4 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;      // KS4: as linear_fwd_kernel
     if (n >= p.N) return;
+    constexpr int KSTEP = KS4 ? 256 : 64;
     float dz[MM], db = 0.f;
 #pragma unroll
     for (int m = 0; m < MM; ++m) {
@@ -149,32 +172,32 @@ __global__ __launch_bounds__(256) void linear_bwd_w_kernel(const Grp<LinearBwdP>
         }
         dz[m] = g; db += g;
     }
-    if (lane == 0 && p.dbias) p.dbias[n] += db;
+    if (lane == 0 && (!KS4 || wave == 0) && p.dbias) p.dbias[n] += db;
     // the gradient row is read-modify-written: NU independent (dw, x[0..M)) load groups are requested before the first store (one
     // group per trip was a chain of K / 64 dependent round trips: 56 us for the 5005-wide first layer)
     constexpr int NU = MM <= 4 ? 8 : 2;
     float* __restrict__ dwr = p.dw + (size_t)n * p.K;
     const float* __restrict__ xr = p.x;
-    int k0 = lane;
-    for (; k0 + 64 * (NU - 1) < p.K; k0 += 64 * NU) {
+    int k0 = lane + (KS4 ? 64 * wave : 0);
+    for (; k0 + KSTEP * (NU - 1) < p.K; k0 += KSTEP * NU) {
         float d0[NU], xx[NU][MM];
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            d0[u] = dwr[k0 + 64 * u];
+            d0[u] = dwr[k0 + KSTEP * u];
 #pragma unroll
-            for (int m = 0; m < MM; ++m) xx[u][m] = m < p.M ? xr[(size_t)m * p.ldx + k0 + 64 * u] : 0.f;
+            for (int m = 0; m < MM; ++m) xx[u][m] = m < p.M ? xr[(size_t)m * p.ldx + k0 + KSTEP * u] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             ColProlog<MM> cp;
-            cp.template apply<false>(p.pro, xx[u], p.M, k0 + 64 * u, p.K);
+            cp.template apply<false>(p.pro, xx[u], p.M, k0 + KSTEP * u, p.K);
             float a = 0.f;
 #pragma unroll
             for (int m = 0; m < MM; ++m) a = fmaf(dz[m], xx[u][m], a);
-            dwr[k0 + 64 * u] = d0[u] + a;
+            dwr[k0 + KSTEP * u] = d0[u] + a;
         }
     }
-    for (int k = k0; k < p.K; k += 64) {
+    for (int k = k0; k < p.K; k += KSTEP) {
         float x[MM];
 #pragma unroll
         for (int m = 0; m < MM; ++m) x[m] = m < p.M ? p.x[(size_t)m * p.ldx + k] : 0.f;
@@ -187,38 +210,58 @@ __global__ __launch_bounds__(256) void linear_bwd_w_kernel(const Grp<LinearBwdP>
     }
 }
 
-// ---- backward: input (one thread per input column k), prologue backward lane-local --------------------------
+// ---- backward: input.  A workgroup owns 64 input columns; its four waves split the output features (wave w takes 32 of every 128) and
+// meet in LDS; the prologue backward is lane-local (wave 0, one lane per column).  A wave's 32 weight rows per chunk are requested 16 at a
+// time before their first use: one thread per column over ALL N rows was a chain of N dependent-latency loads on two CUs (K = 512, N = 256:
+// 18.6 us per launch; 47 us with an 8-deep unroll hint).
 template <int MM>
 __global__ __launch_bounds__(256) void linear_bwd_x_kernel(const Grp<LinearBwdP> grp) {
     const LinearBwdP& p = grp.p[blockIdx.z];
     __shared__ float dzs[MM][128];
-    const int k = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float red[3][MM][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + lane;
+    const int N = p.N, K = p.K;
+    const float* __restrict__ wk = p.w + (k < K ? k : K - 1);        // clamped: branch-free loads
     float acc[MM];
 #pragma unroll
     for (int m = 0; m < MM; ++m) acc[m] = 0.f;
-    for (int nb = 0; nb < p.N; nb += 128) {
+    for (int nb = 0; nb < N; nb += 128) {
         __syncthreads();
         for (int idx = threadIdx.x; idx < MM * 128; idx += 256) {
             const int m = idx >> 7, n = nb + (idx & 127);
             float g = 0.f;
-            if (m < p.M && n < p.N) {
+            if (m < p.M && n < N) {
                 g = p.dy[(size_t)m * p.lddy + n];
                 if (p.out_relu && !(p.y[(size_t)m * p.ldy + n] > 0.f)) g = 0.f;
             }
-            dzs[m][idx & 127] = g;
+            dzs[m][idx & 127] = g;                                   // rows n >= N: zero, so their (clamped) weight loads add nothing
         }
         __syncthreads();
-        if (k < p.K) {
-            const int ne = p.N - nb < 128 ? p.N - nb : 128;
-#pragma unroll 8
-            for (int n = 0; n < ne; ++n) {
-                const float w = p.w[(size_t)(nb + n) * p.K + k];
+        if (nb + 32 * wave < N) {                                    // wave-uniform
 #pragma unroll
-                for (int m = 0; m < MM; ++m) acc[m] = fmaf(dzs[m][n], w, acc[m]);
+            for (int h = 0; h < 2; ++h) {
+                float wv[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int n = nb + 32 * wave + 16 * h + j;
+                    wv[j] = wk[(size_t)(n < N ? n : N - 1) * K];
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+#pragma unroll
+                    for (int m = 0; m < MM; ++m) acc[m] = fmaf(dzs[m][32 * wave + 16 * h + j], wv[j], acc[m]);
             }
         }
     }
-    if (k >= p.K) return;
+    if (wave > 0) {
+#pragma unroll
+        for (int m = 0; m < MM; ++m) red[wave - 1][m][lane] = acc[m];
+    }
+    __syncthreads();
+    if (wave > 0 || k >= K) return;
+#pragma unroll
+    for (int m = 0; m < MM; ++m) acc[m] += red[0][m][lane] + red[1][m][lane] + red[2][m][lane];
     float x[MM];
 #pragma unroll
     for (int m = 0; m < MM; ++m) x[m] = m < p.M ? p.x[(size_t)m * p.ldx + k] : 0.f;
@@ -248,8 +291,11 @@ __global__ __launch_bounds__(256) void linear_bwd_x_kernel(const Grp<LinearBwdP>
 template <int MM>
 static int launch_linear_bwd(const Grp<LinearBwdP>& a, int ng, hipStream_t s) {
     const LinearBwdP& p = a.p[0];
-    if (p.dw) MMS_LAUNCH(linear_bwd_w_kernel<MM>, dim3((p.N + 3) / 4, 1, ng), dim3(256), 0, s, a);
-    if (p.dx) MMS_LAUNCH(linear_bwd_x_kernel<MM>, dim3((p.K + 255) / 256, 1, ng), dim3(256), 0, s, a);
+    if (p.dw) {
+        if (p.K >= 2048) MMS_LAUNCH((linear_bwd_w_kernel<MM, true>), dim3(p.N, 1, ng), dim3(256), 0, s, a);
+        else MMS_LAUNCH((linear_bwd_w_kernel<MM, false>), dim3((p.N + 3) / 4, 1, ng), dim3(256), 0, s, a);
+    }
+    if (p.dx) MMS_LAUNCH(linear_bwd_x_kernel<MM>, dim3((p.K + 63) / 64, 1, ng), dim3(256), 0, s, a);
     return mms_check_launch();
 }
 extern "C" int mms_linear_bwd_group(const LinearBwdP* pp, int ng, hipStream_t s) {

@@ -28,15 +28,19 @@ _DL_SHAPES = [(2, (4, 4, 2), 64, 256, 1), (4, (8, 8, 4), 96, 256, 4), (3, (2, 2,
 # small: MmsDnOpts.conv3_small for the unsplit conv2 launches (None = default: the all-tap 16-row kernels of dn_c3s.hip on every grid here whose
 # neighbourhood window fits -- all but 16x16x8, 7x7x8, 8x16x16; "0" = tile-GEMM form; "1" / "2" = one / two 16-column tiles per wave)
 # "f1" / "f2": the same with the weights in MFMA-fragment order (wfrag -- what the network driver feeds those kernels; small grids only)
-_DL_FORMS = [(0, None), (0, "0"), (0, "1"), (0, "2"), (0, "f1"), (0, "f2"), (27, None), (3, None)]
+# "m": MmsDnOpts.conv3_mt = 3 -- the multi-tap kernels (conv3_fwd_mt_kernel, conv3_bwd_data_mt_kernel; block 1 of the real volumes) wherever
+# they apply (>= 64 rows), here also on small, ragged and W = 2 / 4 / 8 / 16 grids
+_DL_FORMS = [(0, None), (0, "0"), (0, "1"), (0, "2"), (0, "f1"), (0, "f2"), (0, "m"), (27, None), (3, None)]
 _small_grid = lambda dims: 16 + 2 * (dims[1] * dims[2] + dims[2] + 1) <= 120
+_rows = lambda a: a[0] * a[1][0] * a[1][1] * a[1][2]
 
 
-@pytest.mark.parametrize("B,dims,C,Ctot,ms,split,small", [a + f for a in _DL_SHAPES for f in _DL_FORMS if not (f[1] and f[1][0] == "f" and not _small_grid(a[1]))])
+@pytest.mark.parametrize("B,dims,C,Ctot,ms,split,small", [a + f for a in _DL_SHAPES for f in _DL_FORMS if not (f[1] and f[1][0] == "f" and not _small_grid(a[1]))
+                                                          and not (f[1] == "m" and _rows(a) < 64)])
 def test_dense_layer_backward(ops, B, dims, C, Ctot, ms, split, small):
     """One _DenseLayer: norm1-relu-conv1-norm2-relu-conv2 + cat; gradient w.r.t. every parameter and the input slab."""
     frag = small is not None and small[0] == "f"
-    o = ops.dn_opts(**({"conv3_small": {"0": -1, "1": 1, "2": 2}[small[-1]]} if small is not None else {}))
+    o = ops.dn_opts(**({"conv3_mt": 3} if small == "m" else {"conv3_small": {"0": -1, "1": 1, "2": 2}[small[-1]]} if small is not None else {}))
     torch.manual_seed(0)
     M = B * dims[0] * dims[1] * dims[2]
     x = (torch.randn(B, C, *dims) * 1.3 + 0.2).requires_grad_(True)

@@ -11,7 +11,7 @@ def kind(name):
     if "conv3_fwd_reduce" in name: return ("fwd", True)
     if "conv3_bwd_data_reduce" in name: return ("bwd_data", True)
     if "conv3_fwd_mt" in name or "Conv3FwdOp" in name or "conv3s_fwd_kernel" in name: return ("fwd", False)
-    if "Conv3BwdDataOp" in name or "conv3s_bwd_data_kernel" in name: return ("bwd_data", False)
+    if "Conv3BwdDataOp" in name or "conv3s_bwd_data_kernel" in name or "conv3_bwd_data_mt" in name: return ("bwd_data", False)
     if "conv3_bwdw_mt" in name or "Conv3BwdWOp" in name: return ("bwd_weight", False)
     return None
 
