@@ -52,7 +52,7 @@ BLOCKS = ((6, 64), (12, 128), (24, 256), (16, 512))     # (layers, first-layer i
 
 # ---- roofline leg: the dense-layer 3x3x3 convolution family, timed live ------------------------------------------------
 def _stat_reps(M):                 # dn_net.hip make_plan: statistic-accumulator replicas of a level
-    r, rows = 1, 8192
+    r, rows = 1, 2048
     while r < 8 and M // (2 * r) >= rows:
         r *= 2
     return r

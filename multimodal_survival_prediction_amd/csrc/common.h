@@ -60,10 +60,33 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make
 __device__ __forceinline__ double* stat_rep(double* base, int nrep, int stride) {
     return (base && nrep > 1) ? base + (size_t)(blockIdx.x % nrep) * stride : base;
 }
+// Replicas 1 .. nrep-1 of NA accumulators (V = double, or a 2-vector of doubles) whose replica-0 values the caller has already loaded into s[]:
+// three replicas at a time, every load of a chunk requested before the first add and branch-free (absent replicas re-read replica 0 and are
+// not added) -- a plain loop over the runtime replica count is one dependent memory round trip PER REPLICA in every consumer's prologue,
+// which is what made more than one replica per 8192 rows a net loss in rounds 2-3.  Added in replica order.  a[i]: replica 0's address.
+template <int NA, class V>
+__device__ __forceinline__ void rep_add(const V* const (&a)[NA], int nrep, size_t stride_doubles, V (&s)[NA]) {
+    for (int r0 = 1; r0 < nrep; r0 += 3) {                           // uniform
+        V t[NA][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const size_t o = (size_t)(r0 + j < nrep ? r0 + j : 0) * stride_doubles;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) t[i][j] = *(const V*)((const double*)a[i] + o);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (r0 + j < nrep) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) s[i] += t[i][j];
+            }
+    }
+}
 __device__ __forceinline__ double rep_sum(const double* a, int c, int nrep, int stride) {
-    double s = a[c];
-    for (int r = 1; r < nrep; ++r) s += a[c + (size_t)r * stride];
-    return s;
+    double s[1] = {a[c]};
+    const double* const p[1] = {a + c};
+    rep_add(p, nrep, (size_t)stride, s);
+    return s[0];
 }
 
 // Split fixup without a second launch: every workgroup of an output tile publishes its partial, then takes a ticket; the
@@ -92,8 +115,10 @@ __device__ __forceinline__ bool tile_last_arriver(unsigned* counter, unsigned ns
 // memory round trip (two rep_sum calls in a row cost two: the first call's loop block separates the loads and its result is consumed
 // before the second load is issued).
 __device__ __forceinline__ void rep_sum2(const double* a, const double* b, int c, int nrep, int stride, double& sa, double& sb) {
-    sa = a[c]; sb = b[c];
-    for (int r = 1; r < nrep; ++r) { sa += a[c + (size_t)r * stride]; sb += b[c + (size_t)r * stride]; }
+    double s[2] = {a[c], b[c]};
+    const double* const p[2] = {a + c, b + c};
+    rep_add(p, nrep, (size_t)stride, s);
+    sa = s[0]; sb = s[1];
 }
 
 // mean / rstd of channel c.  The batch variance is the biased one (what torch normalises with).
@@ -121,11 +146,12 @@ __device__ __forceinline__ void bn_consts1(const BnSrc& b, int c, float& mean, f
 // Everything a BatchNorm-backward consumer needs for channel c of a training-mode BatchNorm -- (mean, rstd, gamma) and the two backward
 // sums (s1 = sum dy, s2 = sum dy * xhat) -- with all five base loads issued together (one round trip instead of five).
 __device__ __forceinline__ void bn_bwd_consts(const BnSrc& b, const BnBwd& bb, int c, float& mean, float& rstd, float& gamma, double& t1, double& t2) {
-    double s = b.sum[c], q = b.sumsq[c];
-    t1 = bb.s1[c]; t2 = bb.s2[c];
+    double sq[2] = {b.sum[c], b.sumsq[c]}, tt[2] = {bb.s1[c], bb.s2[c]};
     gamma = b.gamma[c];
-    for (int r = 1; r < b.nrep; ++r) { s += b.sum[c + (size_t)r * b.rep_stride]; q += b.sumsq[c + (size_t)r * b.rep_stride]; }
-    for (int r = 1; r < bb.nrep; ++r) { t1 += bb.s1[c + (size_t)r * bb.rep_stride]; t2 += bb.s2[c + (size_t)r * bb.rep_stride]; }
+    { const double* const p[2] = {b.sum + c, b.sumsq + c}; rep_add(p, b.nrep, (size_t)b.rep_stride, sq); }
+    { const double* const p[2] = {bb.s1 + c, bb.s2 + c}; rep_add(p, bb.nrep, (size_t)bb.rep_stride, tt); }
+    t1 = tt[0]; t2 = tt[1];
+    const double s = sq[0], q = sq[1];
     const double m = s * (double)b.inv_count;
     double v = q * (double)b.inv_count - m * m;
     v = v > 0.0 ? v : 0.0;
@@ -141,13 +167,10 @@ __device__ __forceinline__ void bn_consts4(const BnSrc& b, int c, float (&mean)[
     float4 mu4, rs4;
     if (b.train) {
         typedef double d2 __attribute__((ext_vector_type(2)));
-        d2 s01 = *(const d2*)(b.sum + c), s23 = *(const d2*)(b.sum + c + 2);
-        d2 q01 = *(const d2*)(b.sumsq + c), q23 = *(const d2*)(b.sumsq + c + 2);
-        for (int r = 1; r < b.nrep; ++r) {
-            const size_t o = (size_t)r * b.rep_stride + c;
-            s01 += *(const d2*)(b.sum + o); s23 += *(const d2*)(b.sum + o + 2);
-            q01 += *(const d2*)(b.sumsq + o); q23 += *(const d2*)(b.sumsq + o + 2);
-        }
+        d2 sv[4] = {*(const d2*)(b.sum + c), *(const d2*)(b.sum + c + 2), *(const d2*)(b.sumsq + c), *(const d2*)(b.sumsq + c + 2)};
+        { const d2* const p[4] = {(const d2*)(b.sum + c), (const d2*)(b.sum + c + 2), (const d2*)(b.sumsq + c), (const d2*)(b.sumsq + c + 2)};
+          rep_add(p, b.nrep, (size_t)b.rep_stride, sv); }
+        const d2 s01 = sv[0], s23 = sv[1], q01 = sv[2], q23 = sv[3];
         const double ic = (double)b.inv_count;
         const double m0 = s01.x * ic, m1 = s01.y * ic, m2 = s23.x * ic, m3 = s23.y * ic;
         const double v0 = q01.x * ic - m0 * m0, v1 = q01.y * ic - m1 * m1, v2 = q23.x * ic - m2 * m2, v3 = q23.y * ic - m3 * m3;
@@ -186,13 +209,19 @@ __device__ __forceinline__ void bn_consts_to_lds(const BnSrc& b, int C, int tid,
         else { rm[j] = b.rmean[cc]; rv[j] = b.rvar[cc]; s[j] = 0; q[j] = 0; }
         g[j] = b.gamma[cc]; be[j] = b.beta[cc];
     }
-    if (b.train)                               // ... then the replicas, if any
-        for (int r = 1; r < b.nrep; ++r)
+    if (b.train && b.nrep > 1) {               // ... then the replicas, if any (three at a time, rep_add)
+        double sq[2 * NJ];
+        const double* pp[2 * NJ];
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int c = tid + 256 * j, cc = c < C ? c : C - 1;
-                s[j] += b.sum[cc + (size_t)r * b.rep_stride]; q[j] += b.sumsq[cc + (size_t)r * b.rep_stride];
-            }
+        for (int j = 0; j < NJ; ++j) {
+            const int c = tid + 256 * j, cc = c < C ? c : C - 1;
+            sq[2 * j] = s[j]; sq[2 * j + 1] = q[j]; pp[2 * j] = b.sum + cc; pp[2 * j + 1] = b.sumsq + cc;
+        }
+        const double* const (&pr)[2 * NJ] = pp;
+        rep_add(pr, b.nrep, (size_t)b.rep_stride, sq);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { s[j] = sq[2 * j]; q[j] = sq[2 * j + 1]; }
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int c = tid + 256 * j;

@@ -58,11 +58,13 @@ bool make_plan(Plan& P, int B, int D, int H, int W) {
     for (int b = 1; b < NB; ++b) P.g[b] = Dims3{P.g[b - 1].D / 2, P.g[b - 1].H / 2, P.g[b - 1].W / 2};
     P.M0 = B * P.g0.D * P.g0.H * P.g0.W;
     for (int b = 0; b < NB; ++b) P.M[b] = B * P.g[b].D * P.g[b].H * P.g[b].W;
-    // statistic-accumulator replicas of a level: one per 8192 rows, at most 8 -- 65536 rows (the stem; block 1
-    // of 128x128x64 volumes) -> 8, block 1 of 64x64x32 volumes (8192 rows) -> 1.  Replicas relieve the producers' fp64 atomics but every
-    // consumer workgroup re-adds them in its prologue: measured on the K = 5 epoch (rounds 2-3), one replica per 2048 rows (block 1: 4) 2283-2296
-    // patients/s, per 512 rows 2170, per 4096 / 8192 rows or a single replica everywhere 2322-2325.  (Part of the workspace LAYOUT, so a constant.)
-    constexpr int rep_rows = 8192;
+    // statistic-accumulator replicas of a level: one per 2048 rows, at most 8 -- the stem (65536 rows) -> 8, block 1 of 64x64x32 volumes
+    // (8192 rows) -> 4, blocks 2-4 -> 1.  Replicas relieve the producers' fp64 atomics: 256 workgroups adding to the same four cache lines
+    // serialise at the memory side, ~23 ns per line request -- 6 us of a 30 us block-1 conv2 launch of one model (tools/build_variant.sh
+    // with -DMMS_ABLATE_STATS); every consumer workgroup re-adds them in its prologue, three replicas per memory round trip (rep_add,
+    // common.h).  History: with a dependent round trip PER replica in the consumers, one replica per 2048 rows measured 2283-2296 patients/s on
+    // the K = 5 epoch against 2322-2325 for one per 8192 rows (rounds 2-3).  (Part of the workspace LAYOUT, so a constant.)
+    constexpr int rep_rows = 2048;
     auto reps = [](int M) { int r = 1; while (r < 8 && M / (2 * r) >= rep_rows) r *= 2; return r; };
     P.R0 = reps(P.M0);
     for (int b = 0; b < NB; ++b) P.R[b] = reps(P.M[b]);
