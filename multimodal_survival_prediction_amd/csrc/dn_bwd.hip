@@ -1535,20 +1535,28 @@ __global__ __launch_bounds__(256) void conv0_bwd_weight_kernel(const Grp<Conv0Bw
             const float* xb = xs[buf];
             const float* db = dys[buf];
 #ifndef C0_NO_MMA
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const float bv0 = db[(2 * q + kq) * C0_DYP + li], bv1 = db[(2 * q + kq) * C0_DYP + 32 + li];
-                const float a0 = xb[koff[0] + moff[q]], a1 = xb[koff[1] + moff[q]];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv1, acc[1][1], 0, 0, 0);
+            // operands of voxel pair q + 1 are requested before the MFMAs of pair q, order pinned (one wave per SIMD: nothing else covers
+            // the LDS latency; left alone the compiler exposes it twice per pair)
+            float bv0[2], bv1[2], a0[2], a1[2], a2[2];
+            auto oread = [&](int q, int j) __attribute__((always_inline)) {
+                bv0[j] = db[(2 * q + kq) * C0_DYP + li]; bv1[j] = db[(2 * q + kq) * C0_DYP + 32 + li];
+                a0[j] = xb[koff[0] + moff[q]]; a1[j] = xb[koff[1] + moff[q]]; a2[j] = xb[koff[2] + moff[q]];
+            };
+            oread(0, 0);
+            static_for<16>([&](auto Q) __attribute__((always_inline)) {
+                constexpr int q = decltype(Q)::value, j = q & 1;
+                if constexpr (q + 1 < 16) oread(q + 1, j ^ 1);
+                asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bv0[j], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bv1[j], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bv0[j], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bv1[j], acc[1][1], 0, 0, 0);
                 if (t2ok) {
-                    const float a2 = xb[koff[2] + moff[q]];
-                    acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, bv0, acc[2][0], 0, 0, 0);
-                    acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, bv1, acc[2][1], 0, 0, 0);
+                    acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[j], bv0[j], acc[2][0], 0, 0, 0);
+                    acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[j], bv1[j], acc[2][1], 0, 0, 0);
                 }
-            }
+                asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+            });
 #endif
             if (more) sstore(buf ^ 1);
             __syncthreads();

@@ -617,7 +617,19 @@ __global__ __launch_bounds__(256) void conv0_fwd_box_kernel(const Grp<Conv0FwdP>
         const Conv0FwdP& p = grp.p[model];
         float breg[172];                                       // W[32*ct + li][2s + kq], s = 0..171 (tap 343 = padding)
         {
-            const float* wrow = p.w + (size_t)(32 * ct + li) * 343;
+            // through LDS: the 88 KB weight block is copied with coalesced loads, all in flight together, and each lane picks its row from
+            // there.  (Straight from global memory a lane's row sits 1372 B from its neighbour's: 172 load instructions of 32 lines each,
+            // ~15 us of every workgroup's life -- a third of a one-model launch of four boxes per workgroup.)
+            extern __shared__ __attribute__((aligned(16))) float wst[];      // [64][343]
+            __syncthreads();                                   // previous segment's rows are in registers
+            constexpr int NW = 64 * 343, NPASS = (NW + 255) / 256;           // 86 words per thread
+            float t[NPASS];
+#pragma unroll
+            for (int i = 0; i < NPASS; ++i) { const int e = tid + 256 * i; t[i] = p.w[e < NW ? e : NW - 1]; }
+#pragma unroll
+            for (int i = 0; i < NPASS; ++i) { const int e = tid + 256 * i; if (e < NW) wst[e] = t[i]; }
+            __syncthreads();
+            const float* wrow = wst + (32 * ct + li) * 343;
 #pragma unroll
             for (int s = 0; s < 172; ++s) breg[s] = (2 * s + kq < 343) ? wrow[2 * s + kq] : 0.f;
         }
@@ -654,16 +666,25 @@ __global__ __launch_bounds__(256) void conv0_fwd_box_kernel(const Grp<Conv0FwdP>
             f32x16 acc, acc2;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+            // The A operand of MFMA s is requested C0F_PF MFMAs ahead and the order is pinned: left alone the compiler puts each ds_read right
+            // before its two MFMAs and the wave -- the only one on its SIMD: 343 VGPRs -- idles for the LDS latency once per pair.
+            constexpr int C0F_PF = 8;
+            float ring[C0F_PF];
+            auto aread = [&](int s_) __attribute__((always_inline)) {
+                const int k0 = c0f_koff(2 * s_), k1 = c0f_koff(2 * s_ + 1 < 343 ? 2 * s_ + 1 : 342);
+                return xb[k0 + kq * (k1 - k0)];
+            };
 #pragma unroll
-            for (int s = 0; s < 172; s += 2) {
-                constexpr int dummy = 0; (void)dummy;
-                const int k0 = c0f_koff(2 * s), k1 = c0f_koff(2 * s + 1 < 343 ? 2 * s + 1 : 342);
-                const int k2 = c0f_koff(2 * s + 2), k3 = c0f_koff(2 * s + 3 < 343 ? 2 * s + 3 : 342);
-                const float a = xb[k0 + kq * (k1 - k0)];
-                const float a2 = xb[k2 + kq * (k3 - k2)];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, breg[s], acc, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, breg[s + 1], acc2, 0, 0, 0);
-            }
+            for (int s_ = 0; s_ < C0F_PF; ++s_) ring[s_] = aread(s_);
+            static_for<172>([&](auto S) __attribute__((always_inline)) {
+                constexpr int s_ = decltype(S)::value;
+                const float a = ring[s_ % C0F_PF];
+                if constexpr (s_ + C0F_PF < 172) ring[s_ % C0F_PF] = aread(s_ + C0F_PF);
+                asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+                if constexpr ((s_ & 1) == 0) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, breg[s_], acc, 0, 0, 0);
+                else acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, breg[s_], acc2, 0, 0, 0);
+                asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+            });
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
             // statistics (channel 32*ct + li, this lane's 16 voxel rows) and the store through a per-wave LDS transpose
@@ -714,10 +735,15 @@ extern "C" int mms_conv0_fwd_group(const Conv0FwdP* pp, int ng, const MmsDnOpts*
     if (!boxed) return launch_tile_gemm<Conv0FwdOp>(pp, ng, dim3((p.M + 63) / 64, 1, 1), s);
     Grp<Conv0FwdP> a;
     grp_fill(a, pp, ng, ng);
+    // one workgroup per CU at most: 342 VGPRs leave room for one wave per SIMD, so a second round would only pay the per-workgroup set-up
+    // (weight rows into registers) again
     const long boxes = (long)ng * (p.M / 64);
-    int nwg = (opts && opts->c0f_nwg > 0) ? opts->c0f_nwg : (boxes >= 512L * 4 ? 512 : (boxes >= 256L * 2 ? 256 : (int)boxes));
+    int nwg = (opts && opts->c0f_nwg > 0) ? opts->c0f_nwg : (boxes >= 256 ? 256 : (int)boxes);
     if (nwg < 1) nwg = 1;
-    MMS_LAUNCH(conv0_fwd_box_kernel, dim3(nwg, 1, 1), dim3(256), 0, s, a);
+    constexpr int smem = 64 * 343 * (int)sizeof(float);            // 87.8 KB of dynamic LDS (the weight block) + 34.5 KB static
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [&] { hipFuncSetAttribute((const void*)conv0_fwd_box_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem); });
+    MMS_LAUNCH(conv0_fwd_box_kernel, dim3(nwg, 1, 1), dim3(256), smem, s, a);
     return mms_check_launch();
 }
 MMS_SINGLE_O(mms_conv0_fwd, Conv0FwdP)
