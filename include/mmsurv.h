@@ -272,6 +272,9 @@ typedef struct Conv0BwdWP {                 // dW0[64][343] += sum_m bn0bwd(dbn0
     const float* x; Dims3 in; Dims3 out; const int* coords; int M;
     float* dw; int msplit;
     float* dgamma; float* dbeta;    // [64]
+    float* dw_rep; int nrep;        // optional: nrep zeroed replicas [nrep][64*343] -- workgroup x adds to replica x % nrep and a second launch adds the
+                                    // replicas into dw (256 workgroups x 22 k atomics on the 686 lines of ONE gradient serialise at the memory side);
+                                    // NULL / 0: atomics straight into dw
 } Conv0BwdWP;
 
 /* =========================== fallback CT encoder (R/scripts/training/final_multimodal.py:75-86) ==================

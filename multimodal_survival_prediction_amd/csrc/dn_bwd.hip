@@ -1565,6 +1565,7 @@ __global__ __launch_bounds__(256) void conv0_bwd_weight_kernel(const Grp<Conv0Bw
     }
     // epilogue: per wave, tile by tile through LDS so that the atomics run along k (dW0[n][k] is contiguous in k)
     float* cs = Cs[wave];
+    float* dwdst = p.dw_rep ? p.dw_rep + (size_t)(blockIdx.x % (unsigned)p.nrep) * (64 * 343) : p.dw;
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         if (t == 2 && !t2ok) break;
@@ -1577,12 +1578,24 @@ __global__ __launch_bounds__(256) void conv0_bwd_weight_kernel(const Grp<Conv0Bw
 #ifndef C0_NO_EPI
         for (int idx = lane; idx < 32 * 64; idx += 64) {
             const int tl = idx & 31, ch = idx >> 5, tap = 32 * T + tl;
-            if (tap < 343) atomicAdd(&p.dw[ch * 343 + tap], cs[tl * 65 + ch]);
+            if (tap < 343) atomicAdd(&dwdst[ch * 343 + tap], cs[tl * 65 + ch]);
         }
 #endif
         __builtin_amdgcn_wave_barrier();
     }
   }
+}
+__global__ __launch_bounds__(256) void conv0_dw_reduce_kernel(const Grp<Conv0BwdWP> grp) {
+    const Conv0BwdWP& p = grp.p[blockIdx.z];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 64 * 343) return;
+    float v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = p.dw_rep[(size_t)(r < p.nrep ? r : 0) * (64 * 343) + i];
+    float a = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) if (r < p.nrep) { a += v[r]; p.dw_rep[(size_t)r * (64 * 343) + i] = 0.f; }      // (left zeroed for the next call)
+    p.dw[i] += a;
 }
 
 extern "C" int mms_conv0_bwd_weight_group(const Conv0BwdWP* pp, int ng, const MmsDnOpts* opts, hipStream_t s) {
@@ -1604,7 +1617,15 @@ extern "C" int mms_conv0_bwd_weight_group(const Conv0BwdWP* pp, int ng, const Mm
     const long boxes = (long)ng * (p.M / 32);
     int nwg = (opts && opts->c0_nwg > 0) ? opts->c0_nwg : (boxes >= 256L * 8 ? 256 : (int)((boxes + 7) / 8));
     if (nwg < 1) nwg = 1;
+    for (int g = 0; g < ng; ++g) if ((pp[g].dw_rep != nullptr) != (p.dw_rep != nullptr) || pp[g].nrep != p.nrep || (p.dw_rep && (p.nrep < 1 || p.nrep > 8))) return MMS_ERR_ARG;
     MMS_LAUNCH(conv0_bwd_weight_kernel, dim3(nwg, 1, 1), dim3(256), 0, s, a);
+    if (p.dw_rep) {
+        const int rc = mms_check_launch();
+        if (rc != MMS_OK) return rc;
+        Grp<Conv0BwdWP> b;
+        grp_fill(b, pp, ng, 1);
+        MMS_LAUNCH(conv0_dw_reduce_kernel, dim3((64 * 343 + 255) / 256, 1, ng), dim3(256), 0, s, b);
+    }
     return mms_check_launch();
 }
 MMS_SINGLE_O(mms_conv0_bwd_weight, Conv0BwdWP)

@@ -34,6 +34,7 @@ struct Plan {
     size_t coords0, coords[NB], y0, argmax, slab[NB], dslab[NB], y1[NLAYER], wpf[NLAYER], wpb[NLAYER];
     size_t dbn_mid_l[NLAYER], dbn_in, dbn0, pooled, tab_pack, tab_bn, partial, dwp[NLAYER];
     // fp64 statistic accumulators (one contiguous region, zeroed once per step)
+    size_t dw0_rep;                 // 8 replicas of the conv0 weight gradient (inside the zeroed region)
     size_t stats_begin, stats_begin_packed, stats_end;      // (packed primary conv2 storage: the gradient scratch dwp at the head of the region is unused)
     size_t st_y0, st_slab[NB], st_y1[NLAYER];          // forward (sum | sumsq), each 2*C doubles
     size_t counters;                                   // split-fixup tickets (zeroed at init, re-armed by their users)
@@ -133,6 +134,7 @@ bool make_plan(Plan& P, int B, int D, int H, int W) {
             P.cl_gst[b] = take((size_t)ncl * 8 * 192 * 8);
         }
     }
+    P.dw0_rep = take((size_t)8 * 64 * 343 * 4);
     P.stats_end = o;
     P.counters = take(4096 * 4);
     P.b4_err = take(1024);
@@ -718,7 +720,8 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
                                  at<float>(c.ws, P.dbn0), at<double>(c.ws, P.bb_y0), at<double>(c.ws, P.bb_y0) + 64, at<int>(c.ws, P.coords0)};
                 pb[g].srep = P.R0; pb[g].sstride = 2 * 64;
                 cw[g] = Conv0BwdWP{at<float>(c.ws, P.dbn0), at<float>(c.ws, P.y0), bn0, bbsrc(c.ws, P.bb_y0, 64, P.R0), c.x, P.in, P.g0,
-                                   at<int>(c.ws, P.coords0), P.M0, c.grd[IDX.conv0], ms0, c.grd[IDX.n0w], c.grd[IDX.n0b]};
+                                   at<int>(c.ws, P.coords0), P.M0, c.grd[IDX.conv0], ms0, c.grd[IDX.n0w], c.grd[IDX.n0b],
+                                   at<float>(c.ws, P.dw0_rep), 8};
             }
             TRYS(29, mms_pool_bwd_group(pb, ng, s));
             SYNC(at<double>(cx[0].ws, P.bb_y0), P.R0, 2 * 64, 64, 64);

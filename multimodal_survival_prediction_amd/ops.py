@@ -183,9 +183,11 @@ def pool_bwd(dslab, argmax, out_dims, in_dims, B, y0, bn, dbn, s1, s2, coords=No
     call("mms_pool_bwd", p)
 
 
-def conv0_bwd_weight(dbn, y0, bn, bb, x, in_dims, out_dims, coords, dw, msplit, dgamma, dbeta):
+def conv0_bwd_weight(dbn, y0, bn, bb, x, in_dims, out_dims, coords, dw, msplit, dgamma, dbeta, dw_rep=None):
+    """dw_rep: optional zeroed [nrep <= 8][64 * 343] replica scratch (Conv0BwdWP.dw_rep: spreads the gradient atomics, a second launch adds
+    the replicas into dw and leaves them zeroed)"""
     p = _S()["Conv0BwdWP"](ptr(dbn), ptr(y0), bn, bb, ptr(x), dims3(in_dims), dims3(out_dims), ptr(coords),
-                           y0.shape[0], ptr(dw), msplit, ptr(dgamma), ptr(dbeta))
+                           y0.shape[0], ptr(dw), msplit, ptr(dgamma), ptr(dbeta), ptr(dw_rep), 0 if dw_rep is None else dw_rep.shape[0])
     call("mms_conv0_bwd_weight", p)
 
 

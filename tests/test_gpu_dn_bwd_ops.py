@@ -184,8 +184,13 @@ def test_stem_backward(ops, B, dims, ms):
     ops.pool_bwd(dslab, am, pd, od, B, y0d, bn, dbn0, a1, a2, coords if ms > 1 else None)    # with / without the coordinate table
     dw, dg, db = torch.zeros_like(w0), torch.zeros(64, device=DEV), torch.zeros(64, device=DEV)
     ops.conv0_bwd_weight(dbn0, y0d, bn, ops.bnbwd(a1, a2), xd, dims, od, coords, dw, ms, dg, db)
+    # the same through gradient replicas (Conv0BwdWP.dw_rep: what the network driver passes), accumulated into a non-zero gradient
+    dwr, rep = torch.full_like(w0, 0.5), torch.zeros(8 if ms > 1 else 3, 64 * 343, device=DEV)
+    ops.conv0_bwd_weight(dbn0, y0d, bn, ops.bnbwd(a1, a2), xd, dims, od, coords, dwr, ms, torch.zeros(64, device=DEV), torch.zeros(64, device=DEV), dw_rep=rep)
     torch.cuda.synchronize()
     assert_close(dw, c0.weight.grad.view(64, 343), 1e-4, "dW0")
+    assert_close(dwr - 0.5, c0.weight.grad.view(64, 343), 1e-4, "dW0 (replicas)")
+    assert float(rep.abs().max()) == 0.0           # left zeroed for the next call
     assert_close(dg, n0.weight.grad, 1e-4, "dgamma0")
     assert_close(db, n0.bias.grad, 1e-4, "dbeta0")
 
