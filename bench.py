@@ -652,12 +652,15 @@ def run_config2(args, world, rank, dev):
             "value": world * args.steps * B / dt, "unit": "patients/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if world > 1 else None,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: MultiModalSurvivalNet (DenseNet121-3D CT %dx%dx%d + RNA-seq 5005 + clinical), "
-                                   "109 synthetic complete patients, 5-fold split, batch %d, Adam lr 1e-4 wd 1e-4, clip 1.0" % (dims + (B,)),
+            "config": {"workload": ("BASELINE config 4's per-rank problem (--mode ddp: ONE model, this rank's shard of the global batch per step)"
+                                    if one else "BASELINE config 2") +
+                                   ": MultiModalSurvivalNet (DenseNet121-3D CT %dx%dx%d + RNA-seq 5005 + clinical), "
+                                   "109 synthetic complete patients, 5-fold split, batch %d%s, Adam lr 1e-4 wd 1e-4, clip 1.0" % (dims + (B, " per rank" if one else "")),
                        "global_batch": world * B,
                        "parallelism": (f"ddp x{world} (gradient all-reduce per step in {args.ddp_buckets} bucket(s) overlapped with backward, "
                                        f"{'Sync' if args.sync_bn else 'local'} BN + {'global' if args.global_cox else 'local'} Cox risk set"
                                        + (f"; {sync_per_step:.0f} statistic all-reduces per step = 2 per BatchNorm layer and pass, the data-dependence floor" if sync_per_step else "") + ")" if ddp else
+                                       "ddp x1: config 4's step on one rank without its collectives (N = 1: nothing to all-reduce)" if one else
                                        f"kfold-shard x{world} ranks x {F} concurrent groups x {G} lock-step fold models per GPU (one stream + step graph per group, no collective)"),
                        "concurrent_folds": F, "fold_group": G, "fold_models_in_flight": F * G,
                        "hip_graph": not args.no_graph, "mean_train_loss": stats["sum_loss"] / max(stats["n_batches"], 1)},

@@ -81,12 +81,17 @@ typedef struct MmsDnOpts {
                               its forward MFMA-fragment pack (layers of mms_dn121_w2_fragmask; else unused) -- kept current by the caller:
                               mms_clip_adam writes them with the update (AdamP.w2_*), mms_w2_pack after any other change of the weights.
                               0: torch layout, packs and unpack inside the drivers (rounds 1-3) */
+    int trans_prepass;     /* transitions: 0 = AvgPool3d(relu(norm(x))) by its own launch into the workspace (mms_pool_act), the 1x1x1 convolution
+                              and its weight gradient read that pooled operand; -1 = pooled while loading, inside both GEMMs (each of the N / 16-32
+                              column tiles of a row tile re-reads and re-normalises the 8 source voxels: rounds 1-3) */
 } MmsDnOpts;
 
 /* BatchNorm parameter source. train=1: batch statistics from the fp64 accumulators; train=0: running stats.
  * (torch BatchNorm3d/1d, eps 1e-5, momentum 0.1: R/scripts/training/final_multimodal.py:77-96; MONAI norm="batch")
  * The 3x3x3-convolution entry points (mms_conv3_fwd*, mms_conv3_bwd_weight*) read the block with 16-byte vector loads: every array
- * they use (and rep_stride * 8 when nrep > 1) must be 16-byte aligned, else MMS_ERR_ARG. */
+ * they use (and rep_stride * 8 when nrep > 1) must be 16-byte aligned, else MMS_ERR_ARG.
+ * gamma == NULL: the IDENTITY (mean 0, scale 1, shift 0; every other field ignored) -- for an operand that is already normalised and
+ * non-negative (the pooled transition operand of mms_pool_act): relu(identity(x)) == x exactly. */
 typedef struct BnSrc {
     const double* sum;     /* [C] batch sum      (train) */
     const double* sumsq;   /* [C] batch sum x^2  (train) */
@@ -162,6 +167,15 @@ typedef struct PoolFwdP {
     double* osum; double* osumsq;   // [64] stats of the pooled output (nullptr in eval)
     int srep; int sstride;          // statistic-accumulator replicas written by this op: workgroup x adds to replica x % srep (stride in doubles)
 } PoolFwdP;
+
+// ---- transition pre-pass: y[m'][k] = AvgPool3d(2,2)(relu(bn(x)))[m'][k] (MONAI _Transition: norm, relu, conv, pool == norm, relu, pool, conv) ----
+typedef struct PoolActP {
+    const float* x; int ldx;        // [B*in][ldx], first K columns used
+    int K;                          // channels (multiple of 4)
+    BnSrc bn;                       // over the K channels
+    Dims3 in; int Mout;             // input grid (even dims); Mout = B * in / 8 pooled rows
+    float* y; int ldy;              // [Mout][ldy]
+} PoolActP;
 
 // ---- norm5 + relu + global-avg-pool + Linear(1024,128) ---------------------------------------------------
 typedef struct HeadFwdP {
@@ -573,6 +587,7 @@ int mms_rna_log_zscore(const float* counts, float* out, int n, int g, hipStream_
  * The convolution entry points that have several kernel forms take the launch-shape options (MmsDnOpts; NULL = defaults). */
 int mms_conv0_fwd_group(const Conv0FwdP* p, int ng, const MmsDnOpts* opts, hipStream_t s);
 int mms_pool_fwd_group(const PoolFwdP* p, int ng, hipStream_t s);
+int mms_pool_act_group(const PoolActP* p, int ng, hipStream_t s);       /* transition.norm / relu / pool (before transition.conv) */
 int mms_conv1_fwd_group(const Conv1FwdP* p, int ng, const MmsDnOpts* opts, hipStream_t s);
 int mms_conv3_fwd_group(const Conv3FwdP* p, int ng, const MmsDnOpts* opts, hipStream_t s);
 int mms_head_fwd_group(const HeadFwdP* p, int ng, hipStream_t s);

@@ -123,6 +123,7 @@ __device__ __forceinline__ void rep_sum2(const double* a, const double* b, int c
 
 // mean / rstd of channel c.  The batch variance is the biased one (what torch normalises with).
 __device__ __forceinline__ void bn_mean_rstd(const BnSrc& b, int c, float& mean, float& rstd) {
+    if (!b.gamma) { mean = 0.f; rstd = 1.f; return; }             // identity (BnSrc, mmsurv.h)
     if (b.train) {
         double s, q;
         rep_sum2(b.sum, b.sumsq, c, b.nrep, b.rep_stride, s, q);
@@ -139,6 +140,7 @@ __device__ __forceinline__ void bn_mean_rstd(const BnSrc& b, int c, float& mean,
 
 // (mean, rstd, gamma, beta) of channel c with gamma / beta requested BEFORE the statistics' replica loop: one round trip.
 __device__ __forceinline__ void bn_consts1(const BnSrc& b, int c, float& mean, float& rstd, float& gamma, float& beta) {
+    if (!b.gamma) { mean = 0.f; rstd = 1.f; gamma = 1.f; beta = 0.f; return; }
     gamma = b.gamma[c]; beta = b.beta[c];
     bn_mean_rstd(b, c, mean, rstd);
 }
@@ -163,6 +165,11 @@ __device__ __forceinline__ void bn_bwd_consts(const BnSrc& b, const BnBwd& bb, i
 // calls compile to four SERIAL memory round trips (the replica loop's control flow separates them); here the six vector loads are
 // issued together: one round trip.  All six arrays must be 16-byte aligned (mms_bn_aligned16: checked by the launchers).
 __device__ __forceinline__ void bn_consts4(const BnSrc& b, int c, float (&mean)[4], float (&sc)[4], float (&beta)[4]) {
+    if (!b.gamma) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { mean[i] = 0.f; sc[i] = 1.f; beta[i] = 0.f; }
+        return;
+    }
     const float4 g = *(const float4*)(b.gamma + c), be = *(const float4*)(b.beta + c);
     float4 mu4, rs4;
     if (b.train) {
@@ -200,6 +207,11 @@ __device__ __forceinline__ void bn_consts_to_lds(const BnSrc& b, int C, int tid,
 #ifdef MMS_ABLATE_SETUP
     return;
 #endif
+    if (!b.gamma) {                            // identity
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { const int c = tid + 256 * j; if (c < C) { o_mean[c] = 0.f; o_sc[c] = 1.f; o_beta[c] = 0.f; } }
+        return;
+    }
     double s[NJ], q[NJ];
     float g[NJ], be[NJ], rm[NJ], rv[NJ];
 #pragma unroll

@@ -131,6 +131,56 @@ struct Conv1FwdOp {
     }
 };
 
+// ------------------------------------------------------------------------------------------------------
+// transition pre-pass: pooled[m'][k] = mean of relu(bn(x)) over the 2x2x2 source voxels of pooled row m' (summed in the order the
+// pooled GEMM loaders use, then x 0.125).  A thread owns 4 channels (constants in registers) and walks PA_ROWS pooled rows: 8 float4 loads
+// per row, all rows' loads requested before the first use.  Grid: (K / 4 / 64 column groups, row groups, models).
+// ------------------------------------------------------------------------------------------------------
+#define PA_ROWS 2
+__global__ __launch_bounds__(256) void pool_act_kernel(const Grp<PoolActP> grp) {
+    const PoolActP& p = grp.p[blockIdx.z];
+    const int tid = threadIdx.x, c4 = ((int)blockIdx.x * 64 + (tid & 63)) * 4;
+    if (c4 >= p.K) return;
+    float mean[4], sc[4], beta[4];
+    bn_consts4(p.bn, c4, mean, sc, beta);
+    const int D2 = p.in.D >> 1, H2 = p.in.H >> 1, W2 = p.in.W >> 1, vox2 = D2 * H2 * W2, HW = p.in.H * p.in.W, W = p.in.W;
+    const int r0 = ((int)blockIdx.y * 4 + (tid >> 6)) * PA_ROWS;
+    float4 v[PA_ROWS][8];
+#pragma unroll
+    for (int i = 0; i < PA_ROWS; ++i) {
+        const int m = r0 + i < p.Mout ? r0 + i : p.Mout - 1;
+        const int b = m / vox2, r = m % vox2, d = r / (H2 * W2), h = (r / W2) % H2, w = r % W2;
+        const int base = ((b * p.in.D + 2 * d) * p.in.H + 2 * h) * p.in.W + 2 * w;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) v[i][o] = *(const float4*)(p.x + (size_t)(base + (o >> 2) * HW + ((o >> 1) & 1) * W + (o & 1)) * p.ldx + c4);
+    }
+#pragma unroll
+    for (int i = 0; i < PA_ROWS; ++i) {
+        if (r0 + i >= p.Mout) break;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            a.x += fmaxf(bn_apply(v[i][o].x, mean[0], sc[0], beta[0]), 0.f); a.y += fmaxf(bn_apply(v[i][o].y, mean[1], sc[1], beta[1]), 0.f);
+            a.z += fmaxf(bn_apply(v[i][o].z, mean[2], sc[2], beta[2]), 0.f); a.w += fmaxf(bn_apply(v[i][o].w, mean[3], sc[3], beta[3]), 0.f);
+        }
+        *(float4*)(p.y + (size_t)(r0 + i) * p.ldy + c4) = make_float4(a.x * 0.125f, a.y * 0.125f, a.z * 0.125f, a.w * 0.125f);
+    }
+}
+extern "C" int mms_pool_act_group(const PoolActP* pp, int ng, hipStream_t s) {
+    Grp<PoolActP> a;
+    if (!grp_fill(a, pp, ng, 1)) return MMS_ERR_ARG;
+    const PoolActP& p = *pp;
+    if (p.K <= 0 || p.K % 4 != 0 || p.Mout <= 0 || (p.in.D | p.in.H | p.in.W) & 1 || p.in.D <= 0 || p.in.H <= 0 || p.in.W <= 0 ||
+        (long)p.Mout * 8 % ((long)p.in.D * p.in.H * p.in.W) != 0) return MMS_ERR_ARG;
+    for (int g = 0; g < ng; ++g) {
+        const PoolActP& q = pp[g];
+        if (q.K != p.K || q.Mout != p.Mout || q.in.D != p.in.D || q.in.H != p.in.H || q.in.W != p.in.W || q.ldx % 4 != 0 || q.ldy % 4 != 0 ||
+            (((uintptr_t)q.x | (uintptr_t)q.y) & 15) != 0 || !mms_bn_aligned16(q.bn)) return MMS_ERR_ARG;
+    }
+    MMS_LAUNCH(pool_act_kernel, dim3((p.K / 4 + 63) / 64, (p.Mout + 4 * PA_ROWS - 1) / (4 * PA_ROWS), ng), dim3(256), 0, s, a);
+    return mms_check_launch();
+}
+
 extern "C" int mms_conv1_fwd_group(const Conv1FwdP* pp, int ng, const MmsDnOpts* opts, hipStream_t s) {
     if (!pp || ng < 1 || ng > MMS_MAX_GROUP) return MMS_ERR_ARG;
     const MmsDnOpts o = mms_opts(opts);

@@ -35,6 +35,7 @@ struct Plan {
     size_t dbn_mid_l[NLAYER], dbn_in, dbn0, pooled, tab_pack, tab_bn, partial, dwp[NLAYER];
     // fp64 statistic accumulators (one contiguous region, zeroed once per step)
     size_t dw0_rep;                 // 8 replicas of the conv0 weight gradient (inside the zeroed region)
+    size_t tpool[3];                // pooled transition operands [M[t + 1]][CTOT[t]] (forward pre-pass; read again by the weight gradient)
     size_t stats_begin, stats_begin_packed, stats_end;      // (packed primary conv2 storage: the gradient scratch dwp at the head of the region is unused)
     size_t st_y0, st_slab[NB], st_y1[NLAYER];          // forward (sum | sumsq), each 2*C doubles
     size_t counters;                                   // split-fixup tickets (zeroed at init, re-armed by their users)
@@ -136,6 +137,7 @@ bool make_plan(Plan& P, int B, int D, int H, int W) {
     }
     P.dw0_rep = take((size_t)8 * 64 * 343 * 4);
     P.stats_end = o;
+    for (int t = 0; t < 3; ++t) P.tpool[t] = take((size_t)P.M[t + 1] * CTOT[t] * 4);
     P.counters = take(4096 * 4);
     P.b4_err = take(1024);
     for (int b = 0; b < NB; ++b) P.cl_tab[b] = take(sizeof(B4Layer) * LAYERS[b]);
@@ -186,6 +188,7 @@ extern "C" int mms_bn_running_update_group(const void* const*, int, int, float, 
 extern "C" int mms_zero_regions_group(void* const*, int, size_t, hipStream_t);
 extern "C" int mms_conv0_fwd_group(const Conv0FwdP*, int, const MmsDnOpts*, hipStream_t);
 extern "C" int mms_pool_fwd_group(const PoolFwdP*, int, hipStream_t);
+extern "C" int mms_pool_act_group(const PoolActP*, int, hipStream_t);
 extern "C" int mms_conv1_fwd_group(const Conv1FwdP*, int, const MmsDnOpts*, hipStream_t);
 extern "C" int mms_conv3_fwd_group(const Conv3FwdP*, int, const MmsDnOpts*, hipStream_t);
 extern "C" int mms_head_fwd_group(const HeadFwdP*, int, hipStream_t);
@@ -245,6 +248,7 @@ extern "C" int mms_dn121_region(int B, int D, int H, int W, const char* name, in
         while (l >= LAYERS[b]) { l -= LAYERS[b]; ++b; }
         return set(P.y1[index], (size_t)P.M[b] * 128 * 4);
     }
+    if (!strcmp(name, "tpool") && index >= 0 && index < 3) return set(P.tpool[index], (size_t)P.M[index + 1] * CTOT[index] * 4);
     if (!strcmp(name, "stats")) return set(P.stats_begin, P.stats_end - P.stats_begin);
     if (!strcmp(name, "b4_err")) return set(P.b4_err, 1024);
     return MMS_ERR_ARG;
@@ -486,14 +490,18 @@ static int dn121_forward_impl(const Ctx* cx, int ng, int B, int D, int H, int W,
         if (b < 3) {
             const int ip = IDX.trans[b];
             Conv1FwdP t[MMS_MAX_GROUP];
+            PoolActP pa[MMS_MAX_GROUP];
+            const bool pre = o.trans_prepass >= 0;       // norm / relu / pool by their own launch; the convolution reads the pooled rows
             FOR_G {
                 const Ctx& c = cx[g];
-                t[g] = Conv1FwdP{at<float>(c.ws, P.slab[b]), CTOT[b], P.M[b + 1], CTOT[b], c.prm[ip + 2], CTOT[b] / 2,
-                                 at<float>(c.ws, P.slab[b + 1]), CTOT[b + 1],
-                                 mk_bn(c.ws, P.st_slab[b], CTOT[b], c.prm, ip, c.buf, IDX.bn_trans[b], P.M[b] * bw, train, P.R[b]),
-                                 st(c.ws, P.st_slab[b + 1], CTOT[b + 1], 0, false), st(c.ws, P.st_slab[b + 1], CTOT[b + 1], 0, true), 1, P.g[b]};
+                const BnSrc bnt = mk_bn(c.ws, P.st_slab[b], CTOT[b], c.prm, ip, c.buf, IDX.bn_trans[b], P.M[b] * bw, train, P.R[b]);
+                pa[g] = PoolActP{at<float>(c.ws, P.slab[b]), CTOT[b], CTOT[b], bnt, P.g[b], P.M[b + 1], at<float>(c.ws, P.tpool[b]), CTOT[b]};
+                t[g] = Conv1FwdP{pre ? at<float>(c.ws, P.tpool[b]) : at<float>(c.ws, P.slab[b]), CTOT[b], P.M[b + 1], CTOT[b], c.prm[ip + 2], CTOT[b] / 2,
+                                 at<float>(c.ws, P.slab[b + 1]), CTOT[b + 1], pre ? BnSrc{} : bnt,
+                                 st(c.ws, P.st_slab[b + 1], CTOT[b + 1], 0, false), st(c.ws, P.st_slab[b + 1], CTOT[b + 1], 0, true), pre ? 0 : 1, pre ? Dims3{0, 0, 0} : P.g[b]};
                 t[g].srep = P.R[b + 1]; t[g].sstride = 2 * CTOT[b + 1];
             }
+            if (pre) TRYS(30, mms_pool_act_group(pa, ng, s));
             TRYS(30, mms_conv1_fwd_group(t, ng, &o, s));
             SYNC(at<double>(cx[0].ws, P.st_slab[b + 1]), P.R[b + 1], 2 * CTOT[b + 1], CTOT[b] / 2, CTOT[b + 1]);
         }
@@ -705,7 +713,11 @@ static int dn121_backward_impl(const Ctx* cx, int ng, int B, int D, int H, int W
                 ap[g] = BnBwdApplyP{at<float>(c.ws, P.dbn_in), CTOT[t], at<float>(c.ws, P.slab[t]), CTOT[t], at<float>(c.ws, P.dslab[t]), CTOT[t],
                                     Mp, Kp, bnt, bbsrc(c.ws, P.bb_tr[t], 1024, P.R[t]), 0, c.grd[ip], c.grd[ip + 1]};
             }
-            TRYS(31, mms_conv1_bwd_weight_group(c1, ng, s));
+            if (o.trans_prepass >= 0) {       // the weight gradient reads the pooled operand the forward left in the workspace
+                Conv1BwdP cw[MMS_MAX_GROUP];
+                FOR_G { cw[g] = c1[g]; cw[g].x = at<float>(cx[g].ws, P.tpool[t]); cw[g].pool = 0; cw[g].in = Dims3{0, 0, 0}; cw[g].bn_in = BnSrc{}; }
+                TRYS(31, mms_conv1_bwd_weight_group(cw, ng, s));
+            } else TRYS(31, mms_conv1_bwd_weight_group(c1, ng, s));
             TRYS(31, mms_conv1_bwd_data_group(c1, ng, &o, s));
             SYNC(at<double>(cx[0].ws, P.bb_tr[t]), P.R[t], 2 * 1024, Kp, 1024);
             TRYS(31, mms_bn_bwd_apply_group(ap, ng, s));

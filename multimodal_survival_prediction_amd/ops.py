@@ -183,6 +183,12 @@ def pool_bwd(dslab, argmax, out_dims, in_dims, B, y0, bn, dbn, s1, s2, coords=No
     call("mms_pool_bwd", p)
 
 
+def pool_act(x, K, bn, in_dims, y):
+    """Transition pre-pass: y[m'][:K] = AvgPool3d(2, 2)(relu(bn(x)))[m'] for channels-last x [B*in][ldx] (mms_pool_act)."""
+    p = _S()["PoolActP"](ptr(x), x.stride(0), K, bn, dims3(in_dims), y.shape[0], ptr(y), y.stride(0))
+    _lib.check(_lib.load_library().mms_pool_act_group(ctypes.byref(p), 1, stream()), "mms_pool_act_group")
+
+
 def conv0_bwd_weight(dbn, y0, bn, bb, x, in_dims, out_dims, coords, dw, msplit, dgamma, dbeta, dw_rep=None):
     """dw_rep: optional zeroed [nrep <= 8][64 * 343] replica scratch (Conv0BwdWP.dw_rep: spreads the gradient atomics, a second launch adds
     the replicas into dw and leaves them zeroed)"""

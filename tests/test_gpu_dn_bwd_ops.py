@@ -153,6 +153,14 @@ def test_transition_backward(ops, B, dims, C, ms):
     assert_close(dg, n.weight.grad, 1e-4, "dgamma")
     assert_close(db, n.bias.grad, 1e-4, "dbeta")
     assert_close(dx, cl(x.grad), 1e-4, "dx")
+    # the driver's default form of the weight gradient: from the pooled operand of the forward pre-pass (mms_pool_act), un-pooled GEMM with
+    # the identity BatchNorm block
+    pooled = torch.empty(M // 8, C, device=DEV)
+    ops.pool_act(slab, C, bn, dims, pooled)
+    dw2 = torch.zeros_like(w)
+    ops.conv1_bwd("weight", dnext, M // 8, N, pooled, C, ops._S()["BnSrc"](), w, dw2, torch.empty(M // 8, C, device=DEV), *stats(DEV, 1024), msplit=ms)
+    torch.cuda.synchronize()
+    assert_close(dw2, c.weight.grad.view(N, C), 1e-4, "dW (from the pooled operand)")
 
 
 @pytest.mark.parametrize("B,dims,ms", [(2, (16, 16, 8), 1), (1, (32, 32, 16), 4), (2, (12, 8, 10), 2)])

@@ -104,6 +104,21 @@ def test_transition_fwd(ops, B, dims, K):
     assert_close(nxt[:, :N], cl(ref), 1e-4, "transition y")
     assert float(nxt[:, N:].abs().max()) == 0.0
     assert_close(os_, cl(ref).double().sum(0), 1e-4, "transition sum")
+    # the driver's default form: norm / relu / pool by mms_pool_act into a scratch, then the plain 1x1x1 convolution over the pooled rows
+    # with the IDENTITY BatchNorm block (BnSrc.gamma == NULL), tile-GEMM and small-launch kernels
+    pooled = torch.full((M // 8, K + 4), float("nan"), device=DEV)
+    ops.pool_act(slab, K, bn, dims, pooled)
+    torch.cuda.synchronize()
+    assert_close(pooled[:, :K], cl(F.avg_pool3d(F.relu(_bn_ref(x, g, b, True)), 2, 2)), 1e-5, "pooled operand")
+    assert bool(torch.isnan(pooled[:, K:]).all())
+    ident = ops._S()["BnSrc"]()
+    for small in (-1, 1):
+        nx2 = torch.zeros(M // 8, ldn, device=DEV)
+        o2, q2 = stats(DEV, N)
+        ops.conv1_fwd(pooled, K, w.to(DEV), nx2, ident, M // 8, o2, q2, opts=ops.dn_opts(conv1_small=small))
+        torch.cuda.synchronize()
+        assert_close(nx2[:, :N], cl(ref), 1e-4, "transition y (pre-pass, conv1_small=%d)" % small)
+        assert_close(o2, os_, 1e-5, "transition sum (pre-pass)")
 
 
 # (no tap split + W <= 16: MmsDnOpts.conv3_mt = 2 takes the 64-row multi-tap kernel for M >= 1024 rows (cases 1 and 6-8; 7 = ragged last tile),
