@@ -4,7 +4,7 @@
 
 #define SZ(T) if (strcmp(name, #T) == 0) return (int)sizeof(T);
 extern "C" int mms_abi_sizeof(const char* name) {
-    SZ(Dims3) SZ(MmsDnOpts) SZ(BnSrc) SZ(BnBwd) SZ(Conv1FwdP) SZ(Conv3FwdP) SZ(Conv0FwdP) SZ(PoolFwdP) SZ(HeadFwdP)
+    SZ(Dims3) SZ(MmsDnOpts) SZ(BnSrc) SZ(BnBwd) SZ(Conv1FwdP) SZ(Conv3FwdP) SZ(Conv0FwdP) SZ(PoolFwdP) SZ(PoolActP) SZ(HeadFwdP)
     SZ(Conv3BwdDataP) SZ(Conv3BwdWP) SZ(Conv1BwdP) SZ(BnBwdApplyP) SZ(HeadBwdP) SZ(PoolBwdP) SZ(Conv0BwdWP) SZ(InProlog) SZ(LinearFwdP) SZ(LinearBwdP) SZ(GateP) SZ(CoxP) SZ(CindexP) SZ(AdamP) SZ(FbConvP) SZ(FbPoolP) SZ(GatherP) SZ(MixP) SZ(LinBigP)
     return -1;
 }
