@@ -172,10 +172,23 @@ def measure_conv2_family(B, dims, device, G, reps=20, manifest=None):
             for _ in range(3):
                 _lib.check(fn(arr, nm, None, ops.stream()), op)          # (launch-shape options: NULL = the defaults the step runs with)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                _lib.check(fn(arr, nm, None, ops.stream()), op)
-            e1.record()
+            if manifest is None:
+                # as the step issues them: from a captured HIP graph.  Issued one by one from Python the 8-12 us launches of blocks 2-4 are
+                # HOST-bound (ctypes call + launch path per kernel): the same kernels read 12.1 .. 15.3 us on different boxes of the pool.
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    for _ in range(reps):
+                        _lib.check(fn(arr, nm, None, ops.stream()), op)
+                graph.replay()                                           # (first replay: upload)
+                e0.record()
+                graph.replay()
+                e1.record()
+            else:                                                        # --roofline-only (the rocprofv3 kernel-trace / PMC passes): plain launches
+                e0.record()
+                for _ in range(reps):
+                    _lib.check(fn(arr, nm, None, ops.stream()), op)
+                e1.record()
             torch.cuda.synchronize()
             tot[op][0] += e0.elapsed_time(e1) * 1e-3 / reps * nlaunch
             tot[op][1] += nm * 2.0 * M * 27 * 128 * 32 * nlaunch

@@ -15,6 +15,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pm_$c; rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pm_$c -- python3 $R/bench.py --roofline-only > /dev/null 2>&1
 done
 python3 $R/tools/pmc_conv2.py pmc $(ls /tmp/pm_FETCH_SIZE/*/*_counter_collection.csv | head -1) $(ls /tmp/pm_WRITE_SIZE/*/*_counter_collection.csv | head -1) $O/roofline_leg.json > $O/pmc_conv2_traffic.json
+cp $O/pmc_conv2_traffic.json $R/profiles/r04_pmc_conv2_traffic.json      # bench.py's roofline.traffic reads the round's file (same tree, same run)
 echo "step 3 done"
 # 4. plain default bench line (no profiler)
 cd $R && python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
@@ -22,3 +23,6 @@ echo "step 4 done"
 # 5. per-grid breakdown of one lock-step step, one sub-group alone on the GPU
 for G in 1 2 3 5; do TOPN=400 GROUP=$G STEPS=$((12 * G)) bash $R/tools/prof_step.sh > $O/group${G}_step_breakdown.txt 2>&1; done
 echo "step 5 done"
+# 6. BASELINE config 4's per-rank problem at N = 1 (one model, 128x128x64 volumes, 2 patients per step): a full bench line
+cd $R && python3 bench.py --mode ddp --volume 128 128 64 --batch 2 --cpu-steps 3 > $O/c4_rank_bench.json 2> $O/c4_rank_bench.err
+echo "step 6 done"
