@@ -90,12 +90,25 @@ __device__ unsigned long long* c3s_ts_buf = nullptr;
         asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);                                                             \
     }
 
+// Placement (speed only, results unchanged): workgroups are dealt round-robin over the 8 XCDs by flat id, and WHICH weights a workgroup
+// reads is decided by its (model, output-channel half) pair.  The pair is therefore taken from flat % pairs and the row tile from
+// flat / pairs: an XCD's L2 then serves ONE pair when the pair count divides 8 (1, 2, 4, 8: one or two models per launch) and half of them
+// otherwise -- with (tile, half, model) = blockIdx every L2 fetched every model's 442 KB per layer (PMC: 2.9x the algorithmic bytes of the forward).
+__device__ __forceinline__ void c3s_place(int& tile, int& half, int& model) {
+    const int gy = gridDim.y, pairs = gy * (int)gridDim.z;
+    const int flat = blockIdx.x + gridDim.x * (blockIdx.y + gy * blockIdx.z);
+    const int pr = flat % pairs;
+    tile = flat / pairs; model = pr / gy; half = pr - model * gy;
+}
+
 // ---- forward: out[m][co] = sum_tap sum_cin relu(bn2(y1))[m + off(tap)][cin] * W[co][tap][cin] --------------------------------------
 template <int JN, int D, bool FRAG>
 __global__ __launch_bounds__(256) void conv3s_fwd_kernel(const Grp<Conv3FwdP> grp) {
     // every kernel argument the prologue needs, read ONCE into registers: left as references into the kernarg segment the compiler
     // re-loads them (s_load + wait) inside each predicated load below -- 30 serial scalar round trips, 3.3 us before the first MFMA
-    const Conv3FwdP& p = grp.p[blockIdx.z];
+    int tile_, half_, model_;
+    c3s_place(tile_, half_, model_);
+    const Conv3FwdP& p = grp.p[model_];
     const float* __restrict__ y1 = p.y1;
     const float* __restrict__ wp = p.wp;
     const int* __restrict__ coords = p.coords;
@@ -103,7 +116,7 @@ __global__ __launch_bounds__(256) void conv3s_fwd_kernel(const Grp<Conv3FwdP> gr
     const Dims3 g = p.g;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, h = lane >> 4;
-    const int m0 = blockIdx.x * C3S_TM, co0 = JN == 1 ? 16 * (int)blockIdx.y : 0;
+    const int m0 = tile_ * C3S_TM, co0 = JN == 1 ? 16 * half_ : 0;
     const int W = g.W, HW = g.H * g.W, halo = HW + W + 1, nrows = C3S_TM + 2 * halo;
     C3S_TS_DECL;
     C3S_STAMP(0);
@@ -205,7 +218,9 @@ __global__ __launch_bounds__(256) void conv3s_fwd_kernel(const Grp<Conv3FwdP> gr
 // ---- backward-data: dbn2[m][cin] = [a2 > 0] * sum_tap sum_co dz[m - off(tap)][co] * W[cin][tap][co]; BatchNorm2-backward sums -------
 template <int JN, int D, bool FRAG>
 __global__ __launch_bounds__(256) void conv3s_bwd_data_kernel(const Grp<Conv3BwdDataP> grp) {
-    const Conv3BwdDataP& p = grp.p[blockIdx.z];
+    int tile_, half_, model_;
+    c3s_place(tile_, half_, model_);
+    const Conv3BwdDataP& p = grp.p[model_];
     const float* __restrict__ dz = p.dz;               // kernel arguments read once (see conv3s_fwd_kernel)
     const float* __restrict__ wpb = p.wpb;
     const float* __restrict__ y1 = p.y1;
@@ -215,8 +230,8 @@ __global__ __launch_bounds__(256) void conv3s_bwd_data_kernel(const Grp<Conv3Bwd
     const BnSrc bn = p.bn;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, h = lane >> 4;
-    const int m0 = blockIdx.x * C3S_TM;
-    const int cin0 = (JN == 1 ? 64 * (int)blockIdx.y : 0) + 16 * JN * wave;      // this wave's first output column
+    const int m0 = tile_ * C3S_TM;
+    const int cin0 = (JN == 1 ? 64 * half_ : 0) + 16 * JN * wave;      // this wave's first output column
     const int W = g.W, HW = g.H * g.W, halo = HW + W + 1, nrows = C3S_TM + 2 * halo;
 
     // dz window: 8 threads per row (32 channels), 32 rows per pass; clamped addresses, rows outside [0, M) zeroed when staged
