@@ -11,7 +11,7 @@ extern "C" int mms_abi_sizeof(const char* name) {
 extern "C" int mms_abi_version(void) { return 3; }
 // nonzero = a timing-ablation build (MMS_CXXFLAGS=-DMMS_ABLATE_* / -D*_TIMING): its numbers are diagnostics, its results may be wrong
 extern "C" int mms_ablation_build(void) {
-#if defined(MMS_ABLATE_STEP) || defined(MMS_ABLATE_SETUP) || defined(MMS_ABLATE_FLUSH) || defined(B4_TIMING) || defined(C3S_TIMING)
+#if defined(MMS_ABLATE_STEP) || defined(MMS_ABLATE_SETUP) || defined(MMS_ABLATE_FLUSH) || defined(MMS_ABLATE_STATS) || defined(B4_TIMING) || defined(C3S_TIMING) || defined(C3M_TIMING)
     return 1;
 #else
     return 0;
