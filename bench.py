@@ -665,7 +665,8 @@ def run_config2(args, world, rank, dev):
             "value": world * args.steps * B / dt, "unit": "patients/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if world > 1 else None,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("BASELINE config 4's per-rank problem (--mode ddp: ONE model, this rank's shard of the global batch per step)"
+            "config": {"workload": (("BASELINE config 4's per-rank problem (--mode ddp: ONE model, this rank's shard of the global batch per step)" if world == 1 else
+                                     "BASELINE config 4's step (--mode ddp: ONE model data-parallel over %d ranks, global batch %d)" % (world, world * B))
                                     if one else "BASELINE config 2") +
                                    ": MultiModalSurvivalNet (DenseNet121-3D CT %dx%dx%d + RNA-seq 5005 + clinical), "
                                    "109 synthetic complete patients, 5-fold split, batch %d%s, Adam lr 1e-4 wd 1e-4, clip 1.0" % (dims + (B, " per rank" if one else "")),
